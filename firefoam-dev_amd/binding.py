@@ -1,0 +1,375 @@
+"""ctypes binding of include/ffm.h (libffm.so, HIP kernels for gfx950).
+
+Host-side mirror of the OpenFOAM interface on the reference's hot path:
+``lduMatrix`` (Amul/Tmul/sumA/residual, solver/pEqn.H:5,39) and
+``lduMatrix::solver::New(...)->solve(psi, source)`` with the fvSolution keywords
+(solver, preconditioner/smoother, tolerance, relTol, minIter, maxIter, nSweeps;
+cases/steckler/system/fvSolution:21-61).  Device fields are torch CUDA tensors
+(fp64); torch is plumbing only (memory + process launch).
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(_HERE, "lib", "libffm.so")
+_HDR = os.path.join(_ROOT, "include", "ffm.h")
+
+SOLVERS = {"PCG": 0, "PBiCGStab": 1, "PBiCG": 2, "diagonal": 3, "smoothSolver": 4}
+PRECONDS = {"none": 0, "DIC": 1, "DILU": 2, "GaussSeidel": 3, "symGaussSeidel": 4, "diagonal": 5}
+
+
+class FfmError(RuntimeError):
+    pass
+
+
+class Perf(C.Structure):
+    _fields_ = [("initialResidual", C.c_double), ("finalResidual", C.c_double),
+                ("nIterations", C.c_int), ("converged", C.c_int), ("singular", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+HOST_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+def libpath():
+    return _SO
+
+
+def build(force=False):
+    """Compile csrc/*.hip for gfx950 into lib/libffm.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return _SO
+
+
+def declared_symbols():
+    """Function names declared in include/ffm.h."""
+    txt = open(_HDR).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ffm_[a-z0-9_]+)\s*\(", txt)) - {"ffm_host_allreduce_fn", "ffm_host_exchange_fn"})
+
+
+def exported_symbols():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _SO], text=True)
+    return sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("ffm_"))
+
+
+_lib = None
+
+
+def lib():
+    """Load libffm.so.  torch is imported first so that the HIP/RCCL runtime libraries
+    already in the process (same SONAMEs) are the ones libffm binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise FfmError("libffm.so is not built (%s); run __graft_entry__.build() -- there is no CPU fallback" % _SO)
+    import torch  # noqa: F401
+    L = C.CDLL(_SO, mode=C.RTLD_GLOBAL)
+    vp, dp, ip = C.c_void_p, C.c_void_p, C.POINTER(C.c_int)   # device pointers travel as void*
+    hp = C.POINTER(C.c_double)
+    sig = {
+        "ffm_ctx_create": ([C.c_int, vp, C.POINTER(vp)], C.c_int),
+        "ffm_ctx_destroy": ([vp], C.c_int),
+        "ffm_ctx_sync": ([vp], C.c_int),
+        "ffm_ctx_stream": ([vp], vp),
+        "ffm_last_error": ([], C.c_char_p),
+        "ffm_version": ([], C.c_char_p),
+        "ffm_ldu_create": ([vp, C.c_int, C.c_int, ip, ip, C.POINTER(vp)], C.c_int),
+        "ffm_ldu_destroy": ([vp], C.c_int),
+        "ffm_ldu_ncells": ([vp], C.c_int),
+        "ffm_ldu_nfaces": ([vp], C.c_int),
+        "ffm_ldu_nlevels": ([vp], C.c_int),
+        "ffm_ldu_is_native_order": ([vp], C.c_int),
+        "ffm_ldu_get_cell_order": ([vp, ip], C.c_int),
+        "ffm_renumber_levels": ([C.c_int, C.c_int, ip, ip, ip, ip], C.c_int),
+        "ffm_ldu_set_coeffs": ([vp, hp, hp, hp], C.c_int),
+        "ffm_ldu_set_coeffs_d": ([vp, dp, dp, dp], C.c_int),
+        "ffm_ldu_set_interfaces": ([vp, C.c_int, ip, C.POINTER(ip), C.POINTER(hp), C.POINTER(hp), ip], C.c_int),
+        "ffm_ldu_set_global_cells": ([vp, C.c_long], C.c_int),
+        "ffm_spmv": ([vp, dp, dp], C.c_int),
+        "ffm_tmul": ([vp, dp, dp], C.c_int),
+        "ffm_sumA": ([vp, dp], C.c_int),
+        "ffm_residual": ([vp, dp, dp, dp], C.c_int),
+        "ffm_precond_setup": ([vp, C.c_int, dp], C.c_int),
+        "ffm_precond_apply": ([vp, C.c_int, C.c_int, dp, dp], C.c_int),
+        "ffm_gs_smooth": ([vp, C.c_int, C.c_int, dp, dp], C.c_int),
+        "ffm_solve_d": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, dp, dp,
+                         C.POINTER(Perf)], C.c_int),
+        "ffm_solve": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, hp, hp,
+                       C.POINTER(Perf)], C.c_int),
+        "ffm_bench_spmv": ([vp, dp, dp, C.c_int, hp], C.c_int),
+        "ffm_reduce_sum": ([vp, dp, C.c_long, hp], C.c_int),
+        "ffm_reduce_min": ([vp, dp, C.c_long, hp], C.c_int),
+        "ffm_reduce_max": ([vp, dp, C.c_long, hp], C.c_int),
+        "ffm_reduce_dot": ([vp, dp, dp, C.c_long, hp], C.c_int),
+        "ffm_reduce_summag": ([vp, dp, C.c_long, hp], C.c_int),
+        "ffm_comm_unique_id": ([vp], C.c_int),
+        "ffm_comm_init": ([vp, C.c_int, C.c_int, vp], C.c_int),
+        "ffm_comm_init_host": ([vp, C.c_int, C.c_int, vp, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN], C.c_int),
+        "ffm_comm_rank": ([vp], C.c_int),
+        "ffm_comm_size": ([vp], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes, fn.restype = args, res
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise FfmError("%s failed (%d): %s" % (what, rc, lib().ffm_last_error().decode()))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def renumber_levels(nCells, lowerAddr, upperAddr):
+    """Level-major renumbering (pure host code in libffm): returns (newToOldCell, newToOldFace)."""
+    l = np.ascontiguousarray(lowerAddr, np.int32)
+    u = np.ascontiguousarray(upperAddr, np.int32)
+    c2 = np.empty(nCells, np.int32)
+    f2 = np.empty(len(l), np.int32)
+    _check(lib().ffm_renumber_levels(nCells, len(l), _ip(l), _ip(u), _ip(c2), _ip(f2)), "ffm_renumber_levels")
+    return c2, f2
+
+
+class Context:
+    """One GPU, one stream (ffm_ctx)."""
+
+    def __init__(self, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise FfmError("no GPU visible: the HIP path has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(device)
+        h = C.c_void_p()
+        _check(lib().ffm_ctx_create(device, None, C.byref(h)), "ffm_ctx_create")
+        self.h = h
+        self._cb = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ffm_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        _check(lib().ffm_ctx_sync(self.h), "ffm_ctx_sync")
+
+    def to_device(self, a):
+        return self.torch.as_tensor(np.ascontiguousarray(a, np.float64), device=self.device)
+
+    def empty(self, n):
+        return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
+
+    def zeros(self, n):
+        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+
+    def _ready(self):
+        # tensors produced on torch's stream must be complete before libffm's stream reads them
+        self.torch.cuda.current_stream().synchronize()
+
+    def comm_init_rccl(self, rank, nRanks, unique_id_bytes):
+        buf = C.create_string_buffer(bytes(unique_id_bytes), 128)
+        _check(lib().ffm_comm_init(self.h, rank, nRanks, buf), "ffm_comm_init")
+
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().ffm_comm_unique_id(buf), "ffm_comm_unique_id")
+        return buf.raw
+
+    def comm_init_host(self, rank, nRanks, allreduce, exchange):
+        """allreduce(np_array_inplace, op) / exchange(sizes, ranks, offsets, send_np, recv_np)."""
+        def _ar(user, vals, n, op):
+            allreduce(np.ctypeslib.as_array(vals, shape=(n,)), op)
+
+        def _ex(user, nP, size, rank_, off, send, recv):
+            sizes = [size[i] for i in range(nP)]
+            ranks = [rank_[i] for i in range(nP)]
+            offs = [off[i] for i in range(nP)]
+            tot = sum(sizes)
+            exchange(sizes, ranks, offs, np.ctypeslib.as_array(send, shape=(tot,)),
+                     np.ctypeslib.as_array(recv, shape=(tot,)))
+        self._cb = (HOST_ALLREDUCE_FN(_ar), HOST_EXCHANGE_FN(_ex))
+        _check(lib().ffm_comm_init_host(self.h, rank, nRanks, None, self._cb[0], self._cb[1]), "ffm_comm_init_host")
+
+    def _reduce(self, fn, *tensors):
+        self._ready()
+        out = C.c_double()
+        args = [self.h] + [C.c_void_p(t.data_ptr()) for t in tensors] + [tensors[0].numel(), C.byref(out)]
+        _check(fn(*args), "ffm_reduce")
+        return out.value
+
+    def gSum(self, x):
+        return self._reduce(lib().ffm_reduce_sum, x)
+
+    def gMin(self, x):
+        return self._reduce(lib().ffm_reduce_min, x)
+
+    def gMax(self, x):
+        return self._reduce(lib().ffm_reduce_max, x)
+
+    def gSumProd(self, x, y):
+        return self._reduce(lib().ffm_reduce_dot, x, y)
+
+    def gSumMag(self, x):
+        return self._reduce(lib().ffm_reduce_summag, x)
+
+
+class lduMatrix:
+    """Device lduMatrix over lduAddressing (lowerAddr, upperAddr)."""
+
+    def __init__(self, ctx, nCells, lowerAddr, upperAddr):
+        self.ctx = ctx
+        l = np.ascontiguousarray(lowerAddr, np.int32)
+        u = np.ascontiguousarray(upperAddr, np.int32)
+        h = C.c_void_p()
+        _check(lib().ffm_ldu_create(ctx.h, int(nCells), len(l), _ip(l), _ip(u), C.byref(h)), "ffm_ldu_create")
+        self.h = h
+        self.nCells, self.nFaces = int(nCells), len(l)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ffm_ldu_destroy(self.h)
+            self.h = None
+
+    @property
+    def nLevels(self):
+        return lib().ffm_ldu_nlevels(self.h)
+
+    @property
+    def native_order(self):
+        return bool(lib().ffm_ldu_is_native_order(self.h))
+
+    def cell_order(self):
+        o = np.empty(self.nCells, np.int32)
+        _check(lib().ffm_ldu_get_cell_order(self.h, _ip(o)), "ffm_ldu_get_cell_order")
+        return o
+
+    def set_coeffs(self, diag, upper, lower=None):
+        """diag()/upper()/lower(); numpy (host) or torch CUDA tensors (device)."""
+        T = self.ctx.torch
+        if T.is_tensor(diag):
+            self.ctx._ready()
+            lo = None if lower is None else C.c_void_p(lower.data_ptr())
+            _check(lib().ffm_ldu_set_coeffs_d(self.h, C.c_void_p(diag.data_ptr()), C.c_void_p(upper.data_ptr()), lo),
+                   "ffm_ldu_set_coeffs_d")
+            self.ctx.sync()
+        else:
+            d = np.ascontiguousarray(diag, np.float64)
+            u = np.ascontiguousarray(upper, np.float64)
+            lo = None if lower is None else np.ascontiguousarray(lower, np.float64)
+            _check(lib().ffm_ldu_set_coeffs(self.h, _hp(d), _hp(u), None if lo is None else _hp(lo)), "ffm_ldu_set_coeffs")
+        return self
+
+    def set_interfaces(self, faceCells, bouCoeffs, neighbRank, intCoeffs=None, globalCells=None):
+        n = len(faceCells)
+        fc = [np.ascontiguousarray(a, np.int32) for a in faceCells]
+        bc = [np.ascontiguousarray(a, np.float64) for a in bouCoeffs]
+        ic = bc if intCoeffs is None else [np.ascontiguousarray(a, np.float64) for a in intCoeffs]
+        sizes = (C.c_int * n)(*[len(a) for a in fc])
+        ranks = (C.c_int * n)(*[int(r) for r in neighbRank])
+        fcp = (C.POINTER(C.c_int) * n)(*[_ip(a) for a in fc])
+        bcp = (C.POINTER(C.c_double) * n)(*[_hp(a) for a in bc])
+        icp = (C.POINTER(C.c_double) * n)(*[_hp(a) for a in ic])
+        _check(lib().ffm_ldu_set_interfaces(self.h, n, sizes, fcp, bcp, icp, ranks), "ffm_ldu_set_interfaces")
+        if globalCells is not None:
+            _check(lib().ffm_ldu_set_global_cells(self.h, int(globalCells)), "ffm_ldu_set_global_cells")
+        return self
+
+    def _unary(self, fn, x, what):
+        self.ctx._ready()
+        y = self.ctx.empty(self.nCells)
+        _check(fn(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())), what)
+        self.ctx.sync()
+        return y
+
+    def Amul(self, psi):
+        return self._unary(lib().ffm_spmv, psi, "ffm_spmv")
+
+    def Tmul(self, psi):
+        return self._unary(lib().ffm_tmul, psi, "ffm_tmul")
+
+    def sumA(self):
+        s = self.ctx.empty(self.nCells)
+        _check(lib().ffm_sumA(self.h, C.c_void_p(s.data_ptr())), "ffm_sumA")
+        self.ctx.sync()
+        return s
+
+    def residual(self, psi, source):
+        self.ctx._ready()
+        r = self.ctx.empty(self.nCells)
+        _check(lib().ffm_residual(self.h, C.c_void_p(psi.data_ptr()), C.c_void_p(source.data_ptr()),
+                                  C.c_void_p(r.data_ptr())), "ffm_residual")
+        self.ctx.sync()
+        return r
+
+    def reciprocalD(self, preconditioner):
+        rD = self.ctx.empty(self.nCells)
+        _check(lib().ffm_precond_setup(self.h, PRECONDS[preconditioner], C.c_void_p(rD.data_ptr())), "ffm_precond_setup")
+        return rD
+
+    def precondition(self, preconditioner, rA, transpose=False):
+        self.ctx._ready()
+        w = self.ctx.empty(self.nCells)
+        _check(lib().ffm_precond_apply(self.h, PRECONDS[preconditioner], 1 if transpose else 0,
+                                       C.c_void_p(rA.data_ptr()), C.c_void_p(w.data_ptr())), "ffm_precond_apply")
+        return w
+
+    def smooth(self, psi, source, nSweeps=1, smoother="symGaussSeidel"):
+        self.ctx._ready()
+        psi = psi.clone()
+        self.ctx._ready()
+        _check(lib().ffm_gs_smooth(self.h, 1 if smoother == "symGaussSeidel" else 0, nSweeps,
+                                   C.c_void_p(psi.data_ptr()), C.c_void_p(source.data_ptr())), "ffm_gs_smooth")
+        return psi
+
+    def solve(self, psi, source, solver="PCG", preconditioner="DIC", smoother=None, tolerance=1e-6,
+              relTol=0.0, minIter=0, maxIter=1000, nSweeps=1):
+        """lduMatrix::solver::New(dict)->solve(psi, source): psi (torch CUDA fp64) is updated in place.
+        Returns the SolverPerformance as a dict."""
+        self.ctx._ready()
+        p = PRECONDS[smoother if (solver == "smoothSolver" and smoother) else preconditioner]
+        perf = Perf()
+        _check(lib().ffm_solve_d(self.h, SOLVERS[solver], p, tolerance, relTol, minIter, maxIter, nSweeps,
+                                 C.c_void_p(psi.data_ptr()), C.c_void_p(source.data_ptr()), C.byref(perf)), "ffm_solve_d")
+        return perf.as_dict()
+
+    def solve_host(self, psi, source, solver="PCG", preconditioner="DIC", smoother=None, tolerance=1e-6,
+                   relTol=0.0, minIter=0, maxIter=1000, nSweeps=1):
+        """Same through host pointers (what an OpenFOAM-side shim calls): returns (psi, perf)."""
+        psi = np.ascontiguousarray(psi, np.float64).copy()
+        b = np.ascontiguousarray(source, np.float64)
+        p = PRECONDS[smoother if (solver == "smoothSolver" and smoother) else preconditioner]
+        perf = Perf()
+        _check(lib().ffm_solve(self.h, SOLVERS[solver], p, tolerance, relTol, minIter, maxIter, nSweeps,
+                               _hp(psi), _hp(b), C.byref(perf)), "ffm_solve")
+        return psi, perf.as_dict()
+
+    def bench_Amul(self, x, reps=20):
+        self.ctx._ready()
+        y = self.ctx.empty(self.nCells)
+        ms = C.c_double()
+        _check(lib().ffm_bench_spmv(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), reps, C.byref(ms)),
+               "ffm_bench_spmv")
+        return ms.value

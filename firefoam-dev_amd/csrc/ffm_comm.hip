@@ -1,0 +1,235 @@
+// ffm_comm.hip -- the Pstream replacement: processor-patch halo exchange and
+// scalar all-reduces, one process per GPU, RCCL over xGMI.
+//
+// Replaces (OpenFOAM-dev @940e28f, not vendored in the reference):
+//   src/Pstream/mpi/UPstream.C, src/OpenFOAM/db/IOstreams/Pstreams/*  (reduce, gSum*)
+//   src/OpenFOAM/matrices/lduMatrix/lduMatrix/lduMatrixUpdateMatrixInterfaces.C
+//   src/finiteVolume/fields/fvPatchFields/constraint/processor/processorFvPatchField.C
+// Reference-side use: `mpirun -np 2 fireFoam -parallel`
+// (cases/wallFireSpread2D/runParallel.sh:18); collectives C1-C7 of SURVEY 2.4.
+//
+// Halo (C1): one tiny pack kernel gathers psi[faceCells] of every processor
+// patch into one contiguous send buffer; the patches are exchanged in a single
+// ncclGroup of ncclSend/ncclRecv pairs on the context stream (xGMI gives every
+// peer its own link, so the <=6 neighbours of a block decomposition proceed in
+// parallel); an apply kernel then adds coeff*neighbourValue to the boundary
+// cells, one thread per boundary cell, terms in (patch, face) order.
+// Dots (C2, C3): the device scalars are all-reduced in place with
+// ncclAllReduce on the same stream; no host round trip.
+//
+// A second transport (host callbacks) lets several ranks share one GPU, which
+// is how the decomposed path is tested on a single-GPU box; it stages the halo
+// through pinned host memory and calls back into the launcher (gloo/MPI).
+#include "ffm_internal.hpp"
+#include "ffm_device.hpp"
+#include <rccl/rccl.h>
+#include <algorithm>
+
+#define FFM_NCCL(call)                                                           \
+    do {                                                                         \
+        ncclResult_t r_ = (call);                                                \
+        if (r_ != ncclSuccess) {                                                 \
+            ffm_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call,           \
+                          ncclGetErrorString(r_));                               \
+            return FFM_ERR_COMM;                                                 \
+        }                                                                        \
+    } while (0)
+
+extern "C" int ffm_comm_unique_id(void *uniqueId128)
+{
+    if (!uniqueId128) return FFM_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    FFM_NCCL(ncclGetUniqueId(&id));
+    memcpy(uniqueId128, &id, sizeof(id));
+    return FFM_OK;
+}
+
+extern "C" int ffm_comm_init(ffm_ctx *c, int rank, int nRanks, const void *uniqueId128)
+{
+    if (!c || rank < 0 || nRanks < 1 || rank >= nRanks) return FFM_ERR_ARG;
+    c->rank = rank; c->nRanks = nRanks;
+    if (nRanks == 1) return FFM_OK;
+    if (!uniqueId128) return FFM_ERR_ARG;
+    FFM_HIP(hipSetDevice(c->device));
+    ncclUniqueId id; memcpy(&id, uniqueId128, sizeof(id));
+    ncclComm_t comm;
+    FFM_NCCL(ncclCommInitRank(&comm, nRanks, id, rank));
+    c->comm = (ncclComm *)comm;
+    return FFM_OK;
+}
+
+extern "C" int ffm_comm_init_host(ffm_ctx *c, int rank, int nRanks, void *user, ffm_host_allreduce_fn ar,
+                                  ffm_host_exchange_fn ex)
+{
+    if (!c || rank < 0 || nRanks < 1 || rank >= nRanks || (nRanks > 1 && (!ar || !ex))) return FFM_ERR_ARG;
+    c->rank = rank; c->nRanks = nRanks; c->hostUser = user; c->hostAllreduce = ar; c->hostExchange = ex;
+    return FFM_OK;
+}
+
+void ffm_comm_finalize_i(ffm_ctx *c)
+{
+    if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+}
+
+extern "C" int ffm_comm_rank(const ffm_ctx *c) { return c ? c->rank : FFM_ERR_ARG; }
+extern "C" int ffm_comm_size(const ffm_ctx *c) { return c ? c->nRanks : FFM_ERR_ARG; }
+
+int ffm_allreduce_slots(ffm_ctx *c, int firstSlot, int n)
+{
+    if (c->nRanks <= 1) return FFM_OK;
+    if (c->comm) {
+        FFM_NCCL(ncclAllReduce(c->scal_d + firstSlot, c->scal_d + firstSlot, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+        return FFM_OK;
+    }
+    if (!c->hostAllreduce) { ffm_set_error("nRanks>1 but no communicator attached"); return FFM_ERR_COMM; }
+    FFM_HIP(hipMemcpyAsync(c->scal_h + firstSlot, c->scal_d + firstSlot, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    c->hostAllreduce(c->hostUser, c->scal_h + firstSlot, n, 0);
+    FFM_HIP(hipMemcpyAsync(c->scal_d + firstSlot, c->scal_h + firstSlot, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    return FFM_OK;
+}
+
+int ffm_allreduce_minmax(ffm_ctx *c, int slot, int isMax)
+{
+    if (c->nRanks <= 1) return FFM_OK;
+    if (c->comm) {
+        FFM_NCCL(ncclAllReduce(c->scal_d + slot, c->scal_d + slot, 1, ncclDouble, isMax ? ncclMax : ncclMin, (ncclComm_t)c->comm, c->stream));
+        return FFM_OK;
+    }
+    if (!c->hostAllreduce) { ffm_set_error("nRanks>1 but no communicator attached"); return FFM_ERR_COMM; }
+    FFM_HIP(hipMemcpyAsync(c->scal_h + slot, c->scal_d + slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    c->hostAllreduce(c->hostUser, c->scal_h + slot, 1, isMax ? 2 : 1);
+    FFM_HIP(hipMemcpyAsync(c->scal_d + slot, c->scal_h + slot, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    return FFM_OK;
+}
+
+// --------------------------------------------------------------- interfaces ---
+extern "C" int ffm_ldu_set_interfaces(ffm_ldu *A, int nPatches, const int *patchSizes, const int *const *faceCells,
+                                      const double *const *bouCoeffs, const double *const *intCoeffs, const int *neighbRank)
+{
+    if (!A || nPatches < 0 || (nPatches && (!patchSizes || !faceCells || !bouCoeffs || !neighbRank))) return FFM_ERR_ARG;
+    ffm_ctx *c = A->ctx;
+    hipStreamSynchronize(c->stream);
+    hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);
+    hipFree(A->ifCell); hipFree(A->ifCellStart); hipFree(A->ifItem);
+    if (A->haloSend_h) { hipHostFree(A->haloSend_h); A->haloSend_h = nullptr; }
+    if (A->haloRecv_h) { hipHostFree(A->haloRecv_h); A->haloRecv_h = nullptr; }
+    A->ifFaceCells = nullptr; A->ifBou = A->ifInt = A->haloSend = A->haloRecv = nullptr;
+    A->ifCell = A->ifCellStart = A->ifItem = nullptr;
+    A->ifaces.clear(); A->haloTotal = 0; A->nIfCells = 0;
+    for (auto &kv : A->graphs) hipGraphExecDestroy(kv.second);   // halo buffers are baked into no graph, but be safe
+    A->graphs.clear();
+    if (!nPatches) return FFM_OK;
+    // old -> new cell map
+    std::vector<int> oldToNew(A->nCells);
+    for (int i = 0; i < A->nCells; i++) oldToNew[A->h_newToOldCell[i]] = i;
+    int total = 0;
+    for (int p = 0; p < nPatches; p++) {
+        if (patchSizes[p] < 0 || neighbRank[p] < 0 || neighbRank[p] >= std::max(c->nRanks, 1)) { ffm_set_error("interface %d: bad size or rank", p); return FFM_ERR_ARG; }
+        ffm_iface f; f.size = patchSizes[p]; f.nbrRank = neighbRank[p]; f.offset = total; total += f.size;
+        A->ifaces.push_back(f);
+    }
+    A->haloTotal = total;
+    std::vector<int> fc(total); std::vector<double> bou(total), in(total);
+    for (int p = 0; p < nPatches; p++) for (int i = 0; i < patchSizes[p]; i++) {
+        const int oc = faceCells[p][i];
+        if (oc < 0 || oc >= A->nCells) { ffm_set_error("interface %d: faceCell out of range", p); A->ifaces.clear(); A->haloTotal = 0; return FFM_ERR_ARG; }
+        const int k = A->ifaces[p].offset + i;
+        fc[k] = oldToNew[oc]; bou[k] = bouCoeffs[p][i];
+        in[k] = (intCoeffs && intCoeffs[p]) ? intCoeffs[p][i] : bouCoeffs[p][i];
+    }
+    // group packed items by cell, keeping (patch, face) order inside a cell
+    std::vector<int> order(total);
+    for (int k = 0; k < total; k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fc[a] < fc[b]; });
+    std::vector<int> cells, start;
+    for (int j = 0; j < total; j++) {
+        if (j == 0 || fc[order[j]] != fc[order[j - 1]]) { cells.push_back(fc[order[j]]); start.push_back(j); }
+    }
+    start.push_back(total);
+    A->nIfCells = (int)cells.size();
+    const size_t tb = sizeof(double) * std::max(total, 1), ti = sizeof(int) * std::max(total, 1);
+    FFM_HIP(hipMalloc((void **)&A->ifFaceCells, ti)); FFM_HIP(hipMalloc((void **)&A->ifBou, tb)); FFM_HIP(hipMalloc((void **)&A->ifInt, tb));
+    FFM_HIP(hipMalloc((void **)&A->haloSend, tb)); FFM_HIP(hipMalloc((void **)&A->haloRecv, tb));
+    FFM_HIP(hipMalloc((void **)&A->ifCell, sizeof(int) * std::max(A->nIfCells, 1)));
+    FFM_HIP(hipMalloc((void **)&A->ifCellStart, sizeof(int) * (A->nIfCells + 1)));
+    FFM_HIP(hipMalloc((void **)&A->ifItem, ti));
+    FFM_HIP(hipHostMalloc((void **)&A->haloSend_h, tb, hipHostMallocDefault));
+    FFM_HIP(hipHostMalloc((void **)&A->haloRecv_h, tb, hipHostMallocDefault));
+    FFM_HIP(hipMemcpy(A->ifFaceCells, fc.data(), sizeof(int) * total, hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(A->ifBou, bou.data(), sizeof(double) * total, hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(A->ifInt, in.data(), sizeof(double) * total, hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(A->ifCell, cells.data(), sizeof(int) * cells.size(), hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(A->ifCellStart, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(A->ifItem, order.data(), sizeof(int) * total, hipMemcpyHostToDevice));
+    return FFM_OK;
+}
+
+__global__ void k_halo_pack(int n, const int *__restrict__ fc, const double *__restrict__ x, double *__restrict__ send)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) send[i] = x[fc[i]];
+}
+
+// y[cell] (+/-)= coeff[item]*val[item] for the items of each boundary cell, in (patch, face) order
+__global__ void k_halo_apply(int nCells, const int *__restrict__ cell, const int *__restrict__ start,
+                             const int *__restrict__ item, const double *__restrict__ coeff,
+                             const double *__restrict__ val, double *__restrict__ y, int subtract)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nCells; j += gridDim.x * blockDim.x) {
+        const int c = cell[j];
+        double acc = y[c];
+        for (int q = start[j]; q < start[j + 1]; q++) {
+            const int k = item[q];
+            const double t = val ? coeff[k] * val[k] : coeff[k];
+            acc = subtract ? acc - t : acc + t;
+        }
+        y[c] = acc;
+    }
+}
+
+int ffm_halo_exchange(ffm_ldu *A, const double *x)
+{
+    ffm_ctx *c = A->ctx;
+    if (A->ifaces.empty()) return FFM_OK;
+    hipLaunchKernelGGL(k_halo_pack, dim3(std::max(1, std::min(ffm_grid(A->haloTotal, 256), 1024))), dim3(256), 0, c->stream,
+                       A->haloTotal, A->ifFaceCells, x, A->haloSend);
+    FFM_HIP(hipGetLastError());
+    if (c->comm) {
+        FFM_NCCL(ncclGroupStart());
+        for (const ffm_iface &p : A->ifaces) {
+            if (!p.size) continue;
+            FFM_NCCL(ncclSend(A->haloSend + p.offset, p.size, ncclDouble, p.nbrRank, (ncclComm_t)c->comm, c->stream));
+            FFM_NCCL(ncclRecv(A->haloRecv + p.offset, p.size, ncclDouble, p.nbrRank, (ncclComm_t)c->comm, c->stream));
+        }
+        FFM_NCCL(ncclGroupEnd());
+        return FFM_OK;
+    }
+    if (!c->hostExchange) { ffm_set_error("processor interfaces set but no communicator attached"); return FFM_ERR_COMM; }
+    const size_t tb = sizeof(double) * A->haloTotal;
+    FFM_HIP(hipMemcpyAsync(A->haloSend_h, A->haloSend, tb, hipMemcpyDeviceToHost, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    std::vector<int> sizes, ranks, offs;
+    for (const ffm_iface &p : A->ifaces) { sizes.push_back(p.size); ranks.push_back(p.nbrRank); offs.push_back(p.offset); }
+    c->hostExchange(c->hostUser, (int)A->ifaces.size(), sizes.data(), ranks.data(), offs.data(), A->haloSend_h, A->haloRecv_h);
+    FFM_HIP(hipMemcpyAsync(A->haloRecv, A->haloRecv_h, tb, hipMemcpyHostToDevice, c->stream));
+    return FFM_OK;
+}
+
+int ffm_halo_apply(ffm_ldu *A, double *y, const double *coeffs, const double *vals, double sign)
+{
+    if (!A->nIfCells) return FFM_OK;
+    hipLaunchKernelGGL(k_halo_apply, dim3(std::max(1, std::min(ffm_grid(A->nIfCells, 256), 1024))), dim3(256), 0, A->ctx->stream,
+                       A->nIfCells, A->ifCell, A->ifCellStart, A->ifItem, coeffs, vals, y, sign < 0 ? 1 : 0);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+int ffm_halo_update(ffm_ldu *A, const double *x, double *y, const double *coeffs, double sign)
+{
+    FFM_TRY(ffm_halo_exchange(A, x));
+    return ffm_halo_apply(A, y, coeffs, A->haloRecv, sign);
+}

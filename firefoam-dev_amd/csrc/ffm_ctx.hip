@@ -1,0 +1,164 @@
+// ffm_ctx.hip -- context, error reporting, device-memory helpers, reductions.
+#include "ffm_internal.hpp"
+#include "ffm_device.hpp"
+#include <cstdarg>
+
+static thread_local char g_err[1024] = "";
+
+void ffm_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *ffm_last_error(void) { return g_err; }
+extern "C" const char *ffm_version(void) { return "ffm 0.1 (gfx950, fp64/int32, fp-contract=off)"; }
+
+extern "C" int ffm_ctx_create(int device, void *stream, ffm_ctx **out)
+{
+    if (!out) return FFM_ERR_ARG;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) {
+        ffm_set_error("ffm_ctx_create: no HIP device visible (the HIP path has no CPU fallback)");
+        return FFM_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= nDev) { ffm_set_error("ffm_ctx_create: device %d of %d", device, nDev); return FFM_ERR_ARG; }
+    FFM_HIP(hipSetDevice(device));
+    ffm_ctx *c = new ffm_ctx();
+    c->device = device;
+    if (stream) { c->stream = (hipStream_t)stream; c->ownStream = false; }
+    else { FFM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownStream = true; }
+    FFM_HIP(hipMalloc((void **)&c->scal_d, sizeof(double) * NSCAL));
+    FFM_HIP(hipMemsetAsync(c->scal_d, 0, sizeof(double) * NSCAL, c->stream));
+    FFM_HIP(hipMalloc((void **)&c->partials_d, sizeof(double) * 4 * RED_BLOCKS));
+    FFM_HIP(hipHostMalloc((void **)&c->scal_h, sizeof(double) * NSCAL, hipHostMallocDefault));
+    hipDeviceProp_t prop;
+    FFM_HIP(hipGetDeviceProperties(&prop, device));
+    c->cuCount = prop.multiProcessorCount;
+    *out = c;
+    return FFM_OK;
+}
+
+extern "C" int ffm_ctx_destroy(ffm_ctx *c)
+{
+    if (!c) return FFM_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    ffm_comm_finalize_i(c);
+    hipFree(c->scal_d); hipFree(c->partials_d); hipHostFree(c->scal_h);
+    if (c->ownStream) hipStreamDestroy(c->stream);
+    delete c;
+    return FFM_OK;
+}
+
+extern "C" int ffm_ctx_sync(ffm_ctx *c) { FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK; }
+extern "C" void *ffm_ctx_stream(ffm_ctx *c) { return (void *)c->stream; }
+
+extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p)
+{ FFM_HIP(hipSetDevice(c->device)); FFM_HIP(hipMalloc(p, bytes ? bytes : 8)); return FFM_OK; }
+extern "C" int ffm_free(ffm_ctx *c, void *p)
+{ FFM_HIP(hipStreamSynchronize(c->stream)); FFM_HIP(hipFree(p)); return FFM_OK; }
+extern "C" int ffm_memcpy_h2d(ffm_ctx *c, void *d, const void *s, size_t n)
+{ FFM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK; }
+extern "C" int ffm_memcpy_d2h(ffm_ctx *c, void *d, const void *s, size_t n)
+{ FFM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK; }
+extern "C" int ffm_memcpy_d2d(ffm_ctx *c, void *d, const void *s, size_t n)
+{ FFM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, c->stream)); return FFM_OK; }
+extern "C" int ffm_memset(ffm_ctx *c, void *d, int v, size_t n)
+{ FFM_HIP(hipMemsetAsync(d, v, n, c->stream)); return FFM_OK; }
+
+int ffm_read_scalars(ffm_ctx *c)
+{
+    FFM_HIP(hipMemcpyAsync(c->scal_h, c->scal_d, sizeof(double) * NSCAL, hipMemcpyDeviceToHost, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    return FFM_OK;
+}
+
+// ------------------------------------------------------------- reductions ---
+// Stage 1: RED_BLOCKS blocks, grid-stride, per-block partial in fixed order.
+// Stage 2: one block sums the partials in fixed order.  No atomics anywhere.
+enum { R_SUM = 0, R_DOT, R_SUMMAG, R_SUMSQR, R_MIN, R_MAX };
+
+template <int OP>
+__global__ __launch_bounds__(RED_THREADS) void k_reduce1(long n, const double *__restrict__ x,
+                                                         const double *__restrict__ y,
+                                                         double *__restrict__ partials)
+{
+    __shared__ double sm[RED_THREADS / 64];
+    double acc = (OP == R_MIN) ? 1.79769313486231570e+308 : (OP == R_MAX) ? -1.79769313486231570e+308 : 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double v = x[i];
+        if (OP == R_SUM) acc += v;
+        else if (OP == R_DOT) acc += v * y[i];
+        else if (OP == R_SUMMAG) acc += fabs(v);
+        else if (OP == R_SUMSQR) acc += v * v;
+        else if (OP == R_MIN) acc = fmin(acc, v);
+        else acc = fmax(acc, v);
+    }
+    double r;
+    if (OP == R_MIN) r = block_min(acc, sm);
+    else if (OP == R_MAX) r = block_max(acc, sm);
+    else r = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+template <int OP>
+__global__ __launch_bounds__(1024) void k_reduce2(int nPartials, const double *__restrict__ partials,
+                                                  double *__restrict__ scal, int slot)
+{
+    __shared__ double sm[16];
+    double acc = (OP == R_MIN) ? 1.79769313486231570e+308 : (OP == R_MAX) ? -1.79769313486231570e+308 : 0.0;
+    for (int i = threadIdx.x; i < nPartials; i += blockDim.x) {
+        double v = partials[i];
+        if (OP == R_MIN) acc = fmin(acc, v);
+        else if (OP == R_MAX) acc = fmax(acc, v);
+        else acc += v;
+    }
+    double r;
+    if (OP == R_MIN) r = block_min(acc, sm);
+    else if (OP == R_MAX) r = block_max(acc, sm);
+    else r = block_sum(acc, sm);
+    if (threadIdx.x == 0) scal[slot] = r;
+}
+
+template <int OP>
+static int reduce_to_slot(ffm_ctx *c, const double *x, const double *y, long n, int slot)
+{
+    int nb = (int)((n + RED_THREADS - 1) / RED_THREADS);
+    if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_reduce1<OP>, dim3(nb), dim3(RED_THREADS), 0, c->stream, n, x, y, c->partials_d);
+    constexpr int OP2 = (OP == R_MIN) ? R_MIN : (OP == R_MAX) ? R_MAX : R_SUM;
+    hipLaunchKernelGGL(k_reduce2<OP2>, dim3(1), dim3(1024), 0, c->stream, nb, c->partials_d, c->scal_d, slot);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+int ffm_k_dot(ffm_ctx *c, const double *x, const double *y, long n, int slot) { return reduce_to_slot<R_DOT>(c, x, y, n, slot); }
+int ffm_k_summag(ffm_ctx *c, const double *x, long n, int slot) { return reduce_to_slot<R_SUMMAG>(c, x, nullptr, n, slot); }
+int ffm_k_sum(ffm_ctx *c, const double *x, long n, int slot) { return reduce_to_slot<R_SUM>(c, x, nullptr, n, slot); }
+int ffm_k_sumsqr(ffm_ctx *c, const double *x, long n, int slot) { return reduce_to_slot<R_SUMSQR>(c, x, nullptr, n, slot); }
+
+template <int OP>
+static int reduce_public(ffm_ctx *c, const double *x, const double *y, long n, double *out)
+{
+    if (!c || !out || n < 0) return FFM_ERR_ARG;
+    FFM_TRY(reduce_to_slot<OP>(c, x, y, n, S_TMP0));
+    if (c->nRanks > 1) {
+        if (OP == R_MIN) FFM_TRY(ffm_allreduce_minmax(c, S_TMP0, 0));
+        else if (OP == R_MAX) FFM_TRY(ffm_allreduce_minmax(c, S_TMP0, 1));
+        else FFM_TRY(ffm_allreduce_slots(c, S_TMP0, 1));
+    }
+    FFM_TRY(ffm_read_scalars(c));
+    *out = c->scal_h[S_TMP0];
+    return FFM_OK;
+}
+
+extern "C" int ffm_reduce_sum(ffm_ctx *c, const double *x, long n, double *o) { return reduce_public<R_SUM>(c, x, nullptr, n, o); }
+extern "C" int ffm_reduce_min(ffm_ctx *c, const double *x, long n, double *o) { return reduce_public<R_MIN>(c, x, nullptr, n, o); }
+extern "C" int ffm_reduce_max(ffm_ctx *c, const double *x, long n, double *o) { return reduce_public<R_MAX>(c, x, nullptr, n, o); }
+extern "C" int ffm_reduce_dot(ffm_ctx *c, const double *x, const double *y, long n, double *o) { return reduce_public<R_DOT>(c, x, y, n, o); }
+extern "C" int ffm_reduce_summag(ffm_ctx *c, const double *x, long n, double *o) { return reduce_public<R_SUMMAG>(c, x, nullptr, n, o); }

@@ -1,0 +1,158 @@
+// ffm_internal.hpp -- private structures of libffm.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/ffm.h"
+
+struct ncclComm;
+
+void ffm_set_error(const char *fmt, ...);
+
+#define FFM_HIP(call)                                                            \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            ffm_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call,           \
+                          hipGetErrorString(e_));                                \
+            return FFM_ERR_HIP;                                                  \
+        }                                                                        \
+    } while (0)
+
+#define FFM_TRY(call)                                                            \
+    do {                                                                         \
+        int r_ = (call);                                                         \
+        if (r_ != FFM_OK) return r_;                                             \
+    } while (0)
+
+// Fixed reduction geometry: every dot product is a two-stage, atomics-free,
+// order-fixed sum (RED_BLOCKS partials, then one block), so results are
+// bitwise reproducible from run to run.
+constexpr int RED_THREADS = 256;
+constexpr int RED_BLOCKS = 2048;
+constexpr int NSCAL = 64;  // device scalar slots per context
+
+// device scalar slots
+enum {
+    S_TMP0 = 0, S_TMP1, S_TMP2, S_TMP3,
+    S_XREF, S_NORMF, S_RES, S_RES0,
+    S_WARA, S_WARA_OLD, S_WAPA, S_ALPHA, S_BETA, S_OMEGA,
+    S_RA0RA, S_RA0RA_OLD, S_RA0AYA, S_TATA, S_TASA,
+    S_SING,      // != 0 => singular flag
+    S_NEG_ALPHA, S_ONE
+};
+
+struct ffm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    double *scal_d = nullptr;      // [NSCAL]
+    double *partials_d = nullptr;  // [4][RED_BLOCKS]
+    double *scal_h = nullptr;      // pinned [NSCAL]
+    // communicator (RCCL); nRanks == 1 => serial
+    int rank = 0, nRanks = 1;
+    ncclComm *comm = nullptr;
+    void *hostUser = nullptr;
+    ffm_host_allreduce_fn hostAllreduce = nullptr;
+    ffm_host_exchange_fn hostExchange = nullptr;
+    int cuCount = 256;
+};
+
+struct SweepGraphKey {
+    int kind; const void *a; const void *b; const void *c;
+    bool operator<(const SweepGraphKey &o) const {
+        return std::tie(kind, a, b, c) < std::tie(o.kind, o.a, o.b, o.c);
+    }
+};
+
+struct ffm_iface {
+    int size = 0, nbrRank = -1;
+    int offset = 0;                 // offset into the packed halo buffers
+};
+
+struct ffm_ldu {
+    ffm_ctx *ctx = nullptr;
+    int nCells = 0, nFaces = 0;
+    long globalCells = 0;
+    bool identity = true;           // caller numbering == internal numbering
+    bool symmetric = true;
+    bool bwdContig = true;          // backward levels are contiguous cell ranges
+
+    // host copies of the analysis (internal numbering)
+    std::vector<int> h_newToOldCell, h_newToOldFace;
+    std::vector<int> h_fwdLevelStart;   // [nLevels+1] cell ranges (level-major)
+    std::vector<int> h_bwdLevelStart;   // [nBwdLevels+1] ranges into bwdOrder
+    std::vector<int> h_bwdFirstCell;    // [nBwdLevels] first cell of each level (bwdContig)
+    int nLevels = 0, nBwdLevels = 0;
+
+    // device addressing (internal numbering)
+    int *lAddr = nullptr, *uAddr = nullptr;      // [F]
+    int *ownStart = nullptr;                     // [N+1]
+    int *loStart = nullptr;                      // [N+1]
+    int *loFace = nullptr;                       // [F] losort (face id)
+    int *loNbr = nullptr;                        // [F] l[losort[k]]
+    int *bwdOrder = nullptr;                     // [N] (only when !bwdContig)
+    int *cellPerm = nullptr;                     // [N] new->old (only when !identity)
+    int *facePerm = nullptr;                     // [F] new->old (only when !identity)
+
+    // coefficients (internal numbering)
+    double *diag = nullptr, *upper = nullptr, *lower = nullptr;  // lower==upper when symmetric
+    double *lowerBuf = nullptr;                                  // storage for asymmetric lower
+
+    // preconditioner state
+    double *rD = nullptr;          // reciprocal diagonal (DIC/DILU/diagonal)
+    int rDKind = -1;               // which preconditioner rD currently holds
+    unsigned long coeffEpoch = 0, rDEpoch = ~0ul;
+
+    // work vectors (internal numbering), allocated on demand
+    std::vector<double *> work;    // [nWork] each N doubles
+    double *permIn[3] = {nullptr, nullptr, nullptr};  // staging for caller-order vectors
+
+    // interfaces (processor patches), packed patch after patch
+    std::vector<ffm_iface> ifaces;
+    int haloTotal = 0;
+    int *ifFaceCells = nullptr;    // [haloTotal] internal numbering
+    double *ifBou = nullptr, *ifInt = nullptr;   // [haloTotal]
+    double *haloSend = nullptr, *haloRecv = nullptr;
+    double *haloSend_h = nullptr, *haloRecv_h = nullptr;   // pinned, host transport only
+    // boundary cells grouped: cell ifCell[j] owns packed items ifItem[ifCellStart[j]..ifCellStart[j+1])
+    // listed in (patch, face) order, so a cell's interface terms are added in the reference's order
+    int nIfCells = 0;
+    int *ifCell = nullptr, *ifCellStart = nullptr, *ifItem = nullptr;
+
+    // cached hipGraphs of level-scheduled sweeps
+    std::map<SweepGraphKey, hipGraphExec_t> graphs;
+};
+
+// ---- internal helpers shared between translation units -------------------
+int ffm_ldu_work(ffm_ldu *A, int idx, double **out);           // lazily allocated N-vectors
+int ffm_to_internal(ffm_ldu *A, const double *x_d, int slot, const double **out);
+int ffm_from_internal(ffm_ldu *A, const double *xin, double *x_d);
+int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose);
+int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot);  // y=Ax, scal[slot]=x.y (local)
+int ffm_k_residual(ffm_ldu *A, const double *x, const double *b, double *r);
+int ffm_k_sumA(ffm_ldu *A, double *s);
+int ffm_halo_update(ffm_ldu *A, const double *x, double *y, const double *coeffs, double sign);  // exchange + apply
+int ffm_halo_apply(ffm_ldu *A, double *y, const double *coeffs, const double *vals /*null => 1*/, double sign);
+int ffm_allreduce_slots(ffm_ctx *ctx, int firstSlot, int n);   // sum over ranks, in stream
+int ffm_allreduce_minmax(ffm_ctx *ctx, int slot, int isMax);
+void ffm_comm_finalize_i(ffm_ctx *ctx);
+int ffm_precond_setup_i(ffm_ldu *A, int precond);
+int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
+int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b);
+int ffm_halo_exchange(ffm_ldu *A, const double *x);          // pack x[faceCells], exchange into haloRecv
+int ffm_read_scalars(ffm_ctx *ctx);  // scal_d -> scal_h, synchronises the stream
+
+// reductions into device scalar slots (local partial sums; caller all-reduces)
+int ffm_k_dot(ffm_ctx *ctx, const double *x, const double *y, long n, int slot);
+int ffm_k_summag(ffm_ctx *ctx, const double *x, long n, int slot);
+int ffm_k_sum(ffm_ctx *ctx, const double *x, long n, int slot);
+int ffm_k_sumsqr(ffm_ctx *ctx, const double *x, long n, int slot);
+
+static inline int ffm_grid(long n, int threads) { return (int)((n + threads - 1) / threads); }

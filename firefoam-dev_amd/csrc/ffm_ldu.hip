@@ -1,0 +1,461 @@
+// ffm_ldu.hip -- lduAddressing analysis (host), device LDU container and the
+// lduMatrix kernels Amul / Tmul / sumA / residual.
+//
+// Replaces (OpenFOAM-dev @940e28f, not vendored in the reference):
+//   src/OpenFOAM/matrices/lduMatrix/lduAddressing/lduAddressing.C
+//   src/OpenFOAM/matrices/lduMatrix/lduMatrix/lduMatrixATmul.C
+// reached from the reference at solver/pEqn.H:5,39, solver/UEqn.H:19,
+// solver/YEEqn.H:60,111.
+//
+// Data layout in HBM (all arrays in the *internal* cell numbering):
+//   cells are ordered level-major: level(c) = longest path to c in the DAG
+//   owner->neighbour, cells of one level contiguous and sorted by the caller's
+//   index.  Every level-scheduled sweep (DIC/DILU/Gauss-Seidel) then touches a
+//   contiguous cell range per level, and the SpMV runs in the same numbering so
+//   no vector is permuted between SpMV and preconditioner.  The renumbering is a
+//   topological order of the same DAG, so owner<neighbour is preserved and the
+//   incomplete factorisations are the same operators as in the caller's
+//   numbering.  A caller whose mesh is already level-major (ffm_renumber_levels)
+//   pays no permutation pass at all.
+//
+//   Row-gather form of the face loops: for cell c
+//     lower part : k in [loStart[c], loStart[c+1])  -> face loFace[k], column loNbr[k]
+//     upper part : f in [ownStart[c], ownStart[c+1]) -> column uAddr[f]
+//   which visits the faces of c in exactly the order of the serial face loop
+//   (all faces with neighbour c precede all faces owned by c), so each row is
+//   accumulated in the reference's order, with no atomics.
+#include "ffm_internal.hpp"
+#include "ffm_device.hpp"
+#include <algorithm>
+#include <numeric>
+
+// ---------------------------------------------------------------- analysis ---
+struct LduAnalysis {
+    std::vector<int> newToOldCell, oldToNewCell, newToOldFace;
+    std::vector<int> l, u;                 // new numbering, upper-triangular order
+    std::vector<int> fwdLevelStart;        // [nLevels+1]
+    std::vector<int> bwdLevelStart;        // [nBwd+1] into bwdOrder
+    std::vector<int> bwdOrder;             // cells sorted by backward level
+    bool identity = true, bwdContig = true;
+};
+
+static int analyse(int N, int F, const int *l, const int *u, bool renumber, LduAnalysis &a)
+{
+    for (int f = 0; f < F; f++) {
+        if (l[f] < 0 || u[f] >= N || l[f] >= u[f]) {
+            ffm_set_error("LDU addressing: face %d has l=%d u=%d (need 0<=l<u<nCells=%d)", f, l[f], u[f], N);
+            return FFM_ERR_ADDR;
+        }
+        if (f && l[f] < l[f - 1]) {
+            ffm_set_error("LDU addressing: faces not sorted by owner at face %d", f);
+            return FFM_ERR_ADDR;
+        }
+    }
+    // forward levels
+    std::vector<int> lev(N, 0);
+    for (int f = 0; f < F; f++) lev[u[f]] = std::max(lev[u[f]], lev[l[f]] + 1);
+    int nLev = 0;
+    for (int c = 0; c < N; c++) nLev = std::max(nLev, lev[c] + 1);
+    if (N == 0) nLev = 0;
+    a.newToOldCell.resize(N); a.oldToNewCell.resize(N);
+    if (renumber) {
+        std::vector<int> start(nLev + 1, 0);
+        for (int c = 0; c < N; c++) start[lev[c] + 1]++;
+        for (int i = 0; i < nLev; i++) start[i + 1] += start[i];
+        a.fwdLevelStart = start;
+        std::vector<int> pos(start.begin(), start.end() - (nLev ? 1 : 0));
+        if (!nLev) pos.clear();
+        for (int c = 0; c < N; c++) { int p = pos[lev[c]]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
+    } else {
+        // caller insists on its numbering: only legal if it is level-major already
+        std::iota(a.newToOldCell.begin(), a.newToOldCell.end(), 0);
+        a.oldToNewCell = a.newToOldCell;
+        a.fwdLevelStart.assign(nLev + 1, 0);
+        for (int c = 0; c < N; c++) a.fwdLevelStart[lev[c] + 1]++;
+        for (int i = 0; i < nLev; i++) a.fwdLevelStart[i + 1] += a.fwdLevelStart[i];
+        for (int c = 1; c < N; c++) if (lev[c] < lev[c - 1]) { ffm_set_error("numbering is not level-major"); return FFM_ERR_ARG; }
+    }
+    a.identity = true;
+    for (int c = 0; c < N; c++) if (a.newToOldCell[c] != c) { a.identity = false; break; }
+    // faces in the new numbering, sorted by (owner, neighbour)
+    a.l.resize(F); a.u.resize(F); a.newToOldFace.resize(F);
+    if (a.identity) {
+        std::copy(l, l + F, a.l.begin()); std::copy(u, u + F, a.u.begin());
+        std::iota(a.newToOldFace.begin(), a.newToOldFace.end(), 0);
+    } else {
+        std::vector<int> cnt(N + 1, 0);
+        for (int f = 0; f < F; f++) cnt[a.oldToNewCell[l[f]] + 1]++;
+        for (int c = 0; c < N; c++) cnt[c + 1] += cnt[c];
+        std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+        for (int f = 0; f < F; f++) a.newToOldFace[pos[a.oldToNewCell[l[f]]]++] = f;
+        for (int c = 0; c < N; c++) {
+            std::sort(a.newToOldFace.begin() + cnt[c], a.newToOldFace.begin() + cnt[c + 1],
+                      [&](int f1, int f2) { return a.oldToNewCell[u[f1]] < a.oldToNewCell[u[f2]]; });
+        }
+        for (int f = 0; f < F; f++) {
+            int of = a.newToOldFace[f];
+            a.l[f] = a.oldToNewCell[l[of]]; a.u[f] = a.oldToNewCell[u[of]];
+            if (a.l[f] >= a.u[f]) { ffm_set_error("internal: renumbering flipped a face"); return FFM_ERR_ADDR; }
+        }
+    }
+    // backward levels (new numbering)
+    std::vector<int> bl(N, 0);
+    for (int f = F - 1; f >= 0; f--) bl[a.l[f]] = std::max(bl[a.l[f]], bl[a.u[f]] + 1);
+    int nB = 0;
+    for (int c = 0; c < N; c++) nB = std::max(nB, bl[c] + 1);
+    if (N == 0) nB = 0;
+    a.bwdLevelStart.assign(nB + 1, 0);
+    for (int c = 0; c < N; c++) a.bwdLevelStart[bl[c] + 1]++;
+    for (int i = 0; i < nB; i++) a.bwdLevelStart[i + 1] += a.bwdLevelStart[i];
+    a.bwdOrder.resize(N);
+    {
+        std::vector<int> pos(a.bwdLevelStart.begin(), a.bwdLevelStart.end() - (nB ? 1 : 0));
+        if (!nB) pos.clear();
+        for (int c = 0; c < N; c++) a.bwdOrder[pos[bl[c]]++] = c;
+    }
+    a.bwdContig = true;
+    for (int b = 0; b < nB && a.bwdContig; b++) {
+        int s = a.bwdLevelStart[b], e = a.bwdLevelStart[b + 1];
+        if (e > s && a.bwdOrder[e - 1] - a.bwdOrder[s] != e - s - 1) a.bwdContig = false;
+    }
+    return FFM_OK;
+}
+
+extern "C" int ffm_renumber_levels(int nCells, int nFaces, const int *l, const int *u,
+                                   int *newToOldCell, int *newToOldFace)
+{
+    if (nCells < 0 || nFaces < 0 || (nFaces && (!l || !u))) return FFM_ERR_ARG;
+    LduAnalysis a;
+    FFM_TRY(analyse(nCells, nFaces, l, u, true, a));
+    if (newToOldCell) std::copy(a.newToOldCell.begin(), a.newToOldCell.end(), newToOldCell);
+    if (newToOldFace) std::copy(a.newToOldFace.begin(), a.newToOldFace.end(), newToOldFace);
+    return FFM_OK;
+}
+
+template <class T>
+static int upload(ffm_ctx *c, T **dst, const std::vector<T> &v, size_t minCount = 1)
+{
+    size_t n = std::max(v.size(), minCount);
+    FFM_HIP(hipMalloc((void **)dst, n * sizeof(T)));
+    if (!v.empty()) FFM_HIP(hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return FFM_OK;
+}
+
+extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const int *u, ffm_ldu **out)
+{
+    if (!ctx || !out || N < 0 || F < 0 || (F && (!l || !u))) { ffm_set_error("ffm_ldu_create: bad argument"); return FFM_ERR_ARG; }
+    FFM_HIP(hipSetDevice(ctx->device));
+    LduAnalysis a;
+    FFM_TRY(analyse(N, F, l, u, true, a));
+    ffm_ldu *A = new ffm_ldu();
+    A->ctx = ctx; A->nCells = N; A->nFaces = F; A->globalCells = N;
+    A->identity = a.identity; A->bwdContig = a.bwdContig;
+    A->nLevels = (int)a.fwdLevelStart.size() - 1; if (A->nLevels < 0) A->nLevels = 0;
+    A->nBwdLevels = (int)a.bwdLevelStart.size() - 1; if (A->nBwdLevels < 0) A->nBwdLevels = 0;
+    A->h_fwdLevelStart = a.fwdLevelStart; A->h_bwdLevelStart = a.bwdLevelStart;
+    A->h_newToOldCell = a.newToOldCell; A->h_newToOldFace = a.newToOldFace;
+    // derived addressing
+    std::vector<int> ownStart(N + 1, 0), loStart(N + 1, 0), loFace(F), loNbr(F);
+    for (int f = 0; f < F; f++) { ownStart[a.l[f] + 1]++; loStart[a.u[f] + 1]++; }
+    for (int c = 0; c < N; c++) { ownStart[c + 1] += ownStart[c]; loStart[c + 1] += loStart[c]; }
+    {
+        std::vector<int> pos(loStart.begin(), loStart.end() - 1);
+        for (int f = 0; f < F; f++) { int k = pos[a.u[f]]++; loFace[k] = f; loNbr[k] = a.l[f]; }
+    }
+    if (A->bwdContig) {
+        // keep only the first cell of every backward level: ranges are [first, first+count)
+        A->h_bwdFirstCell.resize(A->nBwdLevels);
+        for (int b = 0; b < A->nBwdLevels; b++) {
+            int s = a.bwdLevelStart[b];
+            A->h_bwdFirstCell[b] = (a.bwdLevelStart[b + 1] > s) ? a.bwdOrder[s] : 0;
+        }
+    }
+    int rc = FFM_OK;
+    do {
+        if ((rc = upload(ctx, &A->lAddr, a.l))) break;
+        if ((rc = upload(ctx, &A->uAddr, a.u))) break;
+        if ((rc = upload(ctx, &A->ownStart, ownStart))) break;
+        if ((rc = upload(ctx, &A->loStart, loStart))) break;
+        if ((rc = upload(ctx, &A->loFace, loFace))) break;
+        if ((rc = upload(ctx, &A->loNbr, loNbr))) break;
+        if (!A->bwdContig && (rc = upload(ctx, &A->bwdOrder, a.bwdOrder))) break;
+        if (!A->identity) {
+            if ((rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
+            if ((rc = upload(ctx, &A->facePerm, a.newToOldFace))) break;
+        }
+        size_t nb = sizeof(double) * (size_t)std::max(N, 1), fb = sizeof(double) * (size_t)std::max(F, 1);
+        if (hipMalloc((void **)&A->diag, nb) != hipSuccess || hipMalloc((void **)&A->upper, fb) != hipSuccess ||
+            hipMalloc((void **)&A->rD, nb) != hipSuccess) { ffm_set_error("ffm_ldu_create: hipMalloc failed"); rc = FFM_ERR_HIP; break; }
+        A->lower = A->upper;
+        hipMemsetAsync(A->diag, 0, nb, ctx->stream); hipMemsetAsync(A->upper, 0, fb, ctx->stream);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ffm_set_error("ffm_ldu_create: upload failed"); rc = FFM_ERR_HIP; break; }
+    } while (0);
+    if (rc) { ffm_ldu_destroy(A); return rc; }
+    *out = A;
+    return FFM_OK;
+}
+
+extern "C" int ffm_ldu_destroy(ffm_ldu *A)
+{
+    if (!A) return FFM_OK;
+    hipSetDevice(A->ctx->device);
+    hipStreamSynchronize(A->ctx->stream);
+    for (auto &kv : A->graphs) hipGraphExecDestroy(kv.second);
+    for (double *w : A->work) hipFree(w);
+    for (int i = 0; i < 3; i++) hipFree(A->permIn[i]);
+    hipFree(A->lAddr); hipFree(A->uAddr); hipFree(A->ownStart); hipFree(A->loStart); hipFree(A->loFace);
+    hipFree(A->loNbr); hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->facePerm);
+    hipFree(A->diag); hipFree(A->upper); hipFree(A->lowerBuf); hipFree(A->rD);
+    hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);
+    hipFree(A->ifCell); hipFree(A->ifCellStart); hipFree(A->ifItem);
+    delete A;
+    return FFM_OK;
+}
+
+extern "C" int ffm_ldu_ncells(const ffm_ldu *A) { return A ? A->nCells : FFM_ERR_ARG; }
+extern "C" int ffm_ldu_nfaces(const ffm_ldu *A) { return A ? A->nFaces : FFM_ERR_ARG; }
+extern "C" int ffm_ldu_nlevels(const ffm_ldu *A) { return A ? A->nLevels : FFM_ERR_ARG; }
+extern "C" int ffm_ldu_is_native_order(const ffm_ldu *A) { return A ? (A->identity ? 1 : 0) : FFM_ERR_ARG; }
+extern "C" int ffm_ldu_get_cell_order(const ffm_ldu *A, int *newToOld)
+{
+    if (!A || !newToOld) return FFM_ERR_ARG;
+    std::copy(A->h_newToOldCell.begin(), A->h_newToOldCell.end(), newToOld);
+    return FFM_OK;
+}
+extern "C" int ffm_ldu_set_global_cells(ffm_ldu *A, long g) { if (!A || g < A->nCells) return FFM_ERR_ARG; A->globalCells = g; return FFM_OK; }
+
+int ffm_ldu_work(ffm_ldu *A, int idx, double **out)
+{
+    if (idx < 0 || idx > 31) return FFM_ERR_ARG;
+    if ((int)A->work.size() <= idx) A->work.resize(idx + 1, nullptr);
+    if (!A->work[idx]) FFM_HIP(hipMalloc((void **)&A->work[idx], sizeof(double) * (size_t)std::max(A->nCells, 1)));
+    *out = A->work[idx];
+    return FFM_OK;
+}
+
+// ----------------------------------------------------- permutation kernels ---
+__global__ void k_gather(long n, const int *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[perm[i]];
+}
+__global__ void k_scatter(long n, const int *__restrict__ perm, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[perm[i]] = src[i];
+}
+
+static inline int stream_grid(long n) { long g = (n + 255) / 256; return (int)std::max(1L, std::min(g, (long)RED_BLOCKS)); }
+
+int ffm_to_internal(ffm_ldu *A, const double *x_d, int slot, const double **out)
+{
+    if (A->identity) { *out = x_d; return FFM_OK; }
+    if (!A->permIn[slot]) FFM_HIP(hipMalloc((void **)&A->permIn[slot], sizeof(double) * (size_t)std::max(A->nCells, 1)));
+    hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nCells)), dim3(256), 0, A->ctx->stream, (long)A->nCells, A->cellPerm, x_d, A->permIn[slot]);
+    *out = A->permIn[slot];
+    return FFM_OK;
+}
+int ffm_from_internal(ffm_ldu *A, const double *xin, double *x_d)
+{
+    if (A->identity) {
+        if (xin != x_d) FFM_HIP(hipMemcpyAsync(x_d, xin, sizeof(double) * A->nCells, hipMemcpyDeviceToDevice, A->ctx->stream));
+        return FFM_OK;
+    }
+    hipLaunchKernelGGL(k_scatter, dim3(stream_grid(A->nCells)), dim3(256), 0, A->ctx->stream, (long)A->nCells, A->cellPerm, xin, x_d);
+    return FFM_OK;
+}
+
+extern "C" int ffm_ldu_set_coeffs_d(ffm_ldu *A, const double *diag_d, const double *upper_d, const double *lower_d)
+{
+    if (!A || !diag_d || (A->nFaces && !upper_d)) return FFM_ERR_ARG;
+    hipStream_t s = A->ctx->stream;
+    const size_t nb = sizeof(double) * A->nCells, fb = sizeof(double) * A->nFaces;
+    if (lower_d && lower_d != upper_d) {
+        if (!A->lowerBuf) FFM_HIP(hipMalloc((void **)&A->lowerBuf, std::max(fb, sizeof(double))));
+        A->lower = A->lowerBuf; A->symmetric = false;
+    } else { A->lower = A->upper; A->symmetric = true; }
+    if (A->identity) {
+        FFM_HIP(hipMemcpyAsync(A->diag, diag_d, nb, hipMemcpyDeviceToDevice, s));
+        if (fb) FFM_HIP(hipMemcpyAsync(A->upper, upper_d, fb, hipMemcpyDeviceToDevice, s));
+        if (!A->symmetric && fb) FFM_HIP(hipMemcpyAsync(A->lower, lower_d, fb, hipMemcpyDeviceToDevice, s));
+    } else {
+        hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->cellPerm, diag_d, A->diag);
+        hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nFaces)), dim3(256), 0, s, (long)A->nFaces, A->facePerm, upper_d, A->upper);
+        if (!A->symmetric)
+            hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nFaces)), dim3(256), 0, s, (long)A->nFaces, A->facePerm, lower_d, A->lower);
+        FFM_HIP(hipGetLastError());
+    }
+    A->coeffEpoch++;
+    return FFM_OK;
+}
+
+extern "C" int ffm_ldu_set_coeffs(ffm_ldu *A, const double *diag, const double *upper, const double *lower)
+{
+    if (!A || !diag || (A->nFaces && !upper)) return FFM_ERR_ARG;
+    // stage through temporary device buffers (host pointers may be pageable)
+    double *d = nullptr, *u = nullptr, *l = nullptr;
+    const size_t nb = sizeof(double) * std::max(A->nCells, 1), fb = sizeof(double) * std::max(A->nFaces, 1);
+    FFM_HIP(hipMalloc((void **)&d, nb)); FFM_HIP(hipMalloc((void **)&u, fb));
+    if (lower) FFM_HIP(hipMalloc((void **)&l, fb));
+    FFM_HIP(hipMemcpy(d, diag, sizeof(double) * A->nCells, hipMemcpyHostToDevice));
+    if (A->nFaces) FFM_HIP(hipMemcpy(u, upper, sizeof(double) * A->nFaces, hipMemcpyHostToDevice));
+    if (lower && A->nFaces) FFM_HIP(hipMemcpy(l, lower, sizeof(double) * A->nFaces, hipMemcpyHostToDevice));
+    int rc = ffm_ldu_set_coeffs_d(A, d, u, l);
+    hipStreamSynchronize(A->ctx->stream);
+    hipFree(d); hipFree(u); hipFree(l);
+    return rc;
+}
+
+// ----------------------------------------------------------- lduMatrix::Amul ---
+// One thread per row, grid-stride over a fixed grid.  MODE 0: y = A x.
+// MODE 1: r = b - A x (lduMatrix::residual order).  MODE 2: s = sumA.
+// DOT: additionally accumulates the block-partial of x[c]*y[c] (PCG's wApA).
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(256) void k_rows(int N, const double *__restrict__ diag,
+                                              const double *__restrict__ upper, const double *__restrict__ lower,
+                                              const int *__restrict__ ownStart, const int *__restrict__ uAddr,
+                                              const int *__restrict__ loStart, const int *__restrict__ loFace,
+                                              const int *__restrict__ loNbr, const double *__restrict__ x,
+                                              const double *__restrict__ b, double *__restrict__ y,
+                                              double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    double dot = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += stride) {
+        const int k0 = loStart[c], k1 = loStart[c + 1], f0 = ownStart[c], f1 = ownStart[c + 1];
+        double acc;
+        if (MODE == 0) acc = diag[c] * x[c];
+        else if (MODE == 1) acc = b[c] - diag[c] * x[c];
+        else acc = diag[c];
+        for (int k = k0; k < k1; k++) {
+            const double a = lower[loFace[k]];
+            if (MODE == 0) acc += a * x[loNbr[k]];
+            else if (MODE == 1) acc -= a * x[loNbr[k]];
+            else acc += a;
+        }
+        for (int f = f0; f < f1; f++) {
+            const double a = upper[f];
+            if (MODE == 0) acc += a * x[uAddr[f]];
+            else if (MODE == 1) acc -= a * x[uAddr[f]];
+            else acc += a;
+        }
+        y[c] = acc;
+        if (DOT) dot += acc * x[c];
+    }
+    if (DOT) {
+        double r = block_sum(dot, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_partials(int n, const double *__restrict__ partials, double *__restrict__ scal, int slot)
+{
+    __shared__ double sm[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+    double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) scal[slot] = r;
+}
+
+static inline int rows_grid(const ffm_ldu *A) { return stream_grid(A->nCells); }
+
+int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
+{
+    const double *up = transpose ? A->lower : A->upper, *lo = transpose ? A->upper : A->lower;
+    hipLaunchKernelGGL((k_rows<0, false>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, up, lo,
+                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, x, (const double *)nullptr, y, (double *)nullptr);
+    FFM_HIP(hipGetLastError());
+    if (!A->ifaces.empty()) FFM_TRY(ffm_halo_update(A, x, y, transpose ? A->ifInt : A->ifBou, -1.0));
+    return FFM_OK;
+}
+
+int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
+{
+    if (!A->ifaces.empty()) {  // the halo term changes y after the row kernel: separate dot
+        FFM_TRY(ffm_k_spmv(A, x, y, false));
+        return ffm_k_dot(A->ctx, y, x, A->nCells, slot);
+    }
+    const int g = rows_grid(A);
+    hipLaunchKernelGGL((k_rows<0, true>), dim3(g), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, A->upper, A->lower,
+                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, x, (const double *)nullptr, y, A->ctx->partials_d);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, A->ctx->stream, g, A->ctx->partials_d, A->ctx->scal_d, slot);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+int ffm_k_residual(ffm_ldu *A, const double *x, const double *b, double *r)
+{
+    hipLaunchKernelGGL((k_rows<1, false>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, A->upper, A->lower,
+                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, x, b, r, (double *)nullptr);
+    FFM_HIP(hipGetLastError());
+    if (!A->ifaces.empty()) FFM_TRY(ffm_halo_update(A, x, r, A->ifBou, +1.0));
+    return FFM_OK;
+}
+
+int ffm_k_sumA(ffm_ldu *A, double *s)
+{
+    hipLaunchKernelGGL((k_rows<2, false>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, A->upper, A->lower,
+                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, (const double *)nullptr, (const double *)nullptr, s,
+                       (double *)nullptr);
+    FFM_HIP(hipGetLastError());
+    // coupled patches: sumA[faceCells] -= interfaceBouCoeffs
+    if (!A->ifaces.empty()) FFM_TRY(ffm_halo_apply(A, s, A->ifBou, nullptr, -1.0));
+    return FFM_OK;
+}
+
+// ------------------------------------------------------------- public entry ---
+extern "C" int ffm_spmv(ffm_ldu *A, const double *x_d, double *y_d)
+{
+    if (!A || !x_d || !y_d) return FFM_ERR_ARG;
+    const double *xi; FFM_TRY(ffm_to_internal(A, x_d, 0, &xi));
+    if (A->identity) return ffm_k_spmv(A, xi, y_d, false);
+    double *yi; FFM_TRY(ffm_ldu_work(A, 0, &yi));
+    FFM_TRY(ffm_k_spmv(A, xi, yi, false));
+    return ffm_from_internal(A, yi, y_d);
+}
+extern "C" int ffm_tmul(ffm_ldu *A, const double *x_d, double *y_d)
+{
+    if (!A || !x_d || !y_d) return FFM_ERR_ARG;
+    const double *xi; FFM_TRY(ffm_to_internal(A, x_d, 0, &xi));
+    if (A->identity) return ffm_k_spmv(A, xi, y_d, true);
+    double *yi; FFM_TRY(ffm_ldu_work(A, 0, &yi));
+    FFM_TRY(ffm_k_spmv(A, xi, yi, true));
+    return ffm_from_internal(A, yi, y_d);
+}
+extern "C" int ffm_sumA(ffm_ldu *A, double *s_d)
+{
+    if (!A || !s_d) return FFM_ERR_ARG;
+    if (A->identity) return ffm_k_sumA(A, s_d);
+    double *si; FFM_TRY(ffm_ldu_work(A, 0, &si));
+    FFM_TRY(ffm_k_sumA(A, si));
+    return ffm_from_internal(A, si, s_d);
+}
+extern "C" int ffm_residual(ffm_ldu *A, const double *x_d, const double *b_d, double *r_d)
+{
+    if (!A || !x_d || !b_d || !r_d) return FFM_ERR_ARG;
+    const double *xi, *bi;
+    FFM_TRY(ffm_to_internal(A, x_d, 0, &xi)); FFM_TRY(ffm_to_internal(A, b_d, 1, &bi));
+    if (A->identity) return ffm_k_residual(A, xi, bi, r_d);
+    double *ri; FFM_TRY(ffm_ldu_work(A, 0, &ri));
+    FFM_TRY(ffm_k_residual(A, xi, bi, ri));
+    return ffm_from_internal(A, ri, r_d);
+}
+
+extern "C" int ffm_bench_spmv(ffm_ldu *A, const double *x_d, double *y_d, int reps, double *avg_ms)
+{
+    if (!A || !x_d || !y_d || reps < 1 || !avg_ms) return FFM_ERR_ARG;
+    if (!A->identity) { ffm_set_error("ffm_bench_spmv needs a level-major (native order) LDU"); return FFM_ERR_UNSUPPORTED; }
+    hipEvent_t e0, e1;
+    FFM_HIP(hipEventCreate(&e0)); FFM_HIP(hipEventCreate(&e1));
+    FFM_TRY(ffm_k_spmv(A, x_d, y_d, false));  // warm-up
+    FFM_HIP(hipEventRecord(e0, A->ctx->stream));
+    for (int i = 0; i < reps; i++) FFM_TRY(ffm_k_spmv(A, x_d, y_d, false));
+    FFM_HIP(hipEventRecord(e1, A->ctx->stream));
+    FFM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FFM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+    return FFM_OK;
+}

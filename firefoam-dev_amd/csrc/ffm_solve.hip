@@ -1,0 +1,724 @@
+// ffm_solve.hip -- level-scheduled DIC / DILU / Gauss-Seidel sweeps and the
+// PCG / PBiCGStab / PBiCG / smoothSolver / diagonalSolver drivers.
+//
+// Replaces (OpenFOAM-dev @940e28f, not vendored in the reference):
+//   .../lduMatrix/preconditioners/{DIC,DILU}Preconditioner/*.C
+//   .../lduMatrix/smoothers/{GaussSeidel,symGaussSeidel}/*.C
+//   .../lduMatrix/solvers/{PCG,PBiCGStab,PBiCG,smoothSolver,diagonalSolver}/*.C
+// selected by the reference in cases/steckler/system/fvSolution:21-61 and
+// cases/wallFireSpread2D/system/fvSolution:115-152; entered from
+// solver/pEqn.H:39, solver/UEqn.H:19, solver/YEEqn.H:60,111, solver/rhoEqn.H:43.
+//
+// Exactness: the serial face-order sweeps of the reference carry a dependency
+// DAG (owner -> neighbour).  Cells are stored level-major, one kernel launch
+// per dependency level, all launches of one sweep pair captured once in a
+// hipGraph.  Inside a level every row is accumulated in the reference's face
+// order, and the library is compiled with -ffp-contract=off, so the sweeps are
+// bitwise equal to the serial loops; only the dot products (two-stage tree
+// sums instead of one serial sum) differ, in the last bits.
+//
+// Scalars (alpha, beta, residual norms) stay on the device; the host reads the
+// residual back once per iteration (twice for PBiCGStab) to take the
+// convergence decision, as SolverPerformance::checkConvergence does.
+#include "ffm_internal.hpp"
+#include "ffm_device.hpp"
+#include <algorithm>
+#include <cmath>
+
+static inline int sgrid(long n) { long g = (n + 255) / 256; return (int)std::max(1L, std::min(g, (long)RED_BLOCKS)); }
+
+// --------------------------------------------------------------- scalar ops ---
+enum {
+    OP_XREF = 1, OP_NORMF, OP_RES_INIT, OP_RES, OP_PCG_BETA, OP_PCG_ALPHA,
+    OP_BS_RHO, OP_BS_ALPHA, OP_BS_OMEGA, OP_BICG_BETA, OP_BICG_ALPHA, OP_RESET
+};
+
+#define VSMALL_ 1e-300
+
+__global__ void k_scalar_op(double *__restrict__ s, int op, double arg, int iter)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    switch (op) {
+    case OP_RESET:
+        s[S_SING] = 0.0; s[S_WARA] = 1e+20; s[S_WARA_OLD] = 1e+20; s[S_RA0RA] = 0.0; s[S_ALPHA] = 0.0; s[S_OMEGA] = 0.0;
+        s[S_BETA] = 0.0;
+        break;
+    case OP_XREF: s[S_XREF] = s[S_TMP0] / arg; break;                    // gAverage(psi)
+    case OP_NORMF: s[S_NORMF] = s[S_TMP0] + 1e-20; break;                // + solverPerformance::small_
+    case OP_RES_INIT: s[S_RES] = s[S_TMP0] / s[S_NORMF]; s[S_RES0] = s[S_RES]; break;
+    case OP_RES: if (s[S_SING] == 0.0) s[S_RES] = s[S_TMP0] / s[S_NORMF]; break;
+    case OP_PCG_BETA: {                                                  // wArAold = wArA; wArA = (wA,rA)
+        const double old = s[S_WARA], nw = s[S_TMP0];
+        s[S_WARA_OLD] = old; s[S_WARA] = nw; s[S_BETA] = nw / old;
+        break; }
+    case OP_PCG_ALPHA: case OP_BICG_ALPHA: {                             // wApA; checkSingularity(|wApA|/normFactor)
+        const double wApA = s[S_TMP0];
+        s[S_WAPA] = wApA;
+        if (fabs(wApA) / s[S_NORMF] > VSMALL_) { s[S_ALPHA] = s[S_WARA] / wApA; }
+        else { s[S_SING] = 1.0; s[S_ALPHA] = 0.0; }
+        break; }
+    case OP_BS_RHO: {                                                    // rA0rAold = rA0rA; rA0rA = (rA0,rA)
+        const double old = s[S_RA0RA], nw = s[S_TMP0];
+        s[S_RA0RA_OLD] = old; s[S_RA0RA] = nw;
+        if (!(fabs(nw) > VSMALL_)) { s[S_SING] = 1.0; break; }
+        if (iter > 0) {
+            if (!(fabs(s[S_OMEGA]) > VSMALL_)) { s[S_SING] = 1.0; break; }
+            s[S_BETA] = (nw / old) * (s[S_ALPHA] / s[S_OMEGA]);
+        }
+        break; }
+    case OP_BS_ALPHA: if (s[S_SING] == 0.0) { s[S_RA0AYA] = s[S_TMP0]; s[S_ALPHA] = s[S_RA0RA] / s[S_TMP0]; } break;
+    case OP_BS_OMEGA: if (s[S_SING] == 0.0) { s[S_TATA] = s[S_TMP0]; s[S_TASA] = s[S_TMP1]; s[S_OMEGA] = s[S_TMP1] / s[S_TMP0]; } break;
+    case OP_BICG_BETA: {
+        const double old = s[S_WARA], nw = s[S_TMP0];
+        s[S_WARA_OLD] = old; s[S_WARA] = nw; s[S_BETA] = nw / old;
+        break; }
+    }
+}
+
+static int scalar_op(ffm_ctx *c, int op, double arg = 0.0, int iter = 0)
+{
+    hipLaunchKernelGGL(k_scalar_op, dim3(1), dim3(64), 0, c->stream, c->scal_d, op, arg, iter);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+// local sum sits in S_TMP0(..S_TMP0+n-1): all-reduce over ranks, then derive
+static int finish_dot(ffm_ctx *c, int op, int nSlots = 1, double arg = 0.0, int iter = 0)
+{
+    if (c->nRanks > 1) FFM_TRY(ffm_allreduce_slots(c, S_TMP0, nSlots));
+    return scalar_op(c, op, arg, iter);
+}
+
+// ----------------------------------------------------------- vector kernels ---
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+__global__ void k_sub(long n, double *__restrict__ r, const double *__restrict__ b, const double *__restrict__ w)
+{ GRID_STRIDE(i, n) r[i] = b[i] - w[i]; }
+
+__global__ void k_sub2(long n, double *__restrict__ r, double *__restrict__ rT, const double *__restrict__ b,
+                       const double *__restrict__ w, const double *__restrict__ wT)
+{ GRID_STRIDE(i, n) { r[i] = b[i] - w[i]; rT[i] = b[i] - wT[i]; } }
+
+__global__ void k_copy(long n, double *__restrict__ d, const double *__restrict__ s)
+{ GRID_STRIDE(i, n) d[i] = s[i]; }
+
+// normFactor partial: |Apsi - xRef*sumA| + |source - xRef*sumA|
+__global__ __launch_bounds__(256) void k_normf(long n, const double *__restrict__ Ax, const double *__restrict__ b,
+                                               const double *__restrict__ sumA, const double *__restrict__ scal,
+                                               double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    const double xRef = scal[S_XREF];
+    double acc = 0.0;
+    GRID_STRIDE(i, n) { const double t = sumA[i] * xRef; acc += fabs(Ax[i] - t) + fabs(b[i] - t); }
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// pA = first ? wA : wA + beta*pA
+__global__ void k_p_update(long n, double *__restrict__ p, const double *__restrict__ w, const double *__restrict__ scal, int first)
+{
+    if (scal[S_SING] != 0.0) return;
+    const double beta = scal[S_BETA];
+    if (first) { GRID_STRIDE(i, n) p[i] = w[i]; }
+    else { GRID_STRIDE(i, n) p[i] = w[i] + beta * p[i]; }
+}
+
+// psi += alpha*pA; rA -= alpha*wA; partial sum |rA|      (PCG)
+__global__ __launch_bounds__(256) void k_pcg_xr(long n, double *__restrict__ psi, double *__restrict__ r,
+                                                const double *__restrict__ p, const double *__restrict__ w,
+                                                const double *__restrict__ scal, double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    const double alpha = scal[S_ALPHA];
+    const bool sing = scal[S_SING] != 0.0;
+    double acc = 0.0;
+    GRID_STRIDE(i, n) {
+        double ri = r[i];
+        if (!sing) { psi[i] += alpha * p[i]; ri -= alpha * w[i]; r[i] = ri; }
+        acc += fabs(ri);
+    }
+    const double s = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// PBiCG extra: rT -= alpha*wT
+__global__ void k_axmy_alpha(long n, double *__restrict__ r, const double *__restrict__ w, const double *__restrict__ scal)
+{
+    if (scal[S_SING] != 0.0) return;
+    const double alpha = scal[S_ALPHA];
+    GRID_STRIDE(i, n) r[i] -= alpha * w[i];
+}
+
+// PBiCGStab: pA = first ? rA : rA + beta*(pA - omega*AyA)
+__global__ void k_bs_p(long n, double *__restrict__ p, const double *__restrict__ r, const double *__restrict__ AyA,
+                       const double *__restrict__ scal, int first)
+{
+    if (scal[S_SING] != 0.0) return;
+    const double beta = scal[S_BETA], omega = scal[S_OMEGA];
+    if (first) { GRID_STRIDE(i, n) p[i] = r[i]; }
+    else { GRID_STRIDE(i, n) p[i] = r[i] + beta * (p[i] - omega * AyA[i]); }
+}
+
+// sA = rA - alpha*AyA; partial |sA|
+__global__ __launch_bounds__(256) void k_bs_s(long n, double *__restrict__ sA, const double *__restrict__ r,
+                                              const double *__restrict__ AyA, const double *__restrict__ scal,
+                                              double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    const double alpha = scal[S_ALPHA];
+    const bool sing = scal[S_SING] != 0.0;
+    double acc = 0.0;
+    if (!sing) GRID_STRIDE(i, n) { const double v = r[i] - alpha * AyA[i]; sA[i] = v; acc += fabs(v); }
+    const double s = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// psi += alpha*yA
+__global__ void k_axpy_alpha(long n, double *__restrict__ psi, const double *__restrict__ y, const double *__restrict__ scal)
+{
+    const double alpha = scal[S_ALPHA];
+    GRID_STRIDE(i, n) psi[i] += alpha * y[i];
+}
+
+// two dots in one pass: partials[0..] = tA.tA, partials[RED_BLOCKS..] = tA.sA
+__global__ __launch_bounds__(256) void k_dot2(long n, const double *__restrict__ t, const double *__restrict__ s,
+                                              double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    double a = 0.0, b = 0.0;
+    GRID_STRIDE(i, n) { const double ti = t[i]; a += ti * ti; b += ti * s[i]; }
+    const double ra = block_sum(a, sm);
+    const double rb = block_sum(b, sm);
+    if (threadIdx.x == 0) { partials[blockIdx.x] = ra; partials[RED_BLOCKS + blockIdx.x] = rb; }
+}
+
+__global__ __launch_bounds__(1024) void k_sum_partials2(int n, const double *__restrict__ partials, double *__restrict__ scal,
+                                                        int slot, int nSums)
+{
+    __shared__ double sm[16];
+    for (int k = 0; k < nSums; k++) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[k * RED_BLOCKS + i];
+        const double r = block_sum(acc, sm);
+        if (threadIdx.x == 0) scal[slot + k] = r;
+    }
+}
+
+// psi += alpha*yA + omega*zA; rA = sA - omega*tA; partial |rA|
+__global__ __launch_bounds__(256) void k_bs_xr(long n, double *__restrict__ psi, double *__restrict__ r,
+                                               const double *__restrict__ yA, const double *__restrict__ zA,
+                                               const double *__restrict__ sA, const double *__restrict__ tA,
+                                               const double *__restrict__ scal, double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    const double alpha = scal[S_ALPHA], omega = scal[S_OMEGA];
+    const bool sing = scal[S_SING] != 0.0;
+    double acc = 0.0;
+    if (!sing) GRID_STRIDE(i, n) {
+        psi[i] += alpha * yA[i] + omega * zA[i];
+        const double v = sA[i] - omega * tA[i];
+        r[i] = v; acc += fabs(v);
+    }
+    const double s = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
+// psi = source/diag (diagonalSolver)
+__global__ void k_diag_solve(long n, double *__restrict__ psi, const double *__restrict__ b, const double *__restrict__ d)
+{ GRID_STRIDE(i, n) psi[i] = b[i] / d[i]; }
+
+__global__ void k_mul(long n, double *__restrict__ w, const double *__restrict__ a, const double *__restrict__ b)
+{ GRID_STRIDE(i, n) w[i] = a[i] * b[i]; }
+
+__global__ void k_recip(long n, double *__restrict__ d, const double *__restrict__ s)
+{ GRID_STRIDE(i, n) d[i] = 1.0 / s[i]; }
+
+static int partial_sum_to(ffm_ctx *c, int nb, int slot, int nSums = 1)
+{
+    hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(1024), 0, c->stream, nb, c->partials_d, c->scal_d, slot, nSums);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+// ------------------------------------------------------------ level kernels ---
+// calcReciprocalD, forward part:  rD[c] = diag[c] - sum_k upper*lower/rD[l]   (not yet inverted)
+__global__ void k_rD_level(int c0, int c1, const int *__restrict__ loStart, const int *__restrict__ loFace,
+                           const int *__restrict__ loNbr, const double *__restrict__ upper,
+                           const double *__restrict__ lower, const double *__restrict__ diag, double *__restrict__ rD)
+{
+    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c1) return;
+    double d = diag[c];
+    for (int k = loStart[c]; k < loStart[c + 1]; k++) {
+        const int f = loFace[k];
+        d -= upper[f] * lower[f] / rD[loNbr[k]];
+    }
+    rD[c] = d;
+}
+
+// forward sweep of one level:  w[c] = rD[c]*r[c] - sum_k rD[c]*coef[f]*w[l]
+__global__ void k_fwd_level(int c0, int c1, const int *__restrict__ loStart, const int *__restrict__ loFace,
+                            const int *__restrict__ loNbr, const double *__restrict__ coef,
+                            const double *__restrict__ rD, const double *__restrict__ r, double *__restrict__ w)
+{
+    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c1) return;
+    const double rd = rD[c];
+    double wc = rd * r[c];
+    for (int k = loStart[c]; k < loStart[c + 1]; k++) wc -= rd * coef[loFace[k]] * w[loNbr[k]];
+    w[c] = wc;
+}
+
+// backward sweep of one level: w[c] -= rD[c]*coef[f]*w[u], faces of c in descending order
+__global__ void k_bwd_level(int p0, int p1, const int *__restrict__ order, const int *__restrict__ ownStart,
+                            const int *__restrict__ uAddr, const double *__restrict__ coef,
+                            const double *__restrict__ rD, double *__restrict__ w)
+{
+    const int p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= p1) return;
+    const int c = order ? order[p] : p;
+    const int f0 = ownStart[c], f1 = ownStart[c + 1];
+    if (f1 == f0) return;
+    const double rd = rD[c];
+    double wc = w[c];
+    for (int f = f1 - 1; f >= f0; f--) wc -= rd * coef[f] * w[uAddr[f]];
+    w[c] = wc;
+}
+
+// Gauss-Seidel forward level: psi_c = (bP_c - sum_lower lower*psi_l - sum_upper upper*psi_u)/diag_c;
+// the value after the lower sum is kept in bSave for the reverse sweep of symGaussSeidel
+__global__ void k_gs_fwd_level(int c0, int c1, const int *__restrict__ loStart, const int *__restrict__ loFace,
+                               const int *__restrict__ loNbr, const int *__restrict__ ownStart,
+                               const int *__restrict__ uAddr, const double *__restrict__ upper,
+                               const double *__restrict__ lower, const double *__restrict__ diag,
+                               const double *__restrict__ bP, double *__restrict__ bSave, double *__restrict__ psi)
+{
+    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c1) return;
+    double v = bP[c];
+    for (int k = loStart[c]; k < loStart[c + 1]; k++) v -= lower[loFace[k]] * psi[loNbr[k]];
+    bSave[c] = v;
+    for (int f = ownStart[c]; f < ownStart[c + 1]; f++) v -= upper[f] * psi[uAddr[f]];
+    psi[c] = v / diag[c];
+}
+
+__global__ void k_gs_bwd_level(int p0, int p1, const int *__restrict__ order, const int *__restrict__ ownStart,
+                               const int *__restrict__ uAddr, const double *__restrict__ upper,
+                               const double *__restrict__ diag, const double *__restrict__ bSave, double *__restrict__ psi)
+{
+    const int p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= p1) return;
+    const int c = order ? order[p] : p;
+    double v = bSave[c];
+    for (int f = ownStart[c]; f < ownStart[c + 1]; f++) v -= upper[f] * psi[uAddr[f]];
+    psi[c] = v / diag[c];
+}
+
+// ------------------------------------------------------ level-sweep drivers ---
+enum { SW_RD = 1, SW_PRECOND = 2, SW_GS = 3, SW_SYMGS = 4 };
+
+template <class Body>
+static int run_graphed(ffm_ldu *A, const SweepGraphKey &key, Body body)
+{
+    static const bool noGraph = getenv("FFM_NO_GRAPH") != nullptr;
+    hipStream_t s = A->ctx->stream;
+    if (noGraph) return body();
+    auto it = A->graphs.find(key);
+    if (it == A->graphs.end()) {
+        hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        FFM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = body();
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess) { ffm_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return FFM_ERR_HIP; }
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (e != hipSuccess) { ffm_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return FFM_ERR_HIP; }
+        it = A->graphs.emplace(key, ge).first;
+    }
+    FFM_HIP(hipGraphLaunch(it->second, s));
+    return FFM_OK;
+}
+
+static inline void bwd_range(const ffm_ldu *A, int b, int &p0, int &p1, const int *&order)
+{
+    const int s = A->h_bwdLevelStart[b], e = A->h_bwdLevelStart[b + 1];
+    if (A->bwdContig) { p0 = A->h_bwdFirstCell[b]; p1 = p0 + (e - s); order = nullptr; }
+    else { p0 = s; p1 = e; order = A->bwdOrder; }
+}
+
+// rD = 1/(diag - sum upper*lower/rD[l]) in face order (DIC: lower == upper)
+static int calc_rD(ffm_ldu *A)
+{
+    hipStream_t s = A->ctx->stream;
+    SweepGraphKey key{SW_RD, A->lower, A->upper, nullptr};
+    FFM_TRY(run_graphed(A, key, [&]() -> int {
+        for (int L = 0; L < A->nLevels; L++) {
+            const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
+            if (c1 == c0) continue;
+            hipLaunchKernelGGL(k_rD_level, dim3(ffm_grid(c1 - c0, 256)), dim3(256), 0, s, c0, c1, A->loStart, A->loFace, A->loNbr,
+                               A->upper, A->lower, A->diag, A->rD);
+        }
+        hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->rD, A->rD);
+        FFM_HIP(hipGetLastError());
+        return FFM_OK;
+    }));
+    return FFM_OK;
+}
+
+int ffm_precond_setup_i(ffm_ldu *A, int precond)
+{
+    if (A->rDKind == precond && A->rDEpoch == A->coeffEpoch) return FFM_OK;
+    hipStream_t s = A->ctx->stream;
+    switch (precond) {
+    case FFM_NONE: break;
+    case FFM_DIC:
+        if (!A->symmetric) { ffm_set_error("DIC needs a symmetric matrix"); return FFM_ERR_UNSUPPORTED; }
+        FFM_TRY(calc_rD(A)); break;
+    case FFM_DILU: FFM_TRY(calc_rD(A)); break;
+    case FFM_DIAGONALP:
+        hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->rD, A->diag);
+        FFM_HIP(hipGetLastError());
+        break;
+    default: ffm_set_error("unknown preconditioner %d", precond); return FFM_ERR_UNSUPPORTED;
+    }
+    A->rDKind = precond; A->rDEpoch = A->coeffEpoch;
+    return FFM_OK;
+}
+
+int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r, double *w)
+{
+    hipStream_t s = A->ctx->stream;
+    const long N = A->nCells;
+    if (precond == FFM_NONE) { hipLaunchKernelGGL(k_copy, dim3(sgrid(N)), dim3(256), 0, s, N, w, r); FFM_HIP(hipGetLastError()); return FFM_OK; }
+    if (precond == FFM_DIAGONALP) { hipLaunchKernelGGL(k_mul, dim3(sgrid(N)), dim3(256), 0, s, N, w, A->rD, r); FFM_HIP(hipGetLastError()); return FFM_OK; }
+    // DIC: fwd upper / bwd upper.  DILU: fwd lower / bwd upper.  DILU^T: fwd upper / bwd lower.
+    const double *cf = (precond == FFM_DIC) ? A->upper : (transpose ? A->upper : A->lower);
+    const double *cb = (precond == FFM_DIC) ? A->upper : (transpose ? A->lower : A->upper);
+    SweepGraphKey key{SW_PRECOND + 16 * (transpose ? 1 : 0) + 32 * precond, r, w, cf};
+    return run_graphed(A, key, [&]() -> int {
+        for (int L = 0; L < A->nLevels; L++) {
+            const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
+            if (c1 == c0) continue;
+            hipLaunchKernelGGL(k_fwd_level, dim3(ffm_grid(c1 - c0, 256)), dim3(256), 0, s, c0, c1, A->loStart, A->loFace, A->loNbr,
+                               cf, A->rD, r, w);
+        }
+        // backward level 0 = cells without owned faces: nothing to do
+        for (int b = 1; b < A->nBwdLevels; b++) {
+            int p0, p1; const int *order; bwd_range(A, b, p0, p1, order);
+            if (p1 == p0) continue;
+            hipLaunchKernelGGL(k_bwd_level, dim3(ffm_grid(p1 - p0, 256)), dim3(256), 0, s, p0, p1, order, A->ownStart, A->uAddr,
+                               cb, A->rD, w);
+        }
+        FFM_HIP(hipGetLastError());
+        return FFM_OK;
+    });
+}
+
+// GaussSeidelSmoother::smooth / symGaussSeidelSmoother::smooth
+int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b)
+{
+    hipStream_t s = A->ctx->stream;
+    const long N = A->nCells;
+    double *bP, *bSave;
+    FFM_TRY(ffm_ldu_work(A, 10, &bP)); FFM_TRY(ffm_ldu_work(A, 11, &bSave));
+    for (int sw = 0; sw < nSweeps; sw++) {
+        const double *bUse = b;
+        if (!A->ifaces.empty()) {   // bPrime = source + bou*pnf (negated interface coefficients)
+            hipLaunchKernelGGL(k_copy, dim3(sgrid(N)), dim3(256), 0, s, N, bP, b);
+            FFM_TRY(ffm_halo_update(A, psi, bP, A->ifBou, +1.0));
+            bUse = bP;
+        }
+        SweepGraphKey key{sym ? SW_SYMGS : SW_GS, psi, bUse, A->lower};
+        FFM_TRY(run_graphed(A, key, [&]() -> int {
+            for (int L = 0; L < A->nLevels; L++) {
+                const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
+                if (c1 == c0) continue;
+                hipLaunchKernelGGL(k_gs_fwd_level, dim3(ffm_grid(c1 - c0, 256)), dim3(256), 0, s, c0, c1, A->loStart, A->loFace,
+                                   A->loNbr, A->ownStart, A->uAddr, A->upper, A->lower, A->diag, bUse, bSave, psi);
+            }
+            if (sym) for (int bl = 0; bl < A->nBwdLevels; bl++) {
+                int p0, p1; const int *order; bwd_range(A, bl, p0, p1, order);
+                if (p1 == p0) continue;
+                hipLaunchKernelGGL(k_gs_bwd_level, dim3(ffm_grid(p1 - p0, 256)), dim3(256), 0, s, p0, p1, order, A->ownStart,
+                                   A->uAddr, A->upper, A->diag, bSave, psi);
+            }
+            FFM_HIP(hipGetLastError());
+            return FFM_OK;
+        }));
+    }
+    return FFM_OK;
+}
+
+// ------------------------------------------------------------------ solvers ---
+struct Controls { double tol, relTol; int minIter, maxIter, nSweeps; };
+
+static inline bool check_convergence(ffm_perf *p, const Controls &k)
+{
+    p->converged = (p->finalResidual < k.tol || (k.relTol > 1e-20 && p->finalResidual < k.relTol * p->initialResidual)) ? 1 : 0;
+    return p->converged;
+}
+
+// normFactor + initial residual: wA = A psi already computed, rA = source - wA already formed
+static int norm_and_initial(ffm_ldu *A, const double *psi, const double *source, const double *Apsi, double *tmp,
+                            const double *rA, ffm_perf *perf)
+{
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells;
+    FFM_TRY(ffm_k_sum(c, psi, N, S_TMP0));
+    FFM_TRY(finish_dot(c, OP_XREF, 1, (double)A->globalCells));
+    FFM_TRY(ffm_k_sumA(A, tmp));
+    const int g = sgrid(N);
+    hipLaunchKernelGGL(k_normf, dim3(g), dim3(256), 0, s, N, Apsi, source, tmp, c->scal_d, c->partials_d);
+    FFM_TRY(partial_sum_to(c, g, S_TMP0));
+    FFM_TRY(finish_dot(c, OP_NORMF));
+    FFM_TRY(ffm_k_summag(c, rA, N, S_TMP0));
+    FFM_TRY(finish_dot(c, OP_RES_INIT));
+    FFM_TRY(ffm_read_scalars(c));
+    perf->initialResidual = c->scal_h[S_RES0];
+    perf->finalResidual = perf->initialResidual;
+    perf->nIterations = 0; perf->singular = 0; perf->converged = 0;
+    return FFM_OK;
+}
+
+// PCG::solve
+static int pcg(ffm_ldu *A, int precond, const Controls &k, double *psi, const double *source, ffm_perf *perf)
+{
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    double *pA, *wA, *rA;
+    FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &wA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
+    FFM_TRY(scalar_op(c, OP_RESET));
+    FFM_TRY(ffm_k_spmv(A, psi, wA, false));
+    hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, rA, source, wA);
+    FFM_TRY(norm_and_initial(A, psi, source, wA, pA, rA, perf));
+    if (k.minIter > 0 || !check_convergence(perf, k)) {
+        FFM_TRY(ffm_precond_setup_i(A, precond));
+        do {
+            FFM_TRY(ffm_precond_apply_i(A, precond, false, rA, wA));
+            FFM_TRY(ffm_k_dot(c, wA, rA, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_PCG_BETA));
+            hipLaunchKernelGGL(k_p_update, dim3(g), dim3(256), 0, s, N, pA, wA, c->scal_d, perf->nIterations == 0 ? 1 : 0);
+            FFM_TRY(ffm_k_spmv_dot(A, pA, wA, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_PCG_ALPHA));
+            hipLaunchKernelGGL(k_pcg_xr, dim3(g), dim3(256), 0, s, N, psi, rA, pA, wA, c->scal_d, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_RES));
+            FFM_TRY(ffm_read_scalars(c));
+            if (c->scal_h[S_SING] != 0.0) { perf->singular = 1; break; }
+            perf->finalResidual = c->scal_h[S_RES];
+        } while ((++perf->nIterations < k.maxIter && !check_convergence(perf, k)) || perf->nIterations < k.minIter);
+    }
+    return FFM_OK;
+}
+
+// PBiCGStab::solve
+static int pbicgstab(ffm_ldu *A, int precond, const Controls &k, double *psi, const double *source, ffm_perf *perf)
+{
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    double *yA, *rA, *pA, *AyA, *sA, *zA, *tA, *rA0;
+    FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &yA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
+    FFM_TRY(scalar_op(c, OP_RESET));
+    FFM_TRY(ffm_k_spmv(A, psi, yA, false));
+    hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, rA, source, yA);
+    FFM_TRY(norm_and_initial(A, psi, source, yA, pA, rA, perf));
+    if (k.minIter > 0 || !check_convergence(perf, k)) {
+        FFM_TRY(ffm_ldu_work(A, 4, &AyA)); FFM_TRY(ffm_ldu_work(A, 5, &sA)); FFM_TRY(ffm_ldu_work(A, 6, &zA));
+        FFM_TRY(ffm_ldu_work(A, 7, &tA)); FFM_TRY(ffm_ldu_work(A, 8, &rA0));
+        hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, s, N, rA0, rA);
+        FFM_TRY(ffm_precond_setup_i(A, precond));
+        do {
+            FFM_TRY(ffm_k_dot(c, rA0, rA, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_BS_RHO, 1, 0.0, perf->nIterations));
+            hipLaunchKernelGGL(k_bs_p, dim3(g), dim3(256), 0, s, N, pA, rA, AyA, c->scal_d, perf->nIterations == 0 ? 1 : 0);
+            FFM_TRY(ffm_precond_apply_i(A, precond, false, pA, yA));
+            FFM_TRY(ffm_k_spmv(A, yA, AyA, false));
+            FFM_TRY(ffm_k_dot(c, rA0, AyA, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_BS_ALPHA));
+            hipLaunchKernelGGL(k_bs_s, dim3(g), dim3(256), 0, s, N, sA, rA, AyA, c->scal_d, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_RES));
+            FFM_TRY(ffm_read_scalars(c));
+            if (c->scal_h[S_SING] != 0.0) { perf->singular = 1; break; }
+            perf->finalResidual = c->scal_h[S_RES];
+            if (check_convergence(perf, k)) {
+                hipLaunchKernelGGL(k_axpy_alpha, dim3(g), dim3(256), 0, s, N, psi, yA, c->scal_d);
+                perf->nIterations++;
+                return FFM_OK;
+            }
+            FFM_TRY(ffm_precond_apply_i(A, precond, false, sA, zA));
+            FFM_TRY(ffm_k_spmv(A, zA, tA, false));
+            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, s, N, tA, sA, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0, 2));
+            FFM_TRY(finish_dot(c, OP_BS_OMEGA, 2));
+            hipLaunchKernelGGL(k_bs_xr, dim3(g), dim3(256), 0, s, N, psi, rA, yA, zA, sA, tA, c->scal_d, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_RES));
+            FFM_TRY(ffm_read_scalars(c));
+            perf->finalResidual = c->scal_h[S_RES];
+        } while ((++perf->nIterations < k.maxIter && !check_convergence(perf, k)) || perf->nIterations < k.minIter);
+    }
+    return FFM_OK;
+}
+
+// PBiCG::solve
+static int pbicg(ffm_ldu *A, int precond, const Controls &k, double *psi, const double *source, ffm_perf *perf)
+{
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    double *pA, *pT, *wA, *wT, *rA, *rT;
+    FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &wA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
+    FFM_TRY(ffm_ldu_work(A, 4, &pT)); FFM_TRY(ffm_ldu_work(A, 5, &wT)); FFM_TRY(ffm_ldu_work(A, 6, &rT));
+    FFM_TRY(scalar_op(c, OP_RESET));
+    FFM_TRY(ffm_k_spmv(A, psi, wA, false));
+    FFM_TRY(ffm_k_spmv(A, psi, wT, true));
+    hipLaunchKernelGGL(k_sub2, dim3(g), dim3(256), 0, s, N, rA, rT, source, wA, wT);
+    FFM_TRY(norm_and_initial(A, psi, source, wA, pA, rA, perf));
+    if (k.minIter > 0 || !check_convergence(perf, k)) {
+        FFM_TRY(ffm_precond_setup_i(A, precond));
+        do {
+            FFM_TRY(ffm_precond_apply_i(A, precond, false, rA, wA));
+            FFM_TRY(ffm_precond_apply_i(A, precond, true, rT, wT));
+            FFM_TRY(ffm_k_dot(c, wA, rT, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_BICG_BETA));
+            const int first = perf->nIterations == 0 ? 1 : 0;
+            hipLaunchKernelGGL(k_p_update, dim3(g), dim3(256), 0, s, N, pA, wA, c->scal_d, first);
+            hipLaunchKernelGGL(k_p_update, dim3(g), dim3(256), 0, s, N, pT, wT, c->scal_d, first);
+            FFM_TRY(ffm_k_spmv(A, pA, wA, false));
+            FFM_TRY(ffm_k_spmv(A, pT, wT, true));
+            FFM_TRY(ffm_k_dot(c, wA, pT, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_BICG_ALPHA));
+            hipLaunchKernelGGL(k_axmy_alpha, dim3(g), dim3(256), 0, s, N, rT, wT, c->scal_d);
+            hipLaunchKernelGGL(k_pcg_xr, dim3(g), dim3(256), 0, s, N, psi, rA, pA, wA, c->scal_d, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_RES));
+            FFM_TRY(ffm_read_scalars(c));
+            if (c->scal_h[S_SING] != 0.0) { perf->singular = 1; break; }
+            perf->finalResidual = c->scal_h[S_RES];
+        } while ((++perf->nIterations < k.maxIter && !check_convergence(perf, k)) || perf->nIterations < k.minIter);
+    }
+    return FFM_OK;
+}
+
+// smoothSolver::solve
+static int smooth(ffm_ldu *A, int smoother, const Controls &k, double *psi, const double *source, ffm_perf *perf)
+{
+    if (smoother != FFM_GS && smoother != FFM_SYMGS) { ffm_set_error("smoothSolver: smoother must be GaussSeidel or symGaussSeidel"); return FFM_ERR_UNSUPPORTED; }
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    const int nSweeps = k.nSweeps > 0 ? k.nSweeps : 1;
+    double *Apsi, *tmp, *res;
+    FFM_TRY(ffm_ldu_work(A, 1, &Apsi)); FFM_TRY(ffm_ldu_work(A, 2, &tmp)); FFM_TRY(ffm_ldu_work(A, 3, &res));
+    FFM_TRY(scalar_op(c, OP_RESET));
+    FFM_TRY(ffm_k_spmv(A, psi, Apsi, false));
+    hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, res, source, Apsi);
+    FFM_TRY(norm_and_initial(A, psi, source, Apsi, tmp, res, perf));
+    if (k.minIter > 0 || !check_convergence(perf, k)) {
+        do {
+            FFM_TRY(ffm_gs_smooth_i(A, smoother == FFM_SYMGS, nSweeps, psi, source));
+            FFM_TRY(ffm_k_residual(A, psi, source, res));
+            FFM_TRY(ffm_k_summag(c, res, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_RES));
+            FFM_TRY(ffm_read_scalars(c));
+            perf->finalResidual = c->scal_h[S_RES];
+        } while (((perf->nIterations += nSweeps) < k.maxIter && !check_convergence(perf, k)) || perf->nIterations < k.minIter);
+    }
+    return FFM_OK;
+}
+
+static int diagonal(ffm_ldu *A, double *psi, const double *source, ffm_perf *perf)
+{
+    hipLaunchKernelGGL(k_diag_solve, dim3(sgrid(A->nCells)), dim3(256), 0, A->ctx->stream, (long)A->nCells, psi, source, A->diag);
+    FFM_HIP(hipGetLastError());
+    perf->initialResidual = perf->finalResidual = 0.0; perf->nIterations = 0; perf->converged = 1; perf->singular = 0;
+    return FFM_OK;
+}
+
+static int solve_internal(ffm_ldu *A, int solver, int precond, const Controls &k, double *psi, const double *source, ffm_perf *perf)
+{
+    switch (solver) {
+    case FFM_PCG:
+        if (!A->symmetric) { ffm_set_error("PCG needs a symmetric matrix"); return FFM_ERR_UNSUPPORTED; }
+        return pcg(A, precond, k, psi, source, perf);
+    case FFM_PBICGSTAB: return pbicgstab(A, precond, k, psi, source, perf);
+    case FFM_PBICG: return pbicg(A, precond, k, psi, source, perf);
+    case FFM_DIAGONAL: return diagonal(A, psi, source, perf);
+    case FFM_SMOOTH: return smooth(A, precond, k, psi, source, perf);
+    }
+    ffm_set_error("unknown solver %d", solver);
+    return FFM_ERR_UNSUPPORTED;
+}
+
+extern "C" int ffm_solve_d(ffm_ldu *A, int solver, int precond, double tol, double relTol, int minIter, int maxIter,
+                           int nSweeps, double *psi_d, const double *source_d, ffm_perf *out)
+{
+    if (!A || !psi_d || !source_d || !out) { ffm_set_error("ffm_solve_d: null argument"); return FFM_ERR_ARG; }
+    if ((solver == FFM_PCG || solver == FFM_PBICGSTAB || solver == FFM_PBICG) &&
+        !(precond == FFM_NONE || precond == FFM_DIC || precond == FFM_DILU || precond == FFM_DIAGONALP)) {
+        ffm_set_error("solver %d: preconditioner %d not offered", solver, precond); return FFM_ERR_UNSUPPORTED;
+    }
+    memset(out, 0, sizeof(*out));
+    Controls k{tol, relTol, minIter, maxIter, nSweeps};
+    FFM_HIP(hipSetDevice(A->ctx->device));
+    if (A->identity) {
+        FFM_TRY(solve_internal(A, solver, precond, k, psi_d, source_d, out));
+    } else {
+        const double *si; double *pi;
+        FFM_TRY(ffm_to_internal(A, source_d, 1, &si));
+        const double *pin; FFM_TRY(ffm_to_internal(A, psi_d, 2, &pin)); pi = A->permIn[2];
+        FFM_TRY(solve_internal(A, solver, precond, k, pi, si, out));
+        FFM_TRY(ffm_from_internal(A, pi, psi_d));
+    }
+    FFM_HIP(hipStreamSynchronize(A->ctx->stream));
+    return FFM_OK;
+}
+
+extern "C" int ffm_solve(ffm_ldu *A, int solver, int precond, double tol, double relTol, int minIter, int maxIter,
+                         int nSweeps, double *psi, const double *source, ffm_perf *out)
+{
+    if (!A || !psi || !source || !out) return FFM_ERR_ARG;
+    double *p = nullptr, *b = nullptr;
+    const size_t nb = sizeof(double) * (size_t)std::max(A->nCells, 1);
+    FFM_HIP(hipMalloc((void **)&p, nb)); FFM_HIP(hipMalloc((void **)&b, nb));
+    FFM_HIP(hipMemcpy(p, psi, sizeof(double) * A->nCells, hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(b, source, sizeof(double) * A->nCells, hipMemcpyHostToDevice));
+    int rc = ffm_solve_d(A, solver, precond, tol, relTol, minIter, maxIter, nSweeps, p, b, out);
+    if (!rc && hipMemcpy(psi, p, sizeof(double) * A->nCells, hipMemcpyDeviceToHost) != hipSuccess) rc = FFM_ERR_HIP;
+    hipFree(p); hipFree(b);
+    return rc;
+}
+
+// ------------------------------------------- preconditioner entry (tests) ---
+extern "C" int ffm_precond_setup(ffm_ldu *A, int precond, double *rD_out_d)
+{
+    if (!A) return FFM_ERR_ARG;
+    FFM_TRY(ffm_precond_setup_i(A, precond));
+    if (rD_out_d) FFM_TRY(ffm_from_internal(A, A->rD, rD_out_d));
+    FFM_HIP(hipStreamSynchronize(A->ctx->stream));
+    return FFM_OK;
+}
+
+extern "C" int ffm_precond_apply(ffm_ldu *A, int precond, int transpose, const double *r_d, double *w_d)
+{
+    if (!A || !r_d || !w_d) return FFM_ERR_ARG;
+    FFM_TRY(ffm_precond_setup_i(A, precond));
+    const double *ri; FFM_TRY(ffm_to_internal(A, r_d, 0, &ri));
+    if (A->identity) { FFM_TRY(ffm_precond_apply_i(A, precond, transpose != 0, ri, w_d)); }
+    else {
+        double *wi; FFM_TRY(ffm_ldu_work(A, 0, &wi));
+        FFM_TRY(ffm_precond_apply_i(A, precond, transpose != 0, ri, wi));
+        FFM_TRY(ffm_from_internal(A, wi, w_d));
+    }
+    FFM_HIP(hipStreamSynchronize(A->ctx->stream));
+    return FFM_OK;
+}
+
+extern "C" int ffm_gs_smooth(ffm_ldu *A, int symmetric_sweep, int nSweeps, double *psi_d, const double *b_d)
+{
+    if (!A || !psi_d || !b_d || nSweeps < 1) return FFM_ERR_ARG;
+    if (A->identity) { FFM_TRY(ffm_gs_smooth_i(A, symmetric_sweep != 0, nSweeps, psi_d, b_d)); }
+    else {
+        const double *bi, *pin;
+        FFM_TRY(ffm_to_internal(A, b_d, 1, &bi)); FFM_TRY(ffm_to_internal(A, psi_d, 2, &pin));
+        FFM_TRY(ffm_gs_smooth_i(A, symmetric_sweep != 0, nSweeps, A->permIn[2], bi));
+        FFM_TRY(ffm_from_internal(A, A->permIn[2], psi_d));
+    }
+    FFM_HIP(hipStreamSynchronize(A->ctx->stream));
+    return FFM_OK;
+}

@@ -1,0 +1,191 @@
+/*
+ * ffm.h -- C ABI of libffm.so, the MI355X (gfx950) implementation of fireFoam's
+ * per-time-step hot path: lduMatrix kernels, preconditioned Krylov solves and
+ * finite-volume assembly, as hand-written HIP kernels.
+ *
+ * This is the drop-in boundary.  Each entry point names the
+ * reference call site it serves and the OpenFOAM-dev (pinned @940e28f,
+ * reference CHANGELOG:1-3; not vendored in the reference) interface it
+ * replaces.  INTEGRATION.md shows the OpenFOAM-side binding
+ * (a lduMatrix::solver registered through the run-time selection table and
+ * loaded with controlDict `libs (...)`, the mechanism the reference itself
+ * uses in cases/pyrolysis1D/system/controlDict:59-62).
+ *
+ * Conventions: plain C; opaque handles; every function returns 0 on success or
+ * a negative ffm_status; no exceptions cross the boundary; pointers are HOST
+ * pointers unless the parameter name ends in `_d` (device pointer in the
+ * context's HIP device); the library never frees caller memory; one context =
+ * one GPU = one host thread (OpenFOAM runs one rank per process).
+ * All floating point is fp64, all labels int32 (OpenFOAM WM_PRECISION_OPTION=DP,
+ * WM_LABEL_SIZE=32).
+ */
+#ifndef FFM_H
+#define FFM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ffm_ctx ffm_ctx;
+typedef struct ffm_ldu ffm_ldu;
+
+typedef enum ffm_status {
+    FFM_OK = 0,
+    FFM_ERR_ARG = -1,        /* bad argument / inconsistent sizes             */
+    FFM_ERR_ADDR = -2,       /* LDU addressing not upper-triangular ordered   */
+    FFM_ERR_HIP = -3,        /* HIP runtime error (see ffm_last_error)        */
+    FFM_ERR_NODEVICE = -4,   /* no usable GPU                                 */
+    FFM_ERR_UNSUPPORTED = -5,/* solver/preconditioner combination not offered */
+    FFM_ERR_COMM = -6        /* RCCL error                                    */
+} ffm_status;
+
+/* lduMatrix::solver run-time table keys (fvSolution `solver`), reference
+ * cases/steckler/system/fvSolution:21-81, cases/wallFireSpread2D/system/fvSolution:115-152 */
+typedef enum ffm_solver {
+    FFM_PCG = 0, FFM_PBICGSTAB = 1, FFM_PBICG = 2, FFM_DIAGONAL = 3, FFM_SMOOTH = 4
+} ffm_solver;
+/* fvSolution `preconditioner` / `smoother` */
+typedef enum ffm_precond {
+    FFM_NONE = 0, FFM_DIC = 1, FFM_DILU = 2, FFM_GS = 3, FFM_SYMGS = 4, FFM_DIAGONALP = 5
+} ffm_precond;
+
+/* SolverPerformance<scalar> (what `DICPCG:  Solving for p_rgh, Initial residual
+ * = ..., Final residual = ..., No Iterations n` prints; golden log
+ * cases/steckler/original/linux64/log.fireFoam:220)                          */
+typedef struct ffm_perf {
+    double initialResidual, finalResidual;
+    int nIterations, converged, singular;
+} ffm_perf;
+
+/* ------------------------------------------------------------------ context */
+/* stream: a hipStream_t to launch on, or NULL to create a private stream.    */
+int ffm_ctx_create(int device, void *stream, ffm_ctx **out);
+int ffm_ctx_destroy(ffm_ctx *ctx);
+int ffm_ctx_sync(ffm_ctx *ctx);
+void *ffm_ctx_stream(ffm_ctx *ctx);
+const char *ffm_last_error(void);
+const char *ffm_version(void);
+
+/* device memory helpers so a host without HIP headers (the C++ Foam layer, an
+ * OpenFOAM shim) can hold fields on the GPU                                  */
+int ffm_malloc(ffm_ctx *ctx, size_t bytes, void **ptr_d);
+int ffm_free(ffm_ctx *ctx, void *ptr_d);
+int ffm_memcpy_h2d(ffm_ctx *ctx, void *dst_d, const void *src, size_t bytes);
+int ffm_memcpy_d2h(ffm_ctx *ctx, void *dst, const void *src_d, size_t bytes);
+int ffm_memcpy_d2d(ffm_ctx *ctx, void *dst_d, const void *src_d, size_t bytes);
+int ffm_memset(ffm_ctx *ctx, void *dst_d, int value, size_t bytes);
+
+/* ----------------------------------------------------------- lduAddressing */
+/* Replaces lduAddressing + lduMatrix construction
+ * [upstream src/OpenFOAM/matrices/lduMatrix/lduAddressing/lduAddressing.H].
+ * lowerAddr/upperAddr: owner/neighbour cell of every internal face in
+ * OpenFOAM's upper-triangular order (l<u, faces sorted by owner).  Builds on
+ * the device: ownerStart, losort, losortStart, the dependency levels of the
+ * DIC/DILU/Gauss-Seidel sweeps and a level-major cell renumbering (skipped
+ * when the caller's numbering is already level-major).                       */
+int ffm_ldu_create(ffm_ctx *ctx, int nCells, int nFaces, const int *lowerAddr,
+                   const int *upperAddr, ffm_ldu **out);
+int ffm_ldu_destroy(ffm_ldu *ldu);
+int ffm_ldu_ncells(const ffm_ldu *ldu);
+int ffm_ldu_nfaces(const ffm_ldu *ldu);
+int ffm_ldu_nlevels(const ffm_ldu *ldu);
+/* 1 when the caller's cell numbering is used as is (no permutation passes)   */
+int ffm_ldu_is_native_order(const ffm_ldu *ldu);
+/* new->old cell permutation chosen by the library (host, int[nCells])        */
+int ffm_ldu_get_cell_order(const ffm_ldu *ldu, int *newToOld);
+
+/* Level-major renumbering of an LDU graph, for hosts that want to renumber the
+ * mesh once (like renumberMesh) so that no permutation pass is ever needed:
+ * newToOldCell[nCells], newToOldFace[nFaces]; the renumbered faces are again in
+ * upper-triangular order and keep owner<neighbour.  Pure host code.          */
+int ffm_renumber_levels(int nCells, int nFaces, const int *lowerAddr,
+                        const int *upperAddr, int *newToOldCell,
+                        int *newToOldFace);
+
+/* lduMatrix::diag()/upper()/lower(): lower == NULL => symmetric matrix.      */
+int ffm_ldu_set_coeffs(ffm_ldu *ldu, const double *diag, const double *upper,
+                       const double *lower);
+int ffm_ldu_set_coeffs_d(ffm_ldu *ldu, const double *diag_d,
+                         const double *upper_d, const double *lower_d);
+
+/* processor patches (lduInterface / interfaceBouCoeffs / interfaceIntCoeffs):
+ * face i of patch p couples cell faceCells[p][i] (caller numbering) with face i
+ * of the matching patch on rank neighbRank[p]; as in OpenFOAM there is one
+ * patch per neighbour rank (or both sides list their common patches in the
+ * same order).  Amul: y[faceCells] -= bouCoeffs*psi_neighbour.  DIC/DILU ignore
+ * the interfaces (block-Jacobi).  Needs ffm_comm_init / ffm_comm_init_host.   */
+int ffm_ldu_set_interfaces(ffm_ldu *ldu, int nPatches, const int *patchSizes,
+                           const int *const *faceCells,
+                           const double *const *bouCoeffs,
+                           const double *const *intCoeffs,
+                           const int *neighbRank);
+int ffm_ldu_set_global_cells(ffm_ldu *ldu, long globalCells);
+
+/* ------------------------------------------------------- lduMatrix kernels */
+/* lduMatrix::Amul -- the metric kernel (solver/pEqn.H:39 via PCG; UEqn.H() in
+ * solver/pEqn.H:5).  x_d, y_d in the caller's cell numbering.                */
+int ffm_spmv(ffm_ldu *ldu, const double *x_d, double *y_d);
+int ffm_tmul(ffm_ldu *ldu, const double *x_d, double *y_d);      /* ::Tmul     */
+int ffm_sumA(ffm_ldu *ldu, double *s_d);                         /* ::sumA     */
+int ffm_residual(ffm_ldu *ldu, const double *x_d, const double *b_d, double *r_d);
+/* preconditioner pieces, exposed for parity tests             */
+int ffm_precond_setup(ffm_ldu *ldu, int precond, double *rD_out_d /*nullable*/);
+int ffm_precond_apply(ffm_ldu *ldu, int precond, int transpose,
+                      const double *r_d, double *w_d);
+int ffm_gs_smooth(ffm_ldu *ldu, int symmetric_sweep, int nSweeps, double *psi_d,
+                  const double *b_d);
+
+/* lduMatrix::solver::New(...)->solve(psi, source):
+ * psi in/out, source in; controls = fvSolution entries tolerance, relTol,
+ * minIter, maxIter, nSweeps (defaults 1e-6, 0, 0, 1000, 1).                  */
+int ffm_solve_d(ffm_ldu *ldu, int solver, int precond, double tolerance,
+                double relTol, int minIter, int maxIter, int nSweeps,
+                double *psi_d, const double *source_d, ffm_perf *out);
+int ffm_solve(ffm_ldu *ldu, int solver, int precond, double tolerance,
+              double relTol, int minIter, int maxIter, int nSweeps,
+              double *psi, const double *source, ffm_perf *out);
+
+/* timing helper for bench.py: runs `reps` back-to-back launches of the SpMV
+ * kernel used inside the solvers on the context stream, bracketed by HIP
+ * events on that stream; returns the average kernel time in milliseconds.    */
+int ffm_bench_spmv(ffm_ldu *ldu, const double *x_d, double *y_d, int reps,
+                   double *avg_ms);
+
+/* ---------------------------------------------------------------- reductions */
+/* gSum / gMin / gMax / gSumProd / gSumMag over a device field (solver/YEEqn.H:
+ * 73-78,117-118; solver/phrghEqn.H:54-55).  All-reduced when a communicator is
+ * attached.                                                                  */
+int ffm_reduce_sum(ffm_ctx *ctx, const double *x_d, long n, double *out);
+int ffm_reduce_min(ffm_ctx *ctx, const double *x_d, long n, double *out);
+int ffm_reduce_max(ffm_ctx *ctx, const double *x_d, long n, double *out);
+int ffm_reduce_dot(ffm_ctx *ctx, const double *x_d, const double *y_d, long n, double *out);
+int ffm_reduce_summag(ffm_ctx *ctx, const double *x_d, long n, double *out);
+
+/* ---------------------------------------------------------------------- comm */
+/* Pstream replacement: one process per GPU, RCCL over xGMI.
+ * uniqueId = the 128-byte ncclUniqueId made by rank 0 (ffm_comm_unique_id) and
+ * distributed by the host launcher (torch.distributed / MPI / a file).        */
+int ffm_comm_unique_id(void *uniqueId128);
+int ffm_comm_init(ffm_ctx *ctx, int rank, int nRanks, const void *uniqueId128);
+/* Alternative transport through the host launcher (MPI, gloo, ...): lets several
+ * ranks share one GPU (single-GPU testing of the decomposed path).
+ * allreduce: in-place over n doubles, op 0 = sum, 1 = min, 2 = max.
+ * exchange: patch p sends sendBuf[offset[p] .. +size[p]) to rank nbrRank[p] and
+ * receives the same count from it into recvBuf at the same offset.           */
+typedef void (*ffm_host_allreduce_fn)(void *user, double *vals, int n, int op);
+typedef void (*ffm_host_exchange_fn)(void *user, int nPatches, const int *size,
+                                     const int *nbrRank, const int *offset,
+                                     const double *sendBuf, double *recvBuf);
+int ffm_comm_init_host(ffm_ctx *ctx, int rank, int nRanks, void *user,
+                       ffm_host_allreduce_fn allreduce,
+                       ffm_host_exchange_fn exchange);
+int ffm_comm_rank(const ffm_ctx *ctx);
+int ffm_comm_size(const ffm_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,80 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/ffm.h declares."""
+import ctypes
+
+import numpy as np
+
+
+def test_library_loads_and_exports_every_declared_symbol(ffm):
+    declared = ffm.declared_symbols()
+    exported = set(ffm.exported_symbols())
+    assert len(declared) > 30
+    missing = [s for s in declared if s not in exported]
+    assert not missing, "declared in include/ffm.h but not exported by libffm.so: %s" % missing
+    L = ffm.lib()
+    assert b"gfx950" in L.ffm_version()
+
+
+def test_no_gpu_means_loud_failure_not_fallback(ffm):
+    import torch
+    if torch.cuda.is_available():
+        return
+    L = ffm.lib()
+    h = ctypes.c_void_p()
+    rc = L.ffm_ctx_create(0, None, ctypes.byref(h))
+    assert rc == -4 and b"no HIP device" in L.ffm_last_error()      # FFM_ERR_NODEVICE
+    try:
+        ffm.Context(0)
+        assert False, "Context() must raise without a GPU"
+    except ffm.FfmError:
+        pass
+
+
+def test_renumber_levels_host_logic(ffm, O):
+    """ffm_renumber_levels (pure host code): a level-major topological order, faces stay upper-triangular."""
+    H = ffm.hexmesh
+    n = (5, 4, 6)
+    N, l, u = H.hex_ldu(*n)
+    No, lo, uo = O.hex_ldu(*n)
+    assert N == No and np.array_equal(l, lo) and np.array_equal(u, uo)     # product mesh tool == oracle mesh
+    cOrd, fOrd = ffm.renumber_levels(N, l, u)
+    assert sorted(cOrd) == list(range(N)) and sorted(fOrd) == list(range(len(l)))
+    l2, u2, oldToNew = H.apply_renumbering(N, l, u, cOrd, fOrd)
+    assert np.all(l2 < u2) and np.all(np.diff(l2) >= 0)
+    i, j, k = np.unravel_index(cOrd, (n[2], n[1], n[0]))[::-1]
+    lev = i + j + k
+    assert np.all(np.diff(lev) >= 0)                                        # hyperplanes i+j+k, level-major
+    same = np.diff(lev) == 0
+    assert np.all(np.diff(cOrd)[same] > 0)                                  # sorted by caller index inside a level
+    c3, f3 = ffm.renumber_levels(N, l2, u2)                                 # idempotent
+    assert np.array_equal(c3, np.arange(N)) and np.array_equal(f3, np.arange(len(l)))
+
+
+def test_bad_addressing_is_rejected(ffm):
+    L = ffm.lib()
+    l = np.array([1, 0], np.int32); u = np.array([2, 1], np.int32)        # not owner-sorted
+    c = np.empty(3, np.int32); f = np.empty(2, np.int32)
+    ip = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    assert L.ffm_renumber_levels(3, 2, ip(l), ip(u), ip(c), ip(f)) == -2    # FFM_ERR_ADDR
+    l = np.array([0], np.int32); u = np.array([0], np.int32)               # l == u
+    assert L.ffm_renumber_levels(3, 1, ip(l), ip(u), ip(c), ip(f)) == -2
+
+
+def test_synthetic_matrix_decomposition_is_consistent(ffm):
+    """Host logic of the block decomposition: interfaces pair up and the decomposed synthetic
+    matrix is the serial one (row sums incl. interface coefficients agree)."""
+    H = ffm.hexmesh
+    glob = (6, 5, 4)
+    whole = H.HexBlock(glob)
+    s = H.synth_p_rgh(whole)
+    rowsum = s["diag"].copy()
+    np.add.at(rowsum, whole.l, s["upper"]); np.add.at(rowsum, whole.u, s["upper"])
+    blocks, nbr = H.decompose(glob, (2, 2, 1))
+    assert sum(b.nCells for b in blocks) == whole.nCells
+    for r, b in enumerate(blocks):
+        sb = H.synth_p_rgh(b)
+        rs = sb["diag"].copy()
+        np.add.at(rs, b.l, sb["upper"]); np.add.at(rs, b.u, sb["upper"])
+        for itf, bou in zip(sb["interfaces"], sb["bouCoeffs"]):
+            np.add.at(rs, itf["faceCells"], -bou)
+        assert np.allclose(rs, rowsum[b.gcell], rtol=0, atol=1e-18)
+        assert np.array_equal(sb["source"], s["source"][b.gcell])

@@ -1,0 +1,152 @@
+"""CPU tests of the oracle itself (no GPU): dense cross-checks, solver identities and the
+in-process multi-domain runner.  Operator-level parity of the oracle against OpenFOAM is
+unpinned by the reference (it has no unit tests); the golden-log pin is tests/test_golden_log.py."""
+import numpy as np
+import pytest
+
+from common import laplacian_like, random_dag_mesh, rel_l2
+
+
+def dense(N, l, u, diag, up, lo=None):
+    D = np.zeros((N, N))
+    D[np.arange(N), np.arange(N)] = diag
+    D[l, u] = up
+    D[u, l] = up if lo is None else lo
+    return D
+
+
+@pytest.mark.parametrize("n", [3, 6])
+def test_amul_tmul_sumA_residual_vs_dense(O, n):
+    N, l, u = O.hex_ldu(n, n + 1, n + 2)
+    diag, up, lo = laplacian_like(O, N, l, u, asym=0.4)
+    A = O.Ldu(N, l, u).set_coeffs(diag, up, lo)
+    D = dense(N, l, u, diag, up, lo)
+    x = O.hash_u(0xF4, np.arange(N)); b = O.hash_u(0xF3, np.arange(N))
+    assert np.abs(A.amul(x) - D @ x).max() < 1e-13
+    assert np.abs(A.tmul(x) - D.T @ x).max() < 1e-13
+    assert np.abs(A.sumA() - D.sum(axis=1)).max() < 1e-13
+    assert np.abs(A.residual(x, b) - (b - D @ x)).max() < 1e-13
+
+
+def test_hex_numbering_matches_blockmesh_rule(O):
+    nx, ny, nz = 4, 3, 2
+    N, l, u = O.hex_ldu(nx, ny, nz)
+    assert N == 24 and len(l) == (nx - 1) * ny * nz + nx * (ny - 1) * nz + nx * ny * (nz - 1)
+    assert np.all(l < u) and np.all(np.diff(l) >= 0)
+    # within one owner the neighbours ascend (upper-triangular order)
+    same = l[1:] == l[:-1]
+    assert np.all(u[1:][same] > u[:-1][same])
+    assert set(np.unique(u - l)) == {1, nx, nx * ny}
+
+
+def test_dic_is_incomplete_cholesky_exact_on_tridiagonal(O):
+    # 1-D chain: IC(0) == exact Cholesky, so one DIC-PCG iteration solves the system
+    n = 50
+    N, l, u = O.hex_ldu(n, 1, 1)
+    diag, up, _ = laplacian_like(O, N, l, u)
+    A = O.Ldu(N, l, u).set_coeffs(diag, up)
+    b = O.hash_u(3, np.arange(N))
+    psi, perf = A.solve(O.PCG, O.DIC, np.zeros(N), b, tolerance=1e-12)
+    assert perf["nIterations"] == 1
+    assert rel_l2(dense(N, l, u, diag, up) @ psi, b) < 1e-12
+
+
+@pytest.mark.parametrize("solver,precond", [("PCG", "DIC"), ("PBICGSTAB", "DILU"), ("PBICG", "DILU"),
+                                            ("SMOOTH", "SYMGS"), ("SMOOTH", "GS"), ("PCG", "NONE"),
+                                            ("PBICGSTAB", "NONE"), ("PCG", "DIAGONALP")])
+def test_solvers_converge_to_dense_solution(O, solver, precond):
+    n = 7
+    N, l, u = O.hex_ldu(n, n, n)
+    sym = solver == "PCG"
+    diag, up, lo = laplacian_like(O, N, l, u, asym=0.0 if sym else 0.3, shift=0.05)
+    A = O.Ldu(N, l, u).set_coeffs(diag, up, lo)
+    b = 2 * O.hash_u(0xF3, np.arange(N)) - 1
+    psi, perf = A.solve(getattr(O, solver), getattr(O, precond), np.zeros(N), b, tolerance=1e-11, maxIter=2000)
+    assert perf["converged"] == 1 and perf["initialResidual"] == 1.0
+    ref = np.linalg.solve(dense(N, l, u, diag, up, lo), b)
+    assert rel_l2(psi, ref) < 1e-8
+
+
+def test_diagonal_solver_and_zero_iteration_exit(O):
+    N, l, u = O.hex_ldu(3, 3, 3)
+    diag = 1.0 + O.hash_u(1, np.arange(N))
+    A = O.Ldu(N, l, u).set_coeffs(diag, np.zeros(len(l)))
+    b = O.hash_u(2, np.arange(N))
+    psi, perf = A.solve(O.DIAGONAL, O.NONE, np.zeros(N), b)
+    assert np.array_equal(psi, b / diag) and perf["nIterations"] == 0 and perf["finalResidual"] == 0.0
+    # already converged initial guess: PCG must not iterate (golden log: 'No Iterations 0')
+    psi2, perf2 = A.solve(O.PCG, O.DIC, psi, b, tolerance=1e-6)
+    assert perf2["nIterations"] == 0 and np.array_equal(psi2, psi)
+
+
+def test_relTol_and_maxIter_semantics(O):
+    n = 8
+    N, l, u = O.hex_ldu(n, n, n)
+    diag, up, _ = laplacian_like(O, N, l, u)
+    A = O.Ldu(N, l, u).set_coeffs(diag, up)
+    b = 2 * O.hash_u(0xF3, np.arange(N)) - 1
+    _, p1 = A.solve(O.PCG, O.DIC, np.zeros(N), b, tolerance=1e-12, relTol=0.01)
+    assert p1["finalResidual"] < 0.01 * p1["initialResidual"] and p1["finalResidual"] > 1e-12
+    _, p2 = A.solve(O.PCG, O.DIC, np.zeros(N), b, tolerance=1e-30, maxIter=3)
+    assert p2["nIterations"] == 3 and p2["converged"] == 0
+    _, p3 = A.solve(O.SMOOTH, O.SYMGS, np.zeros(N), b, tolerance=1e-30, maxIter=10, nSweeps=4)
+    assert p3["nIterations"] == 12   # counts in steps of nSweeps, as smoothSolver does
+
+
+def test_renumbered_mesh_gives_same_dic_pcg(O, ffm):
+    """Level-major renumbering is a topological order of the same DAG: DIC-PCG on the renumbered
+    matrix follows the same iteration history (hex box: identical row accumulation order)."""
+    n = 6
+    N, l, u = O.hex_ldu(n, n + 2, n + 1)
+    diag, up, _ = laplacian_like(O, N, l, u)
+    b = 2 * O.hash_u(0xF3, np.arange(N)) - 1
+    psi0, perf0 = O.Ldu(N, l, u).set_coeffs(diag, up).solve(O.PCG, O.DIC, np.zeros(N), b, tolerance=1e-10)
+    cOrd, fOrd = ffm.renumber_levels(N, l, u)
+    l2, u2, _ = ffm.hexmesh.apply_renumbering(N, l, u, cOrd, fOrd)
+    psi1, perf1 = O.Ldu(N, l2, u2).set_coeffs(diag[cOrd], up[fOrd]).solve(O.PCG, O.DIC, np.zeros(N), b[cOrd], tolerance=1e-10)
+    assert perf1["nIterations"] == perf0["nIterations"]
+    assert rel_l2(psi1, psi0[cOrd]) < 1e-13
+
+
+def _decomposed_case(O, ffm, glob, grid, asym=False):
+    H = ffm.hexmesh
+    blocks, nbrRank = H.decompose(glob, grid)
+    ldus, srcs = [], []
+    nbrPatch = []
+    for r, blk in enumerate(blocks):
+        s = H.synth_p_rgh(blk)
+        A = O.Ldu(blk.nCells, blk.l, blk.u).set_coeffs(s["diag"], s["upper"])
+        A.set_interfaces([i["faceCells"] for i in s["interfaces"]], s["bouCoeffs"])
+        ldus.append(A); srcs.append(s["source"])
+    for r, blk in enumerate(blocks):
+        pp = []
+        for q, itf in enumerate(blk.interfaces()):
+            other = blocks[nbrRank[r][q]].interfaces()
+            match = [k for k, o in enumerate(other) if o["dir"] == itf["dir"] and o["side"] != itf["side"]
+                     and nbrRank[nbrRank[r][q]][k] == r]
+            assert len(match) == 1
+            assert np.array_equal(other[match[0]]["gface"], itf["gface"])
+            pp.append(match[0])
+        nbrPatch.append(pp)
+    return blocks, nbrRank, nbrPatch, ldus, srcs
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
+def test_multi_domain_matches_serial(O, ffm, grid):
+    """T8: decomposed (block-Jacobi DIC) vs serial: converged fields agree <= 1e-10 at tolerance 1e-12."""
+    H = ffm.hexmesh
+    glob = (8, 6, 8)
+    whole = H.HexBlock(glob)
+    s = H.synth_p_rgh(whole)
+    psiS, perfS = O.Ldu(whole.nCells, whole.l, whole.u).set_coeffs(s["diag"], s["upper"]).solve(
+        O.PCG, O.DIC, np.zeros(whole.nCells), s["source"], tolerance=1e-12)
+    blocks, nbrRank, nbrPatch, ldus, srcs = _decomposed_case(O, ffm, glob, grid)
+    psis, perfs = O.solve_multi(ldus, nbrRank, nbrPatch, O.PCG, O.DIC, [np.zeros(b.nCells) for b in blocks], srcs,
+                                tolerance=1e-12)
+    assert all(p["converged"] for p in perfs)
+    assert len({p["nIterations"] for p in perfs}) == 1
+    assert abs(perfs[0]["initialResidual"] - perfS["initialResidual"]) < 1e-12
+    full = np.empty(whole.nCells)
+    for b, p in zip(blocks, psis):
+        full[b.gcell] = p
+    assert rel_l2(full, psiS) < 1e-10
