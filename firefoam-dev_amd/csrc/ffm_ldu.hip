@@ -39,7 +39,7 @@ struct LduAnalysis {
     bool identity = true, bwdContig = true;
 };
 
-static int analyse(int N, int F, const int *l, const int *u, bool renumber, LduAnalysis &a)
+static int analyse(int N, int F, const int *l, const int *u, bool renumber, bool sortByNewNeighbour, LduAnalysis &a)
 {
     for (int f = 0; f < F; f++) {
         if (l[f] < 0 || u[f] >= N || l[f] >= u[f]) {
@@ -88,7 +88,10 @@ static int analyse(int N, int F, const int *l, const int *u, bool renumber, LduA
         for (int c = 0; c < N; c++) cnt[c + 1] += cnt[c];
         std::vector<int> pos(cnt.begin(), cnt.end() - 1);
         for (int f = 0; f < F; f++) a.newToOldFace[pos[a.oldToNewCell[l[f]]]++] = f;
-        for (int c = 0; c < N; c++) {
+        // The counting sort leaves the faces of one owner in the caller's face order.  The device
+        // layout keeps that order so every row is accumulated exactly as in the caller's face loop;
+        // the public renumbering sorts by the new neighbour (a proper upper-triangular mesh).
+        if (sortByNewNeighbour) for (int c = 0; c < N; c++) {
             std::sort(a.newToOldFace.begin() + cnt[c], a.newToOldFace.begin() + cnt[c + 1],
                       [&](int f1, int f2) { return a.oldToNewCell[u[f1]] < a.oldToNewCell[u[f2]]; });
         }
@@ -126,7 +129,7 @@ extern "C" int ffm_renumber_levels(int nCells, int nFaces, const int *l, const i
 {
     if (nCells < 0 || nFaces < 0 || (nFaces && (!l || !u))) return FFM_ERR_ARG;
     LduAnalysis a;
-    FFM_TRY(analyse(nCells, nFaces, l, u, true, a));
+    FFM_TRY(analyse(nCells, nFaces, l, u, true, true, a));
     if (newToOldCell) std::copy(a.newToOldCell.begin(), a.newToOldCell.end(), newToOldCell);
     if (newToOldFace) std::copy(a.newToOldFace.begin(), a.newToOldFace.end(), newToOldFace);
     return FFM_OK;
@@ -146,7 +149,7 @@ extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const in
     if (!ctx || !out || N < 0 || F < 0 || (F && (!l || !u))) { ffm_set_error("ffm_ldu_create: bad argument"); return FFM_ERR_ARG; }
     FFM_HIP(hipSetDevice(ctx->device));
     LduAnalysis a;
-    FFM_TRY(analyse(N, F, l, u, true, a));
+    FFM_TRY(analyse(N, F, l, u, true, false, a));
     ffm_ldu *A = new ffm_ldu();
     A->ctx = ctx; A->nCells = N; A->nFaces = F; A->globalCells = N;
     A->identity = a.identity; A->bwdContig = a.bwdContig;
@@ -159,8 +162,11 @@ extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const in
     for (int f = 0; f < F; f++) { ownStart[a.l[f] + 1]++; loStart[a.u[f] + 1]++; }
     for (int c = 0; c < N; c++) { ownStart[c + 1] += ownStart[c]; loStart[c + 1] += loStart[c]; }
     {
+        // lower lists in the CALLER's face order (losort of the caller's addressing)
+        std::vector<int> oldToNewFace(F);
+        for (int f = 0; f < F; f++) oldToNewFace[a.newToOldFace[f]] = f;
         std::vector<int> pos(loStart.begin(), loStart.end() - 1);
-        for (int f = 0; f < F; f++) { int k = pos[a.u[f]]++; loFace[k] = f; loNbr[k] = a.l[f]; }
+        for (int of = 0; of < F; of++) { const int f = oldToNewFace[of]; int k = pos[a.u[f]]++; loFace[k] = f; loNbr[k] = a.l[f]; }
     }
     if (A->bwdContig) {
         // keep only the first cell of every backward level: ranges are [first, first+count)
