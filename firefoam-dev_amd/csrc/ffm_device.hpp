@@ -68,3 +68,67 @@ __device__ __forceinline__ double block_max(double v, double *sm)
     }
     return r;
 }
+
+// ------------------------------------------------------ sliced owner-ELL view ---
+// Passed by value to every kernel that walks matrix rows (layout: ffm_internal.hpp).
+struct LduView {
+    int N;
+    const int *upOff, *loOff;   // [nSlices+1]
+    const int *upNbr;           // [upTotal]
+    const int *loEnt;           // [loTotal]
+    int upW;                    // uniform upper width of every slice, or -1
+    int loW;                    // uniform lower width of every slice, or -1
+};
+
+// first native face index of the slice of cell c
+__device__ __forceinline__ int up_base(const LduView &v, int sl) { return v.upW >= 0 ? sl * v.upW * 64 : v.upOff[sl]; }
+__device__ __forceinline__ int up_width(const LduView &v, int sl) { return v.upW >= 0 ? v.upW : (v.upOff[sl + 1] - v.upOff[sl]) >> 6; }
+__device__ __forceinline__ int lo_base(const LduView &v, int sl) { return v.loW >= 0 ? sl * v.loW * 64 : v.loOff[sl]; }
+__device__ __forceinline__ int lo_width(const LduView &v, int sl) { return v.loW >= 0 ? v.loW : (v.loOff[sl + 1] - v.loOff[sl]) >> 6; }
+// native face index of slot `slot` in the row of cell `cell`
+__device__ __forceinline__ int face_of(const LduView &v, int cell, int slot) { return up_base(v, cell >> 6) + slot * 64 + (cell & 63); }
+
+// Row loaders: fetch all lower / upper entries of the row of cell c into registers with
+// predicated, fully unrolled loads (W = compile-time bound on the slot count), so that the
+// index loads of all slots are in flight together and the dependent gathers likewise: a row
+// costs two memory round trips instead of two per slot.  Padding slots point at harmless
+// addresses (own cell, face 0) and are masked out of the arithmetic.
+template <int W> struct RowEnt { int nb[W]; int f[W]; bool on[W]; };
+
+template <int W>
+__device__ __forceinline__ void load_lower(const LduView &v, int c, RowEnt<W> &R)
+{
+    const int sl = c >> 6, lane = c & 63;
+    const int lb = lo_base(v, sl), lw = lo_width(v, sl);
+    int e[W];
+#pragma unroll
+    for (int s = 0; s < W; s++) e[s] = (s < lw) ? v.loEnt[lb + s * 64 + lane] : -1;
+#pragma unroll
+    for (int s = 0; s < W; s++) {
+        R.on[s] = e[s] >= 0;
+        R.nb[s] = R.on[s] ? (e[s] >> 4) : c;
+        R.f[s] = R.on[s] ? face_of(v, R.nb[s], e[s] & 15) : 0;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void load_upper(const LduView &v, int c, RowEnt<W> &R)
+{
+    const int sl = c >> 6, lane = c & 63;
+    const int ub = up_base(v, sl), uw = up_width(v, sl);
+#pragma unroll
+    for (int s = 0; s < W; s++) {
+        const int idx = ub + s * 64 + lane;
+        const int n = (s < uw) ? v.upNbr[idx] : -1;
+        R.on[s] = n >= 0;
+        R.nb[s] = R.on[s] ? n : c;
+        R.f[s] = R.on[s] ? idx : 0;
+    }
+}
+
+#define FFM_DISPATCH_W(maxW, CALL)                      \
+    do {                                                \
+        if ((maxW) <= 4) { constexpr int W = 4; CALL; } \
+        else if ((maxW) <= 8) { constexpr int W = 8; CALL; } \
+        else { constexpr int W = 16; CALL; }            \
+    } while (0)

@@ -91,17 +91,31 @@ struct ffm_ldu {
     std::vector<int> h_bwdFirstCell;    // [nBwdLevels] first cell of each level (bwdContig)
     int nLevels = 0, nBwdLevels = 0;
 
-    // device addressing (internal numbering)
-    int *lAddr = nullptr, *uAddr = nullptr;      // [F]
-    int *ownStart = nullptr;                     // [N+1]
-    int *loStart = nullptr;                      // [N+1]
-    int *loFace = nullptr;                       // [F] losort (face id)
-    int *loNbr = nullptr;                        // [F] l[losort[k]]
+    // device addressing (internal cell numbering): sliced owner-ELL.
+    // Cells are grouped in slices of 64 (one wavefront).  Slice sl stores its faces slot-major:
+    //   upper part: entry e = upOff[sl] + s*64 + lane, s < upper width of the slice
+    //       upNbr[e]  = neighbour cell of the s-th face OWNED by cell sl*64+lane (-1 = padding)
+    //       upper[e] / lower[e] = the face's upper / lower coefficient (0 on padding)
+    //     e is the library's NATIVE FACE INDEX; the owner of a native face is implicit.
+    //   lower part: entry q = loOff[sl] + s*64 + lane
+    //       loEnt[q] = (owner cell << 4) | slot of that face in the owner's row  (-1 = padding)
+    //     listing the faces whose NEIGHBOUR is the cell, in the caller's face order.
+    // Every load of an index or coefficient array is unit-stride across the wave; the symmetric
+    // coefficient is stored once and re-read through the (nbr, slot) pair by the neighbour row.
+    int nSlices = 0, upTotal = 0, loTotal = 0;
+    int upWidthUniform = -1;                     // >= 0: every slice has this upper width
+    int loWidthUniform = -1;
+    int maxW = 0;                                // max slots (lower or upper) of any row
+    int *upOff = nullptr, *loOff = nullptr;      // [nSlices+1]
+    int *upNbr = nullptr;                        // [upTotal]
+    int *loEnt = nullptr;                        // [loTotal]
     int *bwdOrder = nullptr;                     // [N] (only when !bwdContig)
     int *cellPerm = nullptr;                     // [N] new->old (only when !identity)
-    int *facePerm = nullptr;                     // [F] new->old (only when !identity)
+    int *faceSrc = nullptr;                      // [upTotal] native face -> caller face id (-1 padding)
+    std::vector<int> h_callerToNative;           // [F] caller face id -> native face index
+    int *callerToNative = nullptr;               // device copy (on demand)
 
-    // coefficients (internal numbering)
+    // coefficients (internal numbering / native face index)
     double *diag = nullptr, *upper = nullptr, *lower = nullptr;  // lower==upper when symmetric
     double *lowerBuf = nullptr;                                  // storage for asymmetric lower
 
@@ -130,6 +144,8 @@ struct ffm_ldu {
     std::map<SweepGraphKey, hipGraphExec_t> graphs;
 };
 
+struct LduView;
+LduView ffm_view(const ffm_ldu *A);
 // ---- internal helpers shared between translation units -------------------
 int ffm_ldu_work(ffm_ldu *A, int idx, double **out);           // lazily allocated N-vectors
 int ffm_to_internal(ffm_ldu *A, const double *x_d, int slot, const double **out);

@@ -18,12 +18,18 @@
 //   numbering.  A caller whose mesh is already level-major (ffm_renumber_levels)
 //   pays no permutation pass at all.
 //
-//   Row-gather form of the face loops: for cell c
-//     lower part : k in [loStart[c], loStart[c+1])  -> face loFace[k], column loNbr[k]
-//     upper part : f in [ownStart[c], ownStart[c+1]) -> column uAddr[f]
-//   which visits the faces of c in exactly the order of the serial face loop
-//   (all faces with neighbour c precede all faces owned by c), so each row is
-//   accumulated in the reference's order, with no atomics.
+//   Faces are stored as a sliced owner-ELL (slices of 64 cells = one wavefront,
+//   slot-major inside a slice; see ffm_internal.hpp): every index / coefficient
+//   load is unit-stride across the wave, the owner of a face is implicit, and a
+//   symmetric coefficient is stored once -- the neighbour row re-reads it through
+//   a packed (owner cell, slot) entry, which hits cache because neighbouring rows
+//   are neighbours in memory.  HBM traffic of a symmetric Amul is therefore the
+//   algorithmic 24 N + 16 F bytes plus padding.
+//   Row form of the face loops: row c first adds its lower entries (faces whose
+//   neighbour is c, in the caller's face order), then its upper slots (faces
+//   owned by c, in the caller's face order) -- exactly the order in which the
+//   serial face loop of the reference touches row c, so no atomics are needed
+//   and every row sum is bitwise the reference's.
 #include "ffm_internal.hpp"
 #include "ffm_device.hpp"
 #include <algorithm>
@@ -157,16 +163,50 @@ extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const in
     A->nBwdLevels = (int)a.bwdLevelStart.size() - 1; if (A->nBwdLevels < 0) A->nBwdLevels = 0;
     A->h_fwdLevelStart = a.fwdLevelStart; A->h_bwdLevelStart = a.bwdLevelStart;
     A->h_newToOldCell = a.newToOldCell; A->h_newToOldFace = a.newToOldFace;
-    // derived addressing
-    std::vector<int> ownStart(N + 1, 0), loStart(N + 1, 0), loFace(F), loNbr(F);
-    for (int f = 0; f < F; f++) { ownStart[a.l[f] + 1]++; loStart[a.u[f] + 1]++; }
-    for (int c = 0; c < N; c++) { ownStart[c + 1] += ownStart[c]; loStart[c + 1] += loStart[c]; }
+    // derived addressing: sliced owner-ELL
+    const int nSl = (N + 63) / 64;
+    A->nSlices = nSl;
+    std::vector<int> upCnt(N, 0), loCnt(N, 0);
+    for (int f = 0; f < F; f++) { upCnt[a.l[f]]++; loCnt[a.u[f]]++; }
+    std::vector<int> upOff(nSl + 1, 0), loOff(nSl + 1, 0);
+    int uniform = -2, uniformLo = -2, maxW = 0;
+    for (int sl = 0; sl < nSl; sl++) {
+        int wu = 0, wl = 0;
+        for (int c = sl * 64; c < std::min(N, sl * 64 + 64); c++) { wu = std::max(wu, upCnt[c]); wl = std::max(wl, loCnt[c]); }
+        if (wu > 16 || wl > 16) { ffm_set_error("a cell owns %d faces (>16): not supported by the packed layout", wu); delete A; return FFM_ERR_UNSUPPORTED; }
+        upOff[sl + 1] = upOff[sl] + wu * 64; loOff[sl + 1] = loOff[sl] + wl * 64;
+        uniform = (uniform == -2) ? wu : (uniform == wu ? wu : -1);
+        uniformLo = (uniformLo == -2) ? wl : (uniformLo == wl ? wl : -1);
+        maxW = std::max(maxW, std::max(wu, wl));
+    }
+    if ((long)nSl * 16 * 64 > 0x7fffffffL || N >= (1 << 27)) { ffm_set_error("mesh too large for int32 packed entries"); delete A; return FFM_ERR_UNSUPPORTED; }
+    A->upTotal = upOff[nSl]; A->loTotal = loOff[nSl];
+    A->upWidthUniform = (uniform >= 0) ? uniform : -1;
+    A->loWidthUniform = (uniformLo >= 0) ? uniformLo : -1;
+    A->maxW = maxW;
+    std::vector<int> upNbr(std::max(A->upTotal, 1), -1), faceSrc(std::max(A->upTotal, 1), -1), loEnt(std::max(A->loTotal, 1), -1);
+    A->h_callerToNative.assign(F, -1);
     {
-        // lower lists in the CALLER's face order (losort of the caller's addressing)
+        // upper slots: faces of one owner are consecutive in a.l (owner-sorted), caller order inside
+        std::vector<int> slotOfFace(F);
+        int prev = -1, slot = 0;
+        for (int f = 0; f < F; f++) {
+            const int c = a.l[f];
+            slot = (c == prev) ? slot + 1 : 0; prev = c;
+            slotOfFace[f] = slot;
+            const int e = upOff[c >> 6] + slot * 64 + (c & 63);
+            upNbr[e] = a.u[f]; faceSrc[e] = a.newToOldFace[f];
+            A->h_callerToNative[a.newToOldFace[f]] = e;
+        }
+        // lower entries in the CALLER's face order (losort of the caller's addressing)
         std::vector<int> oldToNewFace(F);
         for (int f = 0; f < F; f++) oldToNewFace[a.newToOldFace[f]] = f;
-        std::vector<int> pos(loStart.begin(), loStart.end() - 1);
-        for (int of = 0; of < F; of++) { const int f = oldToNewFace[of]; int k = pos[a.u[f]]++; loFace[k] = f; loNbr[k] = a.l[f]; }
+        std::vector<int> fill(N, 0);
+        for (int of = 0; of < F; of++) {
+            const int f = oldToNewFace[of], c = a.u[f];
+            const int q = loOff[c >> 6] + fill[c]++ * 64 + (c & 63);
+            loEnt[q] = (a.l[f] << 4) | slotOfFace[f];
+        }
     }
     if (A->bwdContig) {
         // keep only the first cell of every backward level: ranges are [first, first+count)
@@ -178,18 +218,14 @@ extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const in
     }
     int rc = FFM_OK;
     do {
-        if ((rc = upload(ctx, &A->lAddr, a.l))) break;
-        if ((rc = upload(ctx, &A->uAddr, a.u))) break;
-        if ((rc = upload(ctx, &A->ownStart, ownStart))) break;
-        if ((rc = upload(ctx, &A->loStart, loStart))) break;
-        if ((rc = upload(ctx, &A->loFace, loFace))) break;
-        if ((rc = upload(ctx, &A->loNbr, loNbr))) break;
+        if ((rc = upload(ctx, &A->upOff, upOff))) break;
+        if ((rc = upload(ctx, &A->loOff, loOff))) break;
+        if ((rc = upload(ctx, &A->upNbr, upNbr))) break;
+        if ((rc = upload(ctx, &A->loEnt, loEnt))) break;
+        if ((rc = upload(ctx, &A->faceSrc, faceSrc))) break;
         if (!A->bwdContig && (rc = upload(ctx, &A->bwdOrder, a.bwdOrder))) break;
-        if (!A->identity) {
-            if ((rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
-            if ((rc = upload(ctx, &A->facePerm, a.newToOldFace))) break;
-        }
-        size_t nb = sizeof(double) * (size_t)std::max(N, 1), fb = sizeof(double) * (size_t)std::max(F, 1);
+        if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
+        size_t nb = sizeof(double) * (size_t)std::max(N, 1), fb = sizeof(double) * (size_t)std::max(A->upTotal, 1);
         if (hipMalloc((void **)&A->diag, nb) != hipSuccess || hipMalloc((void **)&A->upper, fb) != hipSuccess ||
             hipMalloc((void **)&A->rD, nb) != hipSuccess) { ffm_set_error("ffm_ldu_create: hipMalloc failed"); rc = FFM_ERR_HIP; break; }
         A->lower = A->upper;
@@ -209,8 +245,8 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     for (auto &kv : A->graphs) hipGraphExecDestroy(kv.second);
     for (double *w : A->work) hipFree(w);
     for (int i = 0; i < 3; i++) hipFree(A->permIn[i]);
-    hipFree(A->lAddr); hipFree(A->uAddr); hipFree(A->ownStart); hipFree(A->loStart); hipFree(A->loFace);
-    hipFree(A->loNbr); hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->facePerm);
+    hipFree(A->upOff); hipFree(A->loOff); hipFree(A->upNbr); hipFree(A->loEnt); hipFree(A->faceSrc);
+    hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative);
     hipFree(A->diag); hipFree(A->upper); hipFree(A->lowerBuf); hipFree(A->rD);
     hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);
     hipFree(A->ifCell); hipFree(A->ifCellStart); hipFree(A->ifItem);
@@ -226,6 +262,13 @@ extern "C" int ffm_ldu_get_cell_order(const ffm_ldu *A, int *newToOld)
 {
     if (!A || !newToOld) return FFM_ERR_ARG;
     std::copy(A->h_newToOldCell.begin(), A->h_newToOldCell.end(), newToOld);
+    return FFM_OK;
+}
+extern "C" int ffm_ldu_n_native_faces(const ffm_ldu *A) { return A ? A->upTotal : FFM_ERR_ARG; }
+extern "C" int ffm_ldu_get_face_map(const ffm_ldu *A, int *callerToNative)
+{
+    if (!A || !callerToNative) return FFM_ERR_ARG;
+    std::copy(A->h_callerToNative.begin(), A->h_callerToNative.end(), callerToNative);
     return FFM_OK;
 }
 extern "C" int ffm_ldu_set_global_cells(ffm_ldu *A, long g) { if (!A || g < A->nCells) return FFM_ERR_ARG; A->globalCells = g; return FFM_OK; }
@@ -271,26 +314,33 @@ int ffm_from_internal(ffm_ldu *A, const double *xin, double *x_d)
     return FFM_OK;
 }
 
+// gather with padding: dst[e] = (src_idx[e] >= 0) ? src[src_idx[e]] : 0   (LDU face order -> native faces)
+__global__ void k_gather_faces(long n, const int *__restrict__ srcIdx, const double *__restrict__ src, double *__restrict__ dst)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int f = srcIdx[i];
+        dst[i] = (f >= 0) ? src[f] : 0.0;
+    }
+}
+
 extern "C" int ffm_ldu_set_coeffs_d(ffm_ldu *A, const double *diag_d, const double *upper_d, const double *lower_d)
 {
     if (!A || !diag_d || (A->nFaces && !upper_d)) return FFM_ERR_ARG;
     hipStream_t s = A->ctx->stream;
-    const size_t nb = sizeof(double) * A->nCells, fb = sizeof(double) * A->nFaces;
+    const size_t nb = sizeof(double) * A->nCells, fb = sizeof(double) * std::max(A->upTotal, 1);
     if (lower_d && lower_d != upper_d) {
-        if (!A->lowerBuf) FFM_HIP(hipMalloc((void **)&A->lowerBuf, std::max(fb, sizeof(double))));
+        if (!A->lowerBuf) FFM_HIP(hipMalloc((void **)&A->lowerBuf, fb));
         A->lower = A->lowerBuf; A->symmetric = false;
     } else { A->lower = A->upper; A->symmetric = true; }
-    if (A->identity) {
-        FFM_HIP(hipMemcpyAsync(A->diag, diag_d, nb, hipMemcpyDeviceToDevice, s));
-        if (fb) FFM_HIP(hipMemcpyAsync(A->upper, upper_d, fb, hipMemcpyDeviceToDevice, s));
-        if (!A->symmetric && fb) FFM_HIP(hipMemcpyAsync(A->lower, lower_d, fb, hipMemcpyDeviceToDevice, s));
-    } else {
-        hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->cellPerm, diag_d, A->diag);
-        hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nFaces)), dim3(256), 0, s, (long)A->nFaces, A->facePerm, upper_d, A->upper);
+    if (A->identity) { if (nb) FFM_HIP(hipMemcpyAsync(A->diag, diag_d, nb, hipMemcpyDeviceToDevice, s)); }
+    else hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->cellPerm, diag_d, A->diag);
+    if (A->upTotal) {
+        hipLaunchKernelGGL(k_gather_faces, dim3(stream_grid(A->upTotal)), dim3(256), 0, s, (long)A->upTotal, A->faceSrc, upper_d, A->upper);
         if (!A->symmetric)
-            hipLaunchKernelGGL(k_gather, dim3(stream_grid(A->nFaces)), dim3(256), 0, s, (long)A->nFaces, A->facePerm, lower_d, A->lower);
-        FFM_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_gather_faces, dim3(stream_grid(A->upTotal)), dim3(256), 0, s, (long)A->upTotal, A->faceSrc, lower_d, A->lower);
     }
+    FFM_HIP(hipGetLastError());
     A->coeffEpoch++;
     return FFM_OK;
 }
@@ -312,42 +362,75 @@ extern "C" int ffm_ldu_set_coeffs(ffm_ldu *A, const double *diag, const double *
     return rc;
 }
 
+// native-layout entry for hosts that assemble directly in the library's face layout
+extern "C" int ffm_ldu_set_coeffs_native_d(ffm_ldu *A, const double *diag_d, const double *upper_d, const double *lower_d)
+{
+    if (!A || !diag_d || (A->upTotal && !upper_d)) return FFM_ERR_ARG;
+    if (!A->identity) { ffm_set_error("native coefficient layout needs the library's cell order (ffm_renumber_levels)"); return FFM_ERR_UNSUPPORTED; }
+    hipStream_t s = A->ctx->stream;
+    const size_t nb = sizeof(double) * A->nCells, fb = sizeof(double) * A->upTotal;
+    if (lower_d && lower_d != upper_d) {
+        if (!A->lowerBuf) FFM_HIP(hipMalloc((void **)&A->lowerBuf, std::max(fb, sizeof(double))));
+        A->lower = A->lowerBuf; A->symmetric = false;
+        if (fb) FFM_HIP(hipMemcpyAsync(A->lower, lower_d, fb, hipMemcpyDeviceToDevice, s));
+    } else { A->lower = A->upper; A->symmetric = true; }
+    if (nb) FFM_HIP(hipMemcpyAsync(A->diag, diag_d, nb, hipMemcpyDeviceToDevice, s));
+    if (fb) FFM_HIP(hipMemcpyAsync(A->upper, upper_d, fb, hipMemcpyDeviceToDevice, s));
+    A->coeffEpoch++;
+    return FFM_OK;
+}
+
+LduView ffm_view(const ffm_ldu *A)
+{
+    LduView v; v.N = A->nCells; v.upOff = A->upOff; v.loOff = A->loOff; v.upNbr = A->upNbr; v.loEnt = A->loEnt;
+    v.upW = A->upWidthUniform; v.loW = A->loWidthUniform;
+    return v;
+}
+
 // ----------------------------------------------------------- lduMatrix::Amul ---
-// One thread per row, grid-stride over a fixed grid.  MODE 0: y = A x.
-// MODE 1: r = b - A x (lduMatrix::residual order).  MODE 2: s = sumA.
+// One thread per row, grid-stride over a fixed grid; a wave = one slice, so all
+// index/coefficient loads are unit-stride and the slot loops are wave-uniform.
+// MODE 0: y = A x.  MODE 1: r = b - A x (lduMatrix::residual order).  MODE 2: s = sumA.
 // DOT: additionally accumulates the block-partial of x[c]*y[c] (PCG's wApA).
-template <int MODE, bool DOT>
-__global__ __launch_bounds__(256) void k_rows(int N, const double *__restrict__ diag,
+template <int MODE, bool DOT, int W>
+__global__ __launch_bounds__(256) void k_rows(LduView v, const double *__restrict__ diag,
                                               const double *__restrict__ upper, const double *__restrict__ lower,
-                                              const int *__restrict__ ownStart, const int *__restrict__ uAddr,
-                                              const int *__restrict__ loStart, const int *__restrict__ loFace,
-                                              const int *__restrict__ loNbr, const double *__restrict__ x,
-                                              const double *__restrict__ b, double *__restrict__ y,
-                                              double *__restrict__ partials)
+                                              const double *__restrict__ x, const double *__restrict__ b,
+                                              double *__restrict__ y, double *__restrict__ partials)
 {
     __shared__ double sm[4];
     double dot = 0.0;
     const int stride = gridDim.x * blockDim.x;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < N; c += stride) {
-        const int k0 = loStart[c], k1 = loStart[c + 1], f0 = ownStart[c], f1 = ownStart[c + 1];
-        double acc;
-        if (MODE == 0) acc = diag[c] * x[c];
-        else if (MODE == 1) acc = b[c] - diag[c] * x[c];
-        else acc = diag[c];
-        for (int k = k0; k < k1; k++) {
-            const double a = lower[loFace[k]];
-            if (MODE == 0) acc += a * x[loNbr[k]];
-            else if (MODE == 1) acc -= a * x[loNbr[k]];
-            else acc += a;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < v.N; c += stride) {
+        RowEnt<W> L, U;
+        load_lower<W>(v, c, L);
+        load_upper<W>(v, c, U);
+        double al[W], au[W], xl[W], xu[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) { al[s] = lower[L.f[s]]; au[s] = upper[U.f[s]]; }
+        if (MODE != 2) {
+#pragma unroll
+            for (int s = 0; s < W; s++) { xl[s] = x[L.nb[s]]; xu[s] = x[U.nb[s]]; }
         }
-        for (int f = f0; f < f1; f++) {
-            const double a = upper[f];
-            if (MODE == 0) acc += a * x[uAddr[f]];
-            else if (MODE == 1) acc -= a * x[uAddr[f]];
-            else acc += a;
+        double xc = 0.0, acc;
+        if (MODE != 2) xc = x[c];
+        if (MODE == 0) acc = diag[c] * xc;
+        else if (MODE == 1) acc = b[c] - diag[c] * xc;
+        else acc = diag[c];
+#pragma unroll
+        for (int s = 0; s < W; s++) if (L.on[s]) {
+            if (MODE == 0) acc += al[s] * xl[s];
+            else if (MODE == 1) acc -= al[s] * xl[s];
+            else acc += al[s];
+        }
+#pragma unroll
+        for (int s = 0; s < W; s++) if (U.on[s]) {
+            if (MODE == 0) acc += au[s] * xu[s];
+            else if (MODE == 1) acc -= au[s] * xu[s];
+            else acc += au[s];
         }
         y[c] = acc;
-        if (DOT) dot += acc * x[c];
+        if (DOT) dot += acc * xc;
     }
     if (DOT) {
         double r = block_sum(dot, sm);
@@ -369,8 +452,8 @@ static inline int rows_grid(const ffm_ldu *A) { return stream_grid(A->nCells); }
 int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
 {
     const double *up = transpose ? A->lower : A->upper, *lo = transpose ? A->upper : A->lower;
-    hipLaunchKernelGGL((k_rows<0, false>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, up, lo,
-                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, x, (const double *)nullptr, y, (double *)nullptr);
+    FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
+                                               A->diag, up, lo, x, (const double *)nullptr, y, (double *)nullptr));
     FFM_HIP(hipGetLastError());
     if (!A->ifaces.empty()) FFM_TRY(ffm_halo_update(A, x, y, transpose ? A->ifInt : A->ifBou, -1.0));
     return FFM_OK;
@@ -383,8 +466,8 @@ int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
         return ffm_k_dot(A->ctx, y, x, A->nCells, slot);
     }
     const int g = rows_grid(A);
-    hipLaunchKernelGGL((k_rows<0, true>), dim3(g), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, A->upper, A->lower,
-                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, x, (const double *)nullptr, y, A->ctx->partials_d);
+    FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, true, W>), dim3(g), dim3(256), 0, A->ctx->stream, ffm_view(A), A->diag,
+                                               A->upper, A->lower, x, (const double *)nullptr, y, A->ctx->partials_d));
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, A->ctx->stream, g, A->ctx->partials_d, A->ctx->scal_d, slot);
     FFM_HIP(hipGetLastError());
     return FFM_OK;
@@ -392,8 +475,8 @@ int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
 
 int ffm_k_residual(ffm_ldu *A, const double *x, const double *b, double *r)
 {
-    hipLaunchKernelGGL((k_rows<1, false>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, A->upper, A->lower,
-                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, x, b, r, (double *)nullptr);
+    FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<1, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
+                                               A->diag, A->upper, A->lower, x, b, r, (double *)nullptr));
     FFM_HIP(hipGetLastError());
     if (!A->ifaces.empty()) FFM_TRY(ffm_halo_update(A, x, r, A->ifBou, +1.0));
     return FFM_OK;
@@ -401,9 +484,9 @@ int ffm_k_residual(ffm_ldu *A, const double *x, const double *b, double *r)
 
 int ffm_k_sumA(ffm_ldu *A, double *s)
 {
-    hipLaunchKernelGGL((k_rows<2, false>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, A->nCells, A->diag, A->upper, A->lower,
-                       A->ownStart, A->uAddr, A->loStart, A->loFace, A->loNbr, (const double *)nullptr, (const double *)nullptr, s,
-                       (double *)nullptr);
+    FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<2, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
+                                               A->diag, A->upper, A->lower, (const double *)nullptr, (const double *)nullptr, s,
+                                               (double *)nullptr));
     FFM_HIP(hipGetLastError());
     // coupled patches: sumA[faceCells] -= interfaceBouCoeffs
     if (!A->ifaces.empty()) FFM_TRY(ffm_halo_apply(A, s, A->ifBou, nullptr, -1.0));

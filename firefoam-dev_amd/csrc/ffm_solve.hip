@@ -241,78 +241,108 @@ static int partial_sum_to(ffm_ctx *c, int nb, int slot, int nSums = 1)
 }
 
 // ------------------------------------------------------------ level kernels ---
+// A launch covers the cells [c0,c1) of one dependency level (contiguous in the level-major
+// numbering).  c0 need not be slice-aligned: thread t handles cell (c0 & ~63) + t so that a
+// wave still maps onto one slice and every index load stays unit-stride.
+
 // calcReciprocalD, forward part:  rD[c] = diag[c] - sum_k upper*lower/rD[l]   (not yet inverted)
-__global__ void k_rD_level(int c0, int c1, const int *__restrict__ loStart, const int *__restrict__ loFace,
-                           const int *__restrict__ loNbr, const double *__restrict__ upper,
+template <int W>
+__global__ void k_rD_level(int c0, int c1, LduView v, const double *__restrict__ upper,
                            const double *__restrict__ lower, const double *__restrict__ diag, double *__restrict__ rD)
 {
-    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= c1) return;
+    const int c = (c0 & ~63) + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < c0 || c >= c1) return;
+    RowEnt<W> L; load_lower<W>(v, c, L);
+    double au[W], al[W], rn[W];
+#pragma unroll
+    for (int s = 0; s < W; s++) { au[s] = upper[L.f[s]]; al[s] = lower[L.f[s]]; rn[s] = L.on[s] ? rD[L.nb[s]] : 1.0; }
     double d = diag[c];
-    for (int k = loStart[c]; k < loStart[c + 1]; k++) {
-        const int f = loFace[k];
-        d -= upper[f] * lower[f] / rD[loNbr[k]];
-    }
+#pragma unroll
+    for (int s = 0; s < W; s++) if (L.on[s]) d -= au[s] * al[s] / rn[s];
     rD[c] = d;
 }
 
 // forward sweep of one level:  w[c] = rD[c]*r[c] - sum_k rD[c]*coef[f]*w[l]
-__global__ void k_fwd_level(int c0, int c1, const int *__restrict__ loStart, const int *__restrict__ loFace,
-                            const int *__restrict__ loNbr, const double *__restrict__ coef,
+template <int W>
+__global__ void k_fwd_level(int c0, int c1, LduView v, const double *__restrict__ coef,
                             const double *__restrict__ rD, const double *__restrict__ r, double *__restrict__ w)
 {
-    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= c1) return;
-    const double rd = rD[c];
-    double wc = rd * r[c];
-    for (int k = loStart[c]; k < loStart[c + 1]; k++) wc -= rd * coef[loFace[k]] * w[loNbr[k]];
+    const int c = (c0 & ~63) + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < c0 || c >= c1) return;
+    RowEnt<W> L; load_lower<W>(v, c, L);
+    const double rd = rD[c], rc = r[c];
+    double a[W], wn[W];
+#pragma unroll
+    for (int s = 0; s < W; s++) { a[s] = coef[L.f[s]]; wn[s] = L.on[s] ? w[L.nb[s]] : 0.0; }
+    double wc = rd * rc;
+#pragma unroll
+    for (int s = 0; s < W; s++) if (L.on[s]) wc -= rd * a[s] * wn[s];
     w[c] = wc;
 }
 
 // backward sweep of one level: w[c] -= rD[c]*coef[f]*w[u], faces of c in descending order
-__global__ void k_bwd_level(int p0, int p1, const int *__restrict__ order, const int *__restrict__ ownStart,
-                            const int *__restrict__ uAddr, const double *__restrict__ coef,
+template <int W>
+__global__ void k_bwd_level(int p0, int p1, const int *__restrict__ order, LduView v, const double *__restrict__ coef,
                             const double *__restrict__ rD, double *__restrict__ w)
 {
-    const int p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= p1) return;
-    const int c = order ? order[p] : p;
-    const int f0 = ownStart[c], f1 = ownStart[c + 1];
-    if (f1 == f0) return;
+    int c;
+    if (order) { const int p = p0 + blockIdx.x * blockDim.x + threadIdx.x; if (p >= p1) return; c = order[p]; }
+    else { c = (p0 & ~63) + blockIdx.x * blockDim.x + threadIdx.x; if (c < p0 || c >= p1) return; }
+    RowEnt<W> U; load_upper<W>(v, c, U);
     const double rd = rD[c];
     double wc = w[c];
-    for (int f = f1 - 1; f >= f0; f--) wc -= rd * coef[f] * w[uAddr[f]];
+    double a[W], wn[W];
+#pragma unroll
+    for (int s = 0; s < W; s++) { a[s] = coef[U.f[s]]; wn[s] = U.on[s] ? w[U.nb[s]] : 0.0; }
+#pragma unroll
+    for (int s = W - 1; s >= 0; s--) if (U.on[s]) wc -= rd * a[s] * wn[s];
     w[c] = wc;
 }
 
 // Gauss-Seidel forward level: psi_c = (bP_c - sum_lower lower*psi_l - sum_upper upper*psi_u)/diag_c;
 // the value after the lower sum is kept in bSave for the reverse sweep of symGaussSeidel
-__global__ void k_gs_fwd_level(int c0, int c1, const int *__restrict__ loStart, const int *__restrict__ loFace,
-                               const int *__restrict__ loNbr, const int *__restrict__ ownStart,
-                               const int *__restrict__ uAddr, const double *__restrict__ upper,
+template <int W>
+__global__ void k_gs_fwd_level(int c0, int c1, LduView v, const double *__restrict__ upper,
                                const double *__restrict__ lower, const double *__restrict__ diag,
                                const double *__restrict__ bP, double *__restrict__ bSave, double *__restrict__ psi)
 {
-    const int c = c0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= c1) return;
-    double v = bP[c];
-    for (int k = loStart[c]; k < loStart[c + 1]; k++) v -= lower[loFace[k]] * psi[loNbr[k]];
-    bSave[c] = v;
-    for (int f = ownStart[c]; f < ownStart[c + 1]; f++) v -= upper[f] * psi[uAddr[f]];
-    psi[c] = v / diag[c];
+    const int c = (c0 & ~63) + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < c0 || c >= c1) return;
+    RowEnt<W> L, U; load_lower<W>(v, c, L); load_upper<W>(v, c, U);
+    double al[W], au[W], pl[W], pu[W];
+#pragma unroll
+    for (int s = 0; s < W; s++) {
+        al[s] = lower[L.f[s]]; au[s] = upper[U.f[s]];
+        pl[s] = L.on[s] ? psi[L.nb[s]] : 0.0; pu[s] = U.on[s] ? psi[U.nb[s]] : 0.0;
+    }
+    double val = bP[c];
+#pragma unroll
+    for (int s = 0; s < W; s++) if (L.on[s]) val -= al[s] * pl[s];
+    bSave[c] = val;
+#pragma unroll
+    for (int s = 0; s < W; s++) if (U.on[s]) val -= au[s] * pu[s];
+    psi[c] = val / diag[c];
 }
 
-__global__ void k_gs_bwd_level(int p0, int p1, const int *__restrict__ order, const int *__restrict__ ownStart,
-                               const int *__restrict__ uAddr, const double *__restrict__ upper,
+template <int W>
+__global__ void k_gs_bwd_level(int p0, int p1, const int *__restrict__ order, LduView v, const double *__restrict__ upper,
                                const double *__restrict__ diag, const double *__restrict__ bSave, double *__restrict__ psi)
 {
-    const int p = p0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= p1) return;
-    const int c = order ? order[p] : p;
-    double v = bSave[c];
-    for (int f = ownStart[c]; f < ownStart[c + 1]; f++) v -= upper[f] * psi[uAddr[f]];
-    psi[c] = v / diag[c];
+    int c;
+    if (order) { const int p = p0 + blockIdx.x * blockDim.x + threadIdx.x; if (p >= p1) return; c = order[p]; }
+    else { c = (p0 & ~63) + blockIdx.x * blockDim.x + threadIdx.x; if (c < p0 || c >= p1) return; }
+    RowEnt<W> U; load_upper<W>(v, c, U);
+    double au[W], pu[W];
+#pragma unroll
+    for (int s = 0; s < W; s++) { au[s] = upper[U.f[s]]; pu[s] = U.on[s] ? psi[U.nb[s]] : 0.0; }
+    double val = bSave[c];
+#pragma unroll
+    for (int s = 0; s < W; s++) if (U.on[s]) val -= au[s] * pu[s];
+    psi[c] = val / diag[c];
 }
+
+// blocks needed to cover cells [c0,c1) when thread 0 of block 0 sits on the slice start of c0
+static inline int level_grid(int c0, int c1) { return ffm_grid(c1 - (c0 & ~63), 256); }
 
 // ------------------------------------------------------ level-sweep drivers ---
 enum { SW_RD = 1, SW_PRECOND = 2, SW_GS = 3, SW_SYMGS = 4 };
@@ -356,8 +386,8 @@ static int calc_rD(ffm_ldu *A)
         for (int L = 0; L < A->nLevels; L++) {
             const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
             if (c1 == c0) continue;
-            hipLaunchKernelGGL(k_rD_level, dim3(ffm_grid(c1 - c0, 256)), dim3(256), 0, s, c0, c1, A->loStart, A->loFace, A->loNbr,
-                               A->upper, A->lower, A->diag, A->rD);
+            FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL(k_rD_level<W>, dim3(level_grid(c0, c1)), dim3(256), 0, s, c0, c1, ffm_view(A),
+                               A->upper, A->lower, A->diag, A->rD));
         }
         hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->rD, A->rD);
         FFM_HIP(hipGetLastError());
@@ -400,15 +430,14 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
         for (int L = 0; L < A->nLevels; L++) {
             const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
             if (c1 == c0) continue;
-            hipLaunchKernelGGL(k_fwd_level, dim3(ffm_grid(c1 - c0, 256)), dim3(256), 0, s, c0, c1, A->loStart, A->loFace, A->loNbr,
-                               cf, A->rD, r, w);
+            FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL(k_fwd_level<W>, dim3(level_grid(c0, c1)), dim3(256), 0, s, c0, c1, ffm_view(A), cf, A->rD, r, w));
         }
         // backward level 0 = cells without owned faces: nothing to do
         for (int b = 1; b < A->nBwdLevels; b++) {
             int p0, p1; const int *order; bwd_range(A, b, p0, p1, order);
             if (p1 == p0) continue;
-            hipLaunchKernelGGL(k_bwd_level, dim3(ffm_grid(p1 - p0, 256)), dim3(256), 0, s, p0, p1, order, A->ownStart, A->uAddr,
-                               cb, A->rD, w);
+            FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL(k_bwd_level<W>, dim3(order ? ffm_grid(p1 - p0, 256) : level_grid(p0, p1)), dim3(256), 0, s,
+                                                       p0, p1, order, ffm_view(A), cb, A->rD, w));
         }
         FFM_HIP(hipGetLastError());
         return FFM_OK;
@@ -434,14 +463,14 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             for (int L = 0; L < A->nLevels; L++) {
                 const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
                 if (c1 == c0) continue;
-                hipLaunchKernelGGL(k_gs_fwd_level, dim3(ffm_grid(c1 - c0, 256)), dim3(256), 0, s, c0, c1, A->loStart, A->loFace,
-                                   A->loNbr, A->ownStart, A->uAddr, A->upper, A->lower, A->diag, bUse, bSave, psi);
+                FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL(k_gs_fwd_level<W>, dim3(level_grid(c0, c1)), dim3(256), 0, s, c0, c1, ffm_view(A),
+                                                           A->upper, A->lower, A->diag, bUse, bSave, psi));
             }
             if (sym) for (int bl = 0; bl < A->nBwdLevels; bl++) {
                 int p0, p1; const int *order; bwd_range(A, bl, p0, p1, order);
                 if (p1 == p0) continue;
-                hipLaunchKernelGGL(k_gs_bwd_level, dim3(ffm_grid(p1 - p0, 256)), dim3(256), 0, s, p0, p1, order, A->ownStart,
-                                   A->uAddr, A->upper, A->diag, bSave, psi);
+                FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL(k_gs_bwd_level<W>, dim3(order ? ffm_grid(p1 - p0, 256) : level_grid(p0, p1)), dim3(256),
+                                                           0, s, p0, p1, order, ffm_view(A), A->upper, A->diag, bSave, psi));
             }
             FFM_HIP(hipGetLastError());
             return FFM_OK;

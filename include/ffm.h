@@ -111,6 +111,15 @@ int ffm_ldu_set_coeffs(ffm_ldu *ldu, const double *diag, const double *upper,
 int ffm_ldu_set_coeffs_d(ffm_ldu *ldu, const double *diag_d,
                          const double *upper_d, const double *lower_d);
 
+/* Native face layout (for hosts that assemble on the device in the library's own
+ * layout and skip the LDU-order gather): the library stores faces as a sliced
+ * owner-ELL; nNative >= nFaces entries incl. padding.  callerToNative[f] = native
+ * index of caller face f.  Only valid when ffm_ldu_is_native_order() == 1.     */
+int ffm_ldu_n_native_faces(const ffm_ldu *ldu);
+int ffm_ldu_get_face_map(const ffm_ldu *ldu, int *callerToNative);
+int ffm_ldu_set_coeffs_native_d(ffm_ldu *ldu, const double *diag_d,
+                                const double *upper_d, const double *lower_d);
+
 /* processor patches (lduInterface / interfaceBouCoeffs / interfaceIntCoeffs):
  * face i of patch p couples cell faceCells[p][i] (caller numbering) with face i
  * of the matching patch on rank neighbRank[p]; as in OpenFOAM there is one
