@@ -1,0 +1,34 @@
+"""The same golden-log check with the HIP solver in the loop: the five hydrostatic-initialisation
+DICPCG solves of the steckler case (reference cases/steckler/original/linux64/log.fireFoam:92-101)
+solved by libffm through the C ABI must follow the oracle's (and hence the golden log's) iteration
+counts; the assembled matrices come from the oracle's FV operators (assembly kernels have their own
+parity tests)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "steckler_ph_rgh.json")))
+
+
+def test_steckler_hydrostatic_solves_on_gpu(O, ffm, ctx):
+    from oracle import steckler
+    m = steckler.build_mesh()
+    A = ffm.lduMatrix(ctx, m.nCells, m.l, m.u)       # natural blockMesh numbering -> internal level-major permutation
+
+    def gpu_solve(mesh, diag, upper, source, psi0):
+        A.set_coeffs(diag, upper)
+        psi = ctx.to_device(psi0)
+        perf = A.solve(psi, ctx.to_device(source), solver="PCG", preconditioner="DIC", tolerance=1e-6, relTol=0.01)
+        return psi.cpu().numpy(), perf
+
+    recs, ph = steckler.hydrostatic_initialisation(gpu_solve, mesh=m)
+    ref, phRef = steckler.hydrostatic_initialisation(steckler.oracle_solve, mesh=m)
+    assert [r["nIterations"] for r in recs] == [r["nIterations"] for r in ref]
+    assert [r["nIterations"] for r in recs][:2] == [g["nIterations"] for g in GOLD["solves"]][:2] == [29, 32]
+    for r, o in zip(recs, ref):
+        assert abs(r["finalResidual"] - o["finalResidual"]) <= 1e-6 * o["finalResidual"]
+    assert np.linalg.norm(ph - phRef) / np.linalg.norm(phRef) < 1e-8
+    A.close()
