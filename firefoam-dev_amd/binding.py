@@ -119,6 +119,15 @@ def lib():
         "ffm_reduce_max": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_dot": ([vp, dp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_summag": ([vp, dp, C.c_long, hp], C.c_int),
+        "ffm_plume_create": ([vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(vp)], C.c_int),
+        "ffm_plume_destroy": ([vp], C.c_int),
+        "ffm_plume_step": ([vp], C.c_int),
+        "ffm_plume_ncells": ([vp], C.c_int),
+        "ffm_plume_nfaces": ([vp], C.c_int),
+        "ffm_plume_get_field": ([vp, C.c_char_p, hp], C.c_int),
+        "ffm_plume_nsolves": ([vp], C.c_int),
+        "ffm_plume_get_solve": ([vp, C.c_int, C.c_char_p, C.POINTER(Perf)], C.c_int),
+        "ffm_plume_ldu": ([vp], vp),
         "ffm_comm_unique_id": ([vp], C.c_int),
         "ffm_comm_init": ([vp, C.c_int, C.c_int, vp], C.c_int),
         "ffm_comm_init_host": ([vp, C.c_int, C.c_int, vp, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN], C.c_int),
@@ -376,3 +385,40 @@ class lduMatrix:
         _check(lib().ffm_bench_spmv(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), reps, C.byref(ms)),
                "ffm_bench_spmv")
         return ms.value
+
+
+class Plume:
+    """The synthetic buoyant-plume case (ffm_plume_*): one fireFoam time step per step()."""
+
+    def __init__(self, ctx, n, h=0.05, deltaT=1e-3):
+        self.ctx = ctx
+        hnd = C.c_void_p()
+        _check(lib().ffm_plume_create(ctx.h, int(n[0]), int(n[1]), int(n[2]), float(h), float(deltaT), C.byref(hnd)), "ffm_plume_create")
+        self.h = hnd
+        self.nCells = lib().ffm_plume_ncells(hnd)
+        self.nFaces = lib().ffm_plume_nfaces(hnd)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ffm_plume_destroy(self.h)
+            self.h = None
+
+    def step(self):
+        _check(lib().ffm_plume_step(self.h), "ffm_plume_step")
+
+    def field(self, name):
+        out = np.empty(self.nCells)
+        _check(lib().ffm_plume_get_field(self.h, name.encode(), _hp(out)), "ffm_plume_get_field")
+        return out
+
+    def solves(self):
+        res = []
+        for i in range(lib().ffm_plume_nsolves(self.h)):
+            nm = C.create_string_buffer(16)
+            pf = Perf()
+            _check(lib().ffm_plume_get_solve(self.h, i, nm, C.byref(pf)), "ffm_plume_get_solve")
+            res.append((nm.value.decode(), pf.as_dict()))
+        return res
+
+    def ldu_handle(self):
+        return lib().ffm_plume_ldu(self.h)

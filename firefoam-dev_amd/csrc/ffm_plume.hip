@@ -1,0 +1,605 @@
+// ffm_plume.hip -- the synthetic buoyant-plume case of SURVEY 8(d): host-side driver of one
+// fireFoam time step (solver/fireFoam.C:76-121 with PIMPLE 1/2/0, cases/steckler/system/
+// fvSolution:84-89) written against the C ABI of include/ffm.h, in the order of the reference's
+// equation snippets:
+//   rhoEqn  solver/rhoEqn.H:33-43      UEqn  solver/UEqn.H:3-33
+//   YEEqn   solver/YEEqn.H:37-118      pEqn  solver/pEqn.H:1-60 (x2)   start-up solver/phrghEqn.H:25-56
+// This is bench.py's workload and the subject of tests/test_plume_gpu.py (oracle: oracle/plume.py,
+// same sequence in numpy).  The physics plug-ins that the reference takes from other libraries are
+// replaced by the stand-ins listed in oracle/plume.py (perfect gas / constant Cp, constant mu, Pr,
+// EDC-shaped single-step source, zero-gradient thermo boundary values); their kernels are the
+// k_standin_* below and are not part of the hot path being reproduced.
+#include "ffm_internal.hpp"
+#include "ffm_device.hpp"
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+struct ffm_mesh;
+extern "C" {
+int ffm_mesh_create(ffm_ldu *, const double *, const double *, const double *, const double *, const double *, const double *, int,
+                    const int *, const int *const *, const double *const *, const double *const *, ffm_mesh **);
+int ffm_mesh_destroy(ffm_mesh *);
+int ffm_fvc_interpolate(ffm_mesh *, const double *, const double *, double *);
+int ffm_fvc_snGrad(ffm_mesh *, const double *, double *);
+int ffm_fvc_snGrad_b(ffm_mesh *, const double *, const double *, double *);
+int ffm_fvc_flux(ffm_mesh *, const double *, const double *, const double *, double *);
+int ffm_fvc_surface_integrate(ffm_mesh *, const double *, const double *, double *);
+int ffm_fvc_grad(ffm_mesh *, const double *, const double *, double *, double *, double *);
+int ffm_fvc_reconstruct(ffm_mesh *, const double *, const double *, double *, double *, double *);
+int ffm_fv_limited_weights(ffm_mesh *, int, double, double, double, const double *, const double *, const double *, const double *,
+                           const double *, double *);
+int ffm_fvm_transport(ffm_mesh *, double, const double *, const double *, const double *, const double *, int, double *, double *, double *);
+int ffm_fvm_boundary_coeffs(ffm_mesh *, const double *, const double *, int, const double *, const double *, const double *, double *, double *);
+int ffm_bc_values(ffm_mesh *, const double *, const double *, const double *, const double *, double *);
+int ffm_fvm_add_boundary(ffm_mesh *, const double *, const double *, const double *, const double *, const double *, double *, double *);
+int ffm_fvm_A(ffm_mesh *, int, const double *, const double *, const double *, const double *, double *);
+int ffm_fvm_H(ffm_mesh *, int, int, const double *, const double *, const double *, const double *, const double *, const double *,
+              const double *, const double *, double *);
+int ffm_fvm_flux(ffm_mesh *, const double *, const double *, const double *, const double *, const double *, double *, double *);
+}
+const int *ffm_mesh_bcells(const ffm_mesh *m);
+const double *ffm_mesh_geom(const ffm_mesh *m, int which);
+
+namespace {
+constexpr double RR = 8314.47, CP = 1005.0, TREF = 298.15, PREF = 101325.0, MU = 1.8e-5, PR = 0.7;
+constexpr double S_O2 = 3.6282945, HC = 46357151.0, TAU = 0.05, T_IN = 600.0, U_IN = 0.5;
+constexpr int NSP = 5, INERT = 4;
+const double WMOL[NSP] = {31.9988, 18.0153, 44.0962, 44.01, 28.0134};
+const double Y_AMB[NSP] = {0.23301, 0.0, 0.0, 0.0, 0.76699};
+const double Y_IN[NSP] = {0.0, 0.0, 1.0, 0.0, 0.0};
+const double NU[NSP] = {-S_O2, 4 * 18.0153 / 44.0962, -1.0, 3 * 44.01 / 44.0962, 0.0};
+const char *SPN[NSP] = {"O2", "H2O", "C3H8", "CO2", "N2"};
+enum { P_INLET = 0, P_FLOOR = 1, P_TOP = 2, P_SIDES = 3 };
+
+template <class F> __global__ void k_for(long n, F f)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) f(i);
+}
+inline int sgrid(long n) { long g = (n + 255) / 256; return (int)std::max(1L, std::min(g, (long)RED_BLOCKS)); }
+}  // namespace
+
+struct SolveLog { char name[16]; ffm_perf perf; };
+
+struct ffm_plume {
+    ffm_ctx *ctx = nullptr; ffm_ldu *A = nullptr; ffm_mesh *mesh = nullptr;
+    int nx = 0, ny = 0, nz = 0, N = 0, F = 0, nNat = 0, B = 0;
+    double h = 0.05, dt = 1e-3, rdt = 1e3, time = 0.0;
+    std::vector<int> newToOld;             // library cell order -> natural blockMesh cell id
+    std::vector<double *> pool;            // every device buffer, for destroy
+    // fields
+    double *Y[NSP], *Y0[NSP], *T, *hs, *hs0, *U[3], *U0[3], *p, *p0, *p_rgh, *p_rgh0, *psi, *psi0, *rho, *rho0, *K, *K0, *dpdt;
+    double *phi, *phi0, *phib, *phib0, *gh, *ghf, *ph_rgh, *ph_rgh_b;
+    // boundary-condition data [B]
+    double *kind_d;                        // patch kind per boundary face (as double for simple kernels)
+    double *fU[3], *refU[3], *fS, *refS, *fP, *refP, *gradP, *zeroB, *oneB;
+    double *fStaticU[3], *fStaticS, *fStaticH, *fH, *refY[NSP], *refH;      // static templates (-1 = inletOutlet)
+    // matrix + work
+    double *diag, *upper, *lower, *src[3], *ic[3], *bc[3], *dWork, *sWork;
+    double *wN[12], *wF[6], *wB[8];
+    // UEqn kept for pEqn (A, H)
+    double *Udiag, *Uupper, *Ulower, *Usrc[3], *Uic[3], *Ubc[3];
+    std::vector<SolveLog> log;
+};
+
+#define PL_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ffm_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e_)); return FFM_ERR_HIP; } } while (0)
+
+static double *dalloc(ffm_plume *P, size_t n)
+{
+    double *p = nullptr;
+    if (hipMalloc((void **)&p, sizeof(double) * std::max<size_t>(n, 1)) != hipSuccess) return nullptr;
+    hipMemset(p, 0, sizeof(double) * std::max<size_t>(n, 1));   // synchronous: uploads below use the null stream
+    P->pool.push_back(p);
+    return p;
+}
+static double *dupload(ffm_plume *P, const std::vector<double> &v)
+{
+    double *p = dalloc(P, v.size());
+    if (p && !v.empty()) hipMemcpy(p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice);
+    return p;
+}
+template <class Fn> static void forN(ffm_plume *P, long n, Fn f)
+{
+    if (n > 0) hipLaunchKernelGGL(k_for<Fn>, dim3(sgrid(n)), dim3(256), 0, P->ctx->stream, n, f);
+}
+static void dcopy(ffm_plume *P, double *d, const double *s, long n)
+{ hipMemcpyAsync(d, s, sizeof(double) * n, hipMemcpyDeviceToDevice, P->ctx->stream); }
+
+// ---- stand-in physics (not part of the reproduced hot path) -----------------------------------
+static void standin_thermo(ffm_plume *P)
+{   // T = Tref + h/Cp ; psi = 1/(R T sum(Y_i/W_i))
+    double *T = P->T, *psi = P->psi; const double *h = P->hs;
+    const double *y0 = P->Y[0], *y1 = P->Y[1], *y2 = P->Y[2], *y3 = P->Y[3], *y4 = P->Y[4];
+    const double w0 = WMOL[0], w1 = WMOL[1], w2 = WMOL[2], w3 = WMOL[3], w4 = WMOL[4];
+    forN(P, P->N, [=] __device__(long i) {
+        const double t = TREF + h[i] / CP;
+        T[i] = t;
+        psi[i] = 1.0 / (RR * t * ((((y0[i] / w0 + y1[i] / w1) + y2[i] / w2) + y3[i] / w3) + y4[i] / w4));
+    });
+}
+static void mul(ffm_plume *P, double *o, const double *a, const double *b, long n) { forN(P, n, [=] __device__(long i) { o[i] = a[i] * b[i]; }); }
+
+// boundary zero-gradient copy of a cell field
+static void zg(ffm_plume *P, double *ob, const double *vf)
+{ const int *fc = ffm_mesh_bcells(P->mesh); forN(P, P->B, [=] __device__(long k) { ob[k] = vf[fc[k]]; }); }
+
+// dynamic part of the mixed BCs: inletOutlet / pressureInletOutletVelocity value fraction f = 1 - pos0(phi_b)
+static void bc_update_f(ffm_plume *P, double *f, const double *fStatic)
+{ const double *pb = P->phib; forN(P, P->B, [=] __device__(long k) { f[k] = fStatic[k] < 0 ? 1.0 - (pb[k] >= 0 ? 1.0 : 0.0) : fStatic[k]; }); }
+
+static int solve_named(ffm_plume *P, const char *name, int solver, int pre, double tol, double relTol, const double *d,
+                       const double *up, const double *lo, double *psi, const double *src)
+{
+    FFM_TRY(ffm_ldu_set_coeffs_native_d(P->A, d, up, lo));
+    SolveLog L; memset(&L, 0, sizeof(L)); strncpy(L.name, name, sizeof(L.name) - 1);
+    FFM_TRY(ffm_solve_d(P->A, solver, pre, tol, relTol, 0, 1000, 1, psi, src, &L.perf));
+    P->log.push_back(L);
+    return FFM_OK;
+}
+
+// ---- boundary values of U from its mixed BC (per component) -----------------------------------
+static int U_boundary(ffm_plume *P, double *Ub[3])
+{
+    for (int c = 0; c < 3; c++) FFM_TRY(ffm_bc_values(P->mesh, P->fU[c], P->refU[c], P->zeroB, P->U[c], Ub[c]));
+    return FFM_OK;
+}
+
+static int update_bcs(ffm_plume *P)
+{
+    for (int c = 0; c < 3; c++) bc_update_f(P, P->fU[c], P->fStaticU[c]);
+    bc_update_f(P, P->fS, P->fStaticS);
+    bc_update_f(P, P->fH, P->fStaticH);
+    return FFM_OK;
+}
+
+// p_rgh BC: fixedFluxPressure gradient on inlet/floor, prghTotalHydrostaticPressure value on top/sides
+static int bc_p_rgh(ffm_plume *P, const double *grad /*[B] or null*/, double *Ub[3], const double *rhob)
+{
+    const double *kind = P->kind_d, *pb = P->phib, *phb = P->ph_rgh_b;
+    const double *u0 = Ub[0], *u1 = Ub[1], *u2 = Ub[2];
+    double *f = P->fP, *ref = P->refP, *g = P->gradP;
+    forN(P, P->B, [=] __device__(long k) {
+        if (kind[k] < 1.5) { f[k] = 0.0; ref[k] = 0.0; g[k] = grad ? grad[k] : 0.0; }
+        else {
+            f[k] = 1.0; g[k] = 0.0;
+            ref[k] = phb[k] - 0.5 * rhob[k] * (1.0 - (pb[k] >= 0 ? 1.0 : 0.0)) * ((u0[k] * u0[k] + u1[k] * u1[k]) + u2[k] * u2[k]);
+        }
+    });
+    return FFM_OK;
+}
+
+static int rho_eqn(ffm_plume *P)
+{   // fvm::ddt(rho) + fvc::div(phi) == 0  -> diagonal: rho = (rdt*rho0*V - V*div(phi))/(rdt*V)
+    double *div = P->wN[0];
+    FFM_TRY(ffm_fvc_surface_integrate(P->mesh, P->phi, P->phib, div));
+    const double *V = ffm_mesh_geom(P->mesh, 0), *rho0 = P->rho0; double *rho = P->rho; const double rdt = P->rdt;
+    forN(P, P->N, [=] __device__(long i) { rho[i] = (rdt * rho0[i] * V[i] - V[i] * div[i]) / (rdt * V[i]); });
+    return FFM_OK;
+}
+
+static int hydrostatic_init(ffm_plume *P)
+{
+    ffm_mesh *m = P->mesh; const int N = P->N, B = P->B;
+    double *ph = P->ph_rgh, *rhof = P->wF[0], *sg = P->wF[1], *phig = P->wF[2], *rhob = P->wB[0];
+    const double *gh = P->gh, *ghf = P->ghf, *magSf = ffm_mesh_geom(m, 1);
+    double *p = P->p, *rho = P->rho; const double *psi = P->psi;
+    // top fixedValue 0, everything else fixedFluxPressure with zero gradient
+    double *fTop = P->wB[1]; const double *kind = P->kind_d;
+    forN(P, B, [=] __device__(long k) { fTop[k] = (kind[k] > 1.5 && kind[k] < 2.5) ? 1.0 : 0.0; });
+    forN(P, N, [=] __device__(long i) { p[i] = ph[i] + rho[i] * gh[i] + PREF; });
+    standin_thermo(P); mul(P, rho, psi, p, N);
+    const long nNat = P->nNat;
+    for (int corr = 0; corr < 5; corr++) {
+        FFM_TRY(ffm_fvc_interpolate(m, nullptr, rho, rhof));
+        zg(P, rhob, rho);
+        FFM_TRY(ffm_fvc_snGrad(m, rho, sg));
+        forN(P, nNat, [=] __device__(long e) { phig[e] = -rhof[e] * ghf[e] * sg[e] * magSf[e]; });
+        FFM_TRY(ffm_fvm_transport(m, 0.0, nullptr, nullptr, nullptr, rhof, +1, P->diag, P->upper, P->lower));
+        FFM_TRY(ffm_fvm_boundary_coeffs(m, nullptr, rhob, +1, fTop, P->zeroB, P->zeroB, P->ic[0], P->bc[0]));
+        FFM_TRY(ffm_fvc_surface_integrate(m, phig, P->zeroB, P->wN[0]));
+        {
+            double *s0 = P->src[0]; const double *dv = P->wN[0], *V = ffm_mesh_geom(m, 0);
+            forN(P, N, [=] __device__(long i) { s0[i] = V[i] * dv[i]; });
+        }
+        FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, P->src[0], nullptr, P->dWork, P->sWork));
+        FFM_TRY(solve_named(P, "ph_rgh", FFM_PCG, FFM_DIC, 1e-6, 0.01, P->dWork, P->upper, nullptr, ph, P->sWork));
+        forN(P, N, [=] __device__(long i) { p[i] = ph[i] + rho[i] * gh[i] + PREF; });
+        standin_thermo(P); mul(P, rho, psi, p, N);
+    }
+    FFM_TRY(ffm_bc_values(m, fTop, P->zeroB, P->zeroB, ph, P->ph_rgh_b));
+    dcopy(P, P->p_rgh, ph, N);
+    return FFM_OK;
+}
+
+// transport equation of a scalar: ddt(rho,vf) + div(phi,vf) - laplacian(gamma,vf) == su (+ explicit LHS terms in `expl`)
+static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *vf, const double *vf0, const double *fBC, const double *ref,
+                            const double *gamma_f, const double *gamma_b, const double *su, const double *expl, double tol)
+{
+    ffm_mesh *m = P->mesh; const int N = P->N;
+    double *vb = P->wB[2], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *w = P->wF[3];
+    FFM_TRY(ffm_bc_values(m, fBC, ref, P->zeroB, vf, vb));
+    FFM_TRY(ffm_fvc_grad(m, vf, vb, gx, gy, gz));
+    FFM_TRY(ffm_fv_limited_weights(m, scheme, 1.0, 0.0, 1.0, P->phi, vf, gx, gy, gz, w));
+    FFM_TRY(ffm_fvm_transport(m, P->rdt, P->rho, P->phi, w, gamma_f, -1, P->diag, P->upper, P->lower));
+    FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, gamma_b, -1, fBC, ref, P->zeroB, P->ic[0], P->bc[0]));
+    // source = rdt*rho0*vf0*V (- V*expl) ; then + boundaryCoeffs + V*su
+    const double *V = ffm_mesh_geom(m, 0), *rho0 = P->rho0; double *s = P->src[0]; const double rdt = P->rdt;
+    if (expl) forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * vf0[i] * V[i] - V[i] * expl[i]; });
+    else forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * vf0[i] * V[i]; });
+    double *s2 = P->wN[4];
+    if (su) { forN(P, N, [=] __device__(long i) { s2[i] = s[i] + V[i] * su[i]; }); }
+    else s2 = s;
+    FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, s2, nullptr, P->dWork, P->sWork));
+    return solve_named(P, name, FFM_PBICGSTAB, FFM_DILU, tol, 0.0, P->dWork, P->upper, P->lower, vf, P->sWork);
+}
+
+static int p_corrector(ffm_plume *P, bool final)
+{
+    ffm_mesh *m = P->mesh; const int N = P->N, B = P->B; const long nNat = P->nNat; const double rdt = P->rdt;
+    const double *V = ffm_mesh_geom(m, 0), *magSf = ffm_mesh_geom(m, 1), *bMag = ffm_mesh_geom(m, 4);
+    const double *bSx = ffm_mesh_geom(m, 6), *bSy = ffm_mesh_geom(m, 7), *bSz = ffm_mesh_geom(m, 8);
+    const double *Sx = ffm_mesh_geom(m, 9), *Sy = ffm_mesh_geom(m, 10), *Sz = ffm_mesh_geom(m, 11), *wlin = ffm_mesh_geom(m, 3);
+    double *rho = P->rho; const double *psi = P->psi; double *p = P->p;
+    mul(P, rho, psi, p, N);                                                        // rho = thermo.rho()
+    double *rAU = P->wN[0], *rhorAU = P->wN[1], *HbyA[3] = {P->wN[2], P->wN[3], P->wN[4]};
+    FFM_TRY(ffm_fvm_A(m, 3, P->Udiag, P->Uic[0], P->Uic[1], P->Uic[2], rAU));
+    forN(P, N, [=] __device__(long i) { rAU[i] = 1.0 / rAU[i]; rhorAU[i] = rho[i] * rAU[i]; });
+    double *rhorAUf = P->wF[0], *rhorAUfb = P->wB[0];
+    FFM_TRY(ffm_fvc_interpolate(m, nullptr, rhorAU, rhorAUf));
+    zg(P, rhorAUfb, rhorAU);
+    for (int c = 0; c < 3; c++) {
+        FFM_TRY(ffm_fvm_H(m, 3, c, P->Uupper, P->Ulower, P->Usrc[c], P->Uic[0], P->Uic[1], P->Uic[2], P->Ubc[c], P->U[c], HbyA[c]));
+        double *Hc = HbyA[c];
+        forN(P, N, [=] __device__(long i) { Hc[i] = rAU[i] * Hc[i]; });
+    }
+    FFM_TRY(update_bcs(P));
+    double *Ub[3] = {P->wB[1], P->wB[2], P->wB[3]};
+    FFM_TRY(U_boundary(P, Ub));
+    double *rhob = P->wB[4];
+    zg(P, rhob, rho);
+    // phig = -rhorAUf*ghf*snGrad(rho)*magSf
+    double *sg = P->wF[1], *phig = P->wF[2];
+    FFM_TRY(ffm_fvc_snGrad(m, rho, sg));
+    const double *ghf = P->ghf;
+    forN(P, nNat, [=] __device__(long e) { phig[e] = -rhorAUf[e] * ghf[e] * sg[e] * magSf[e]; });
+    // fvc::flux(rho*HbyA): interior by linear interpolation; boundary rho_b*HbyA_b.Sf with constrainHbyA
+    double *rH[3] = {P->wN[5], P->wN[6], P->wN[7]};
+    for (int c = 0; c < 3; c++) mul(P, rH[c], rho, HbyA[c], N);
+    double *phiHbyA = P->wF[3], *phiHbyAb = P->wB[5];
+    FFM_TRY(ffm_fvc_flux(m, rH[0], rH[1], rH[2], phiHbyA));
+    {
+        const int *fc = ffm_mesh_bcells(m); const double *kind = P->kind_d;
+        const double *h0 = HbyA[0], *h1 = HbyA[1], *h2 = HbyA[2], *u0 = Ub[0], *u1 = Ub[1], *u2 = Ub[2];
+        forN(P, B, [=] __device__(long k) {
+            const bool fixed = kind[k] < 1.5; const int c = fc[k];
+            const double a0 = fixed ? u0[k] : h0[c], a1 = fixed ? u1[k] : h1[c], a2 = fixed ? u2[k] : h2[c];
+            phiHbyAb[k] = (rhob[k] * a0 * bSx[k] + rhob[k] * a1 * bSy[k]) + rhob[k] * a2 * bSz[k];
+        });
+    }
+    // + rhorAUf*ddtCorr(rho,U,phi) + phig
+    {
+        double *rU0[3] = {P->wN[8], P->wN[9], P->wN[10]};
+        for (int c = 0; c < 3; c++) mul(P, rU0[c], P->rho0, P->U0[c], N);
+        double *fl0 = P->wF[4];
+        FFM_TRY(ffm_fvc_flux(m, rU0[0], rU0[1], rU0[2], fl0));
+        const double *phi0 = P->phi0;
+        forN(P, nNat, [=] __device__(long e) {
+            const double phiCorr = phi0[e] - fl0[e];
+            const double coeff = 1.0 - fmin(fabs(phiCorr) / (fabs(phi0[e]) + 1e-15), 1.0);
+            phiHbyA[e] = (phiHbyA[e] + rhorAUf[e] * (coeff * rdt * phiCorr)) + phig[e];
+        });
+        (void)Sx; (void)Sy; (void)Sz; (void)wlin;
+    }
+    // constrainPressure: gradient on fixedFluxPressure patches
+    double *grads = P->wB[6];
+    {
+        const double *u0 = Ub[0], *u1 = Ub[1], *u2 = Ub[2];
+        forN(P, B, [=] __device__(long k) {
+            grads[k] = (phiHbyAb[k] - rhob[k] * ((bSx[k] * u0[k] + bSy[k] * u1[k]) + bSz[k] * u2[k])) / (bMag[k] * rhorAUfb[k]);
+        });
+    }
+    FFM_TRY(bc_p_rgh(P, grads, Ub, rhob));
+    // p_rghEqn = fvm::ddt(psi,p_rgh) + fvc::ddt(psi,rho)*gh + fvc::ddt(psi)*pRef + fvc::div(phiHbyA) - fvm::laplacian(rhorAUf,p_rgh)
+    FFM_TRY(ffm_fvm_transport(m, rdt, psi, nullptr, nullptr, rhorAUf, -1, P->diag, P->upper, P->lower));
+    FFM_TRY(ffm_fvm_boundary_coeffs(m, nullptr, rhorAUfb, -1, P->fP, P->refP, P->gradP, P->ic[0], P->bc[0]));
+    double *div = P->wN[8];
+    FFM_TRY(ffm_fvc_surface_integrate(m, phiHbyA, phiHbyAb, div));
+    {
+        double *s = P->src[0]; const double *psi0 = P->psi0, *prgh0 = P->p_rgh0, *rho0 = P->rho0, *gh = P->gh;
+        forN(P, N, [=] __device__(long i) {
+            const double expl = (rdt * (psi[i] * rho[i] - psi0[i] * rho0[i]) * gh[i] + rdt * (psi[i] - psi0[i]) * PREF) + div[i];
+            s[i] = rdt * psi0[i] * prgh0[i] * V[i] - V[i] * expl;
+        });
+    }
+    FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, P->src[0], nullptr, P->dWork, P->sWork));
+    FFM_TRY(solve_named(P, "p_rgh", FFM_PCG, FFM_DIC, 1e-6, final ? 0.0 : 0.01, P->dWork, P->upper, nullptr, P->p_rgh, P->sWork));
+    // phi = phiHbyA + p_rghEqn.flux(); U = HbyA + rAU*reconstruct((flux + phig)/rhorAUf)
+    double *fl = P->wF[4], *flb = P->wB[7];
+    FFM_TRY(ffm_fvm_flux(m, P->upper, P->lower, P->ic[0], P->bc[0], P->p_rgh, fl, flb));
+    {
+        double *phi = P->phi, *phib = P->phib, *t = P->wF[5], *tb = P->wB[6];
+        forN(P, nNat, [=] __device__(long e) { phi[e] = phiHbyA[e] + fl[e]; t[e] = rhorAUf[e] != 0.0 ? (fl[e] + phig[e]) / rhorAUf[e] : 0.0; });
+        forN(P, B, [=] __device__(long k) { phib[k] = phiHbyAb[k] + flb[k]; tb[k] = flb[k] / rhorAUfb[k]; });
+        double *rx = P->wN[5], *ry = P->wN[6], *rz = P->wN[7];
+        FFM_TRY(ffm_fvc_reconstruct(m, t, tb, rx, ry, rz));
+        double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2]; const double *h0 = HbyA[0], *h1 = HbyA[1], *h2 = HbyA[2];
+        double *K = P->K, *dpdt = P->dpdt; const double *p_rgh = P->p_rgh, *gh = P->gh, *p0 = P->p0;
+        forN(P, N, [=] __device__(long i) {
+            const double a = h0[i] + rAU[i] * rx[i], b = h1[i] + rAU[i] * ry[i], c = h2[i] + rAU[i] * rz[i];
+            U0[i] = a; U1[i] = b; U2[i] = c;
+            p[i] = p_rgh[i] + rho[i] * gh[i] + PREF;
+        });
+        FFM_TRY(rho_eqn(P));
+        forN(P, N, [=] __device__(long i) {
+            K[i] = 0.5 * ((U0[i] * U0[i] + U1[i] * U1[i]) + U2[i] * U2[i]);
+            dpdt[i] = rdt * (p[i] - p0[i]);
+        });
+    }
+    return FFM_OK;
+}
+
+extern "C" int ffm_plume_step(ffm_plume *P)
+{
+    if (!P) return FFM_ERR_ARG;
+    ffm_mesh *m = P->mesh; const int N = P->N, B = P->B; const long nNat = P->nNat; const double rdt = P->rdt;
+    const double *V = ffm_mesh_geom(m, 0), *magSf = ffm_mesh_geom(m, 1);
+    P->log.clear();
+    // oldTime fields
+    dcopy(P, P->rho0, P->rho, N); dcopy(P, P->hs0, P->hs, N); dcopy(P, P->K0, P->K, N); dcopy(P, P->p0, P->p, N);
+    dcopy(P, P->psi0, P->psi, N); dcopy(P, P->p_rgh0, P->p_rgh, N); dcopy(P, P->phi0, P->phi, nNat); dcopy(P, P->phib0, P->phib, B);
+    for (int c = 0; c < 3; c++) dcopy(P, P->U0[c], P->U[c], N);
+    for (int i = 0; i < NSP; i++) dcopy(P, P->Y0[i], P->Y[i], N);
+    FFM_TRY(rho_eqn(P));
+    // ---------------- UEqn.H
+    FFM_TRY(update_bcs(P));
+    double *Ub[3] = {P->wB[1], P->wB[2], P->wB[3]};
+    FFM_TRY(U_boundary(P, Ub));
+    double *mag2 = P->wN[0], *mag2b = P->wB[0], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *wU = P->wF[3];
+    {
+        const double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2], *b0 = Ub[0], *b1 = Ub[1], *b2 = Ub[2];
+        forN(P, N, [=] __device__(long i) { mag2[i] = (U0[i] * U0[i] + U1[i] * U1[i]) + U2[i] * U2[i]; });
+        forN(P, B, [=] __device__(long k) { mag2b[k] = (b0[k] * b0[k] + b1[k] * b1[k]) + b2[k] * b2[k]; });
+    }
+    FFM_TRY(ffm_fvc_grad(m, mag2, mag2b, gx, gy, gz));
+    FFM_TRY(ffm_fv_limited_weights(m, 2, 1.0, 0.0, 1.0, P->phi, mag2, gx, gy, gz, wU));
+    double *muf = P->wF[0], *mub = P->wB[4];
+    forN(P, nNat, [=] __device__(long e) { muf[e] = MU; });
+    forN(P, B, [=] __device__(long k) { mub[k] = MU; });
+    FFM_TRY(ffm_fvm_transport(m, rdt, P->rho, P->phi, wU, muf, -1, P->Udiag, P->Uupper, P->Ulower));
+    // reconstruct((-ghf*snGrad(rho) - snGrad(p_rgh))*magSf)
+    double *sgr = P->wF[1], *sgp = P->wF[2], *t = P->wF[4], *tb = P->wB[5], *rhob = P->wB[6], *pb = P->wB[7];
+    FFM_TRY(ffm_fvc_snGrad(m, P->rho, sgr));
+    zg(P, rhob, P->rho);
+    FFM_TRY(bc_p_rgh(P, nullptr, Ub, rhob));
+    FFM_TRY(ffm_bc_values(m, P->fP, P->refP, P->gradP, P->p_rgh, pb));
+    FFM_TRY(ffm_fvc_snGrad(m, P->p_rgh, sgp));
+    FFM_TRY(ffm_fvc_snGrad_b(m, P->p_rgh, pb, tb));
+    {
+        const double *ghf = P->ghf, *bMag = ffm_mesh_geom(m, 4);
+        forN(P, nNat, [=] __device__(long e) { t[e] = (-ghf[e] * sgr[e] - sgp[e]) * magSf[e]; });
+        forN(P, B, [=] __device__(long k) { tb[k] = -tb[k] * bMag[k]; });
+    }
+    double *rx = P->wN[5], *ry = P->wN[6], *rz = P->wN[7];
+    FFM_TRY(ffm_fvc_reconstruct(m, t, tb, rx, ry, rz));
+    double *rec[3] = {rx, ry, rz};
+    for (int c = 0; c < 3; c++) {
+        FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, mub, -1, P->fU[c], P->refU[c], P->zeroB, P->Uic[c], P->Ubc[c]));
+        double *s = P->Usrc[c]; const double *rho0 = P->rho0, *u0 = P->U0[c];
+        forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * u0[i] * V[i]; });
+    }
+    for (int c = 0; c < 3; c++) {
+        FFM_TRY(ffm_fvm_add_boundary(m, P->Uic[c], P->Ubc[c], P->Udiag, P->Usrc[c], rec[c], P->dWork, P->sWork));
+        const char *nm[3] = {"Ux", "Uy", "Uz"};
+        FFM_TRY(solve_named(P, nm[c], FFM_PBICGSTAB, FFM_DILU, 1e-6, 0.0, P->dWork, P->Uupper, P->Ulower, P->U[c], P->sWork));
+    }
+    {
+        double *K = P->K; const double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2];
+        forN(P, N, [=] __device__(long i) { K[i] = 0.5 * ((U0[i] * U0[i] + U1[i] * U1[i]) + U2[i] * U2[i]); });
+    }
+    // ---------------- YEEqn.H
+    double *af = P->wF[0], *afb = P->wB[4];
+    forN(P, nNat, [=] __device__(long e) { af[e] = 0.5 * (MU / PR) + (1.0 - 0.5) * (MU / PR); });
+    forN(P, B, [=] __device__(long k) { afb[k] = MU / PR; });
+    double *wFuel = P->wN[8], *Qdot = P->wN[9], *Yt = P->wN[10], *su = P->wN[11];
+    {
+        const double *rho = P->rho, *fuel = P->Y[2], *o2 = P->Y[0];
+        forN(P, N, [=] __device__(long i) { const double w = rho[i] * fmin(fuel[i], o2[i] / S_O2) / TAU; wFuel[i] = w; Qdot[i] = w * HC; Yt[i] = 0.0; });
+    }
+    for (int i = 0; i < NSP; i++) {
+        if (i == INERT) continue;
+        const double nu = NU[i];
+        forN(P, N, [=] __device__(long c) { su[c] = nu * wFuel[c]; });
+        FFM_TRY(scalar_transport(P, SPN[i], 3, P->Y[i], P->Y0[i], P->fS, P->refY[i], af, afb, su, nullptr, 1e-8));
+        double *Yi = P->Y[i];
+        forN(P, N, [=] __device__(long c) { const double v = fmax(Yi[c], 0.0); Yi[c] = v; Yt[c] += v; });
+    }
+    {
+        double *Yn = P->Y[INERT];
+        forN(P, N, [=] __device__(long c) { Yn[c] = fmax(1.0 - Yt[c], 0.0); });
+    }
+    // EEqn: explicit LHS terms fvc::ddt(rho,K) + fvc::div(phi,K) - dpdt
+    {
+        FFM_TRY(U_boundary(P, Ub));     // U.correctBoundaryConditions() after the momentum solve
+        double *Kb = P->wB[0], *kgx = P->wN[1], *kgy = P->wN[2], *kgz = P->wN[3], *wK = P->wF[3], *Kf = P->wF[4], *KfB = P->wB[5];
+        const double *b0 = Ub[0], *b1 = Ub[1], *b2 = Ub[2];
+        forN(P, B, [=] __device__(long k) { Kb[k] = 0.5 * ((b0[k] * b0[k] + b1[k] * b1[k]) + b2[k] * b2[k]); });
+        FFM_TRY(ffm_fvc_grad(m, P->K, Kb, kgx, kgy, kgz));
+        FFM_TRY(ffm_fv_limited_weights(m, 2, 1.0, 0.0, 1.0, P->phi, P->K, kgx, kgy, kgz, wK));
+        FFM_TRY(ffm_fvc_interpolate(m, wK, P->K, Kf));
+        const double *phi = P->phi, *phib = P->phib;
+        forN(P, nNat, [=] __device__(long e) { Kf[e] = phi[e] * Kf[e]; });
+        forN(P, B, [=] __device__(long k) { KfB[k] = phib[k] * Kb[k]; });
+        double *divK = P->wN[4];
+        FFM_TRY(ffm_fvc_surface_integrate(m, Kf, KfB, divK));
+        double *expl = P->wN[0]; const double *rho = P->rho, *rho0 = P->rho0, *K = P->K, *K0 = P->K0, *dpdt = P->dpdt;
+        forN(P, N, [=] __device__(long c) { expl[c] = (rdt * (rho[c] * K[c] - rho0[c] * K0[c]) + divK[c]) - dpdt[c]; });
+        FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8));
+    }
+    standin_thermo(P);
+    // ---------------- pEqn.H x 2
+    FFM_TRY(p_corrector(P, false));
+    FFM_TRY(p_corrector(P, true));
+    mul(P, P->rho, P->psi, P->p, N);
+    P->time += P->dt;
+    PL_HIP(hipStreamSynchronize(P->ctx->stream));
+    return FFM_OK;
+}
+
+extern "C" int ffm_plume_create(ffm_ctx *ctx, int nx, int ny, int nz, double h, double dt, ffm_plume **out)
+{
+    if (!ctx || !out || nx < 2 || ny < 2 || nz < 2) return FFM_ERR_ARG;
+    PL_HIP(hipSetDevice(ctx->device));
+    ffm_plume *P = new ffm_plume();
+    P->ctx = ctx; P->nx = nx; P->ny = ny; P->nz = nz; P->h = h; P->dt = dt; P->rdt = 1.0 / dt;
+    const long N = (long)nx * ny * nz;
+    P->N = (int)N;
+    // ---- natural blockMesh LDU
+    std::vector<int> l, u; std::vector<signed char> fd;
+    l.reserve(3 * N); u.reserve(3 * N); fd.reserve(3 * N);
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) {
+        const int c = i + nx * (j + ny * k);
+        if (i < nx - 1) { l.push_back(c); u.push_back(c + 1); fd.push_back(0); }
+        if (j < ny - 1) { l.push_back(c); u.push_back(c + nx); fd.push_back(1); }
+        if (k < nz - 1) { l.push_back(c); u.push_back(c + nx * ny); fd.push_back(2); }
+    }
+    const int F = (int)l.size(); P->F = F;
+    // ---- renumber once to the library's cell order (no permutation pass ever after)
+    std::vector<int> c2(N), f2(F);
+    FFM_TRY(ffm_renumber_levels((int)N, F, l.data(), u.data(), c2.data(), f2.data()));
+    P->newToOld = c2;
+    std::vector<int> oldToNew(N);
+    for (long c = 0; c < N; c++) oldToNew[c2[c]] = (int)c;
+    std::vector<int> l2(F), u2(F); std::vector<signed char> fd2(F);
+    for (int f = 0; f < F; f++) { l2[f] = oldToNew[l[f2[f]]]; u2[f] = oldToNew[u[f2[f]]]; fd2[f] = fd[f2[f]]; }
+    FFM_TRY(ffm_ldu_create(ctx, (int)N, F, l2.data(), u2.data(), &P->A));
+    if (!P->A->identity) { ffm_set_error("plume: renumbered mesh is not native"); return FFM_ERR_ADDR; }
+    P->nNat = P->A->upTotal;
+    // ---- geometry
+    auto ijk = [&](int cOld, int &i, int &j, int &k) { i = cOld % nx; j = (cOld / nx) % ny; k = cOld / (nx * ny); };
+    std::vector<double> V(N, h * h * h), C(3 * N), Sf(3 * (size_t)F, 0.0), magSf(F, h * h), wgt(F, 0.5), del(F, 1.0 / h), Cfy(F);
+    for (long c = 0; c < N; c++) { int i, j, k; ijk(c2[c], i, j, k); C[c] = (i + 0.5) * h; C[N + c] = (j + 0.5) * h; C[2 * N + c] = (k + 0.5) * h; }
+    for (int f = 0; f < F; f++) { Sf[(size_t)fd2[f] * F + f] = h * h; Cfy[f] = C[N + l2[f]] + (fd2[f] == 1 ? 0.5 * h : 0.0); }
+    // ---- patches: inlet, floor, top, sides(xmin,xmax,zmin,zmax)
+    const double Lx = nx * h, Lz = nz * h, hwx = std::min(0.5, Lx / 4), hwz = std::min(0.5, Lz / 4);
+    std::vector<int> pc[4]; std::vector<double> pS[4][3];
+    auto addFace = [&](int patch, int cOld, double sx, double sy, double sz) {
+        pc[patch].push_back(oldToNew[cOld]); pS[patch][0].push_back(sx); pS[patch][1].push_back(sy); pS[patch][2].push_back(sz);
+    };
+    for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) {          // ymin in natural cell order
+        const int c = i + nx * (0 + ny * k);
+        const bool in = std::fabs((i + 0.5) * h - Lx / 2) < hwx && std::fabs((k + 0.5) * h - Lz / 2) < hwz;
+        addFace(in ? P_INLET : P_FLOOR, c, 0, -h * h, 0);
+    }
+    for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) addFace(P_TOP, i + nx * ((ny - 1) + ny * k), 0, h * h, 0);
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) addFace(P_SIDES, 0 + nx * (j + ny * k), -h * h, 0, 0);
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) addFace(P_SIDES, (nx - 1) + nx * (j + ny * k), h * h, 0, 0);
+    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) addFace(P_SIDES, i + nx * (j + ny * 0), 0, 0, -h * h);
+    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) addFace(P_SIDES, i + nx * (j + ny * (nz - 1)), 0, 0, h * h);
+    int sizes[4]; const int *fcs[4]; const double *pSf[4]; const double *pDel[4];
+    std::vector<double> pSflat[4], pD[4];
+    int Btot = 0;
+    for (int p = 0; p < 4; p++) {
+        sizes[p] = (int)pc[p].size(); fcs[p] = pc[p].data(); Btot += sizes[p];
+        for (int d = 0; d < 3; d++) pSflat[p].insert(pSflat[p].end(), pS[p][d].begin(), pS[p][d].end());
+        pD[p].assign(sizes[p], 2.0 / h); pSf[p] = pSflat[p].data(); pDel[p] = pD[p].data();
+    }
+    P->B = Btot;
+    FFM_TRY(ffm_mesh_create(P->A, V.data(), C.data(), Sf.data(), magSf.data(), wgt.data(), del.data(), 4, sizes, fcs, pSf, pDel, &P->mesh));
+    const int B = Btot; const long nNat = P->nNat;
+    // ---- fields
+    auto NN = [&]() { return dalloc(P, N); };
+    for (int i = 0; i < NSP; i++) { P->Y[i] = dupload(P, std::vector<double>(N, Y_AMB[i])); P->Y0[i] = NN(); }
+    P->T = dupload(P, std::vector<double>(N, TREF)); P->hs = NN(); P->hs0 = NN();
+    for (int c = 0; c < 3; c++) { P->U[c] = NN(); P->U0[c] = NN(); }
+    P->p = dupload(P, std::vector<double>(N, PREF)); P->p0 = NN(); P->p_rgh = NN(); P->p_rgh0 = NN(); P->psi = NN(); P->psi0 = NN();
+    P->rho = NN(); P->rho0 = NN(); P->K = NN(); P->K0 = NN(); P->dpdt = NN(); P->ph_rgh = NN();
+    P->phi = dalloc(P, nNat); P->phi0 = dalloc(P, nNat); P->phib = dalloc(P, B); P->phib0 = dalloc(P, B); P->ph_rgh_b = dalloc(P, B);
+    {
+        const double ghRef = -9.81 * (ny * h);
+        std::vector<double> gh(N), ghf(std::max<long>(nNat, 1), 0.0);
+        for (long c = 0; c < N; c++) gh[c] = -9.81 * C[N + c] - ghRef;
+        for (int f = 0; f < F; f++) ghf[P->A->h_callerToNative[f]] = -9.81 * Cfy[f] - ghRef;
+        P->gh = dupload(P, gh); P->ghf = dupload(P, ghf);
+    }
+    // ---- boundary-condition templates
+    std::vector<double> kind(B), fsU[3], rU[3], fsS(B), fsH(B), rY[NSP], rH(B);
+    for (int c = 0; c < 3; c++) { fsU[c].assign(B, 0.0); rU[c].assign(B, 0.0); }
+    for (int i = 0; i < NSP; i++) rY[i].assign(B, 0.0);
+    int k0 = 0;
+    for (int p = 0; p < 4; p++) for (int q = 0; q < sizes[p]; q++, k0++) {
+        kind[k0] = p;
+        for (int c = 0; c < 3; c++) {
+            if (p == P_INLET) { fsU[c][k0] = 1.0; rU[c][k0] = (c == 1) ? U_IN : 0.0; }
+            else if (p == P_FLOOR) fsU[c][k0] = 1.0;
+            else fsU[c][k0] = (pS[p][c][q] != 0.0) ? 0.0 : -1.0;      // normal: zeroGradient; tangential: inletOutlet(0)
+        }
+        fsH[k0] = (p == P_INLET || p == P_FLOOR) ? 1.0 : -1.0;
+        if (p == P_INLET) { fsS[k0] = 1.0; rH[k0] = CP * (T_IN - TREF); for (int i = 0; i < NSP; i++) rY[i][k0] = Y_IN[i]; }
+        else if (p == P_FLOOR) { fsS[k0] = 0.0; }                     // species zeroGradient; h handled below
+        else { fsS[k0] = -1.0; rH[k0] = 0.0; for (int i = 0; i < NSP; i++) rY[i][k0] = Y_AMB[i]; }
+    }
+    P->kind_d = dupload(P, kind);
+    for (int c = 0; c < 3; c++) { P->fStaticU[c] = dupload(P, fsU[c]); P->refU[c] = dupload(P, rU[c]); P->fU[c] = dalloc(P, B); }
+    P->fStaticS = dupload(P, fsS); P->fS = dalloc(P, B); P->refH = dupload(P, rH);
+    P->fStaticH = dupload(P, fsH); P->fH = dalloc(P, B);
+    for (int i = 0; i < NSP; i++) P->refY[i] = dupload(P, rY[i]);
+    P->fP = dalloc(P, B); P->refP = dalloc(P, B); P->gradP = dalloc(P, B); P->zeroB = dalloc(P, B);
+    P->oneB = dupload(P, std::vector<double>(std::max(B, 1), 1.0));
+    // ---- matrix + work
+    P->diag = NN(); P->upper = dalloc(P, nNat); P->lower = dalloc(P, nNat); P->dWork = NN(); P->sWork = NN();
+    P->Udiag = NN(); P->Uupper = dalloc(P, nNat); P->Ulower = dalloc(P, nNat);
+    for (int c = 0; c < 3; c++) { P->src[c] = NN(); P->ic[c] = dalloc(P, B); P->bc[c] = dalloc(P, B); P->Usrc[c] = NN(); P->Uic[c] = dalloc(P, B); P->Ubc[c] = dalloc(P, B); }
+    for (auto &w : P->wN) w = NN();
+    for (auto &w : P->wF) w = dalloc(P, nNat);
+    for (auto &w : P->wB) w = dalloc(P, B);
+    for (double *p : P->pool) if (!p) { ffm_set_error("plume: out of device memory"); return FFM_ERR_HIP; }
+    PL_HIP(hipDeviceSynchronize());
+    // ---- initial state: quiescent ambient, then hydrostatic initialisation
+    standin_thermo(P);
+    mul(P, P->rho, P->psi, P->p, N);
+    FFM_TRY(hydrostatic_init(P));
+    PL_HIP(hipStreamSynchronize(ctx->stream));
+    *out = P;
+    return FFM_OK;
+}
+
+extern "C" int ffm_plume_destroy(ffm_plume *P)
+{
+    if (!P) return FFM_OK;
+    hipStreamSynchronize(P->ctx->stream);
+    for (double *p : P->pool) hipFree(p);
+    ffm_mesh_destroy(P->mesh); ffm_ldu_destroy(P->A);
+    delete P;
+    return FFM_OK;
+}
+
+extern "C" int ffm_plume_ncells(const ffm_plume *P) { return P ? P->N : FFM_ERR_ARG; }
+extern "C" int ffm_plume_nfaces(const ffm_plume *P) { return P ? P->F : FFM_ERR_ARG; }
+
+// copy a cell field to the host in NATURAL blockMesh cell order; name in rho,p,p_rgh,T,h,K,Ux,Uy,Uz,psi,<specie>
+extern "C" int ffm_plume_get_field(ffm_plume *P, const char *name, double *out)
+{
+    if (!P || !name || !out) return FFM_ERR_ARG;
+    const std::string n(name);
+    const double *src = nullptr;
+    if (n == "rho") src = P->rho; else if (n == "p") src = P->p; else if (n == "p_rgh") src = P->p_rgh; else if (n == "T") src = P->T;
+    else if (n == "h") src = P->hs; else if (n == "K") src = P->K; else if (n == "Ux") src = P->U[0]; else if (n == "Uy") src = P->U[1];
+    else if (n == "Uz") src = P->U[2]; else if (n == "psi") src = P->psi; else if (n == "ph_rgh") src = P->ph_rgh;
+    else for (int i = 0; i < NSP; i++) if (n == SPN[i]) src = P->Y[i];
+    if (!src) { ffm_set_error("unknown field %s", name); return FFM_ERR_ARG; }
+    std::vector<double> v(P->N);
+    PL_HIP(hipStreamSynchronize(P->ctx->stream));
+    PL_HIP(hipMemcpy(v.data(), src, sizeof(double) * P->N, hipMemcpyDeviceToHost));
+    for (int c = 0; c < P->N; c++) out[P->newToOld[c]] = v[c];
+    return FFM_OK;
+}
+
+extern "C" int ffm_plume_nsolves(const ffm_plume *P) { return P ? (int)P->log.size() : FFM_ERR_ARG; }
+extern "C" int ffm_plume_get_solve(const ffm_plume *P, int i, char *name16, ffm_perf *perf)
+{
+    if (!P || i < 0 || i >= (int)P->log.size()) return FFM_ERR_ARG;
+    if (name16) memcpy(name16, P->log[i].name, 16);
+    if (perf) *perf = P->log[i].perf;
+    return FFM_OK;
+}
+extern "C" ffm_ldu *ffm_plume_ldu(ffm_plume *P) { return P ? P->A : nullptr; }

@@ -163,6 +163,87 @@ int ffm_solve(ffm_ldu *ldu, int solver, int precond, double tolerance,
 int ffm_bench_spmv(ffm_ldu *ldu, const double *x_d, double *y_d, int reps,
                    double *avg_ms);
 
+/* ------------------------------------------------------- finite-volume mesh */
+/* fvMesh geometry on the device (mesh.V(), Sf(), magSf(), weights(), deltaCoeffs(),
+ * boundary(); reference use: solver/UEqn.H:28, solver/pEqn.H:7).  The LDU must
+ * be in the library's cell order (ffm_renumber_levels).  Host arrays: V[N],
+ * C[3][N]; Sf[3][F], magSf[F], weights[F], deltaCoeffs[F] in LDU face order;
+ * per patch faceCells[n], Sf[3][n], deltaCoeffs[n].  Face fields handed to the
+ * fv entry points are in the NATIVE face layout (ffm_mesh_nnative entries,
+ * conversion helpers below); boundary fields have ffm_mesh_nboundary entries,
+ * patches concatenated in the order given here.                              */
+typedef struct ffm_mesh ffm_mesh;
+int ffm_mesh_create(ffm_ldu *ldu, const double *V, const double *C,
+                    const double *Sf, const double *magSf, const double *weights,
+                    const double *deltaCoeffs, int nPatches, const int *patchSizes,
+                    const int *const *faceCells, const double *const *patchSf,
+                    const double *const *patchDeltaCoeffs, ffm_mesh **out);
+int ffm_mesh_destroy(ffm_mesh *mesh);
+int ffm_mesh_nboundary(const ffm_mesh *mesh);
+int ffm_mesh_nnative(const ffm_mesh *mesh);
+int ffm_faces_to_native(const ffm_mesh *mesh, const double *lduOrder, double *native_d);
+int ffm_faces_from_native(const ffm_mesh *mesh, const double *native_d, double *lduOrder);
+
+/* ------------------------------------------------------- fvc:: (explicit)    */
+/* solver/UEqn.H:23-29, solver/pEqn.H:4-17,43-44, solver/YEEqn.H:87-95.  All
+ * pointers are device pointers; *_f = face field (native), *_b = boundary field. */
+int ffm_fvc_interpolate(ffm_mesh *m, const double *w_f, const double *vf, double *out_f);
+int ffm_fvc_snGrad(ffm_mesh *m, const double *vf, double *out_f);
+int ffm_fvc_snGrad_b(ffm_mesh *m, const double *vf, const double *vb, double *out_b);
+int ffm_fvc_flux(ffm_mesh *m, const double *vx, const double *vy, const double *vz, double *out_f);
+int ffm_fvc_surface_integrate(ffm_mesh *m, const double *ssf_f, const double *ssf_b, double *out);
+int ffm_fvc_surface_sum(ffm_mesh *m, const double *ssf_f, const double *ssf_b, double *out);
+int ffm_fvc_grad(ffm_mesh *m, const double *vf, const double *vb, double *gx, double *gy, double *gz);
+int ffm_fvc_reconstruct(ffm_mesh *m, const double *ssf_f, const double *ssf_b, double *ox, double *oy, double *oz);
+/* limitedSurfaceInterpolationScheme weights: scheme 0 upwind, 1 linear,
+ * 2 limitedLinear k, 3 limitedLinear01 k with bounds [lo,hi]
+ * (cases/steckler/system/fvSchemes:28-54)                                    */
+int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double hi,
+                           const double *phi_f, const double *vf, const double *gx,
+                           const double *gy, const double *gz, double *out_w_f);
+
+/* ------------------------------------------------------- fvm:: (implicit)    */
+/* [fvm::ddt(rho,.)] + [fvm::div(phi,.)] (+/-) [fvm::laplacian(gamma,.)] in one
+ * pass; absent terms: NULL.  Writes lduMatrix diag/upper/lower (native layout). */
+int ffm_fvm_transport(ffm_mesh *m, double rDeltaT, const double *rho,
+                      const double *phi_f, const double *w_f, const double *gamma_f,
+                      int laplacianSign, double *diag, double *upper, double *lower);
+/* internalCoeffs / boundaryCoeffs of the same terms for a patch field in
+ * `mixed` form (valueFraction f, refValue, refGradient); fixedValue,
+ * zeroGradient, fixedGradient, inletOutlet are special cases               */
+int ffm_fvm_boundary_coeffs(ffm_mesh *m, const double *phi_b, const double *gamma_b,
+                            int laplacianSign, const double *f, const double *ref,
+                            const double *refGrad, double *internalCoeffs, double *boundaryCoeffs);
+int ffm_bc_values(ffm_mesh *m, const double *f, const double *ref, const double *refGrad,
+                  const double *vf, double *out_b);
+/* fvMatrix::addBoundaryDiag + addBoundarySource (+ V*su)                     */
+int ffm_fvm_add_boundary(ffm_mesh *m, const double *internalCoeffs, const double *boundaryCoeffs,
+                         const double *diag, const double *source, const double *su,
+                         double *diagOut, double *sourceOut);
+/* fvMatrix::A(), H() (one component), flux()  (solver/pEqn.H:3,5,43)          */
+int ffm_fvm_A(ffm_mesh *m, int nCmpt, const double *diag, const double *ic0, const double *ic1,
+              const double *ic2, double *out);
+int ffm_fvm_H(ffm_mesh *m, int nCmpt, int cmpt, const double *upper, const double *lower,
+              const double *source, const double *ic0, const double *ic1, const double *ic2,
+              const double *bcCmpt, const double *psi, double *out);
+int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lower, const double *internalCoeffs,
+                 const double *boundaryCoeffs, const double *psi, double *out_f, double *out_b);
+
+/* ------------------------------------------------------- synthetic plume case */
+/* Host-side driver (C++ over the entry points above) of one fireFoam time step on
+ * the synthetic buoyant-plume box of SURVEY 8(d): rhoEqn, UEqn, YEEqn, 2 x pEqn in
+ * the order of solver/fireFoam.C:97-119.  bench.py's workload.                */
+typedef struct ffm_plume ffm_plume;
+int ffm_plume_create(ffm_ctx *ctx, int nx, int ny, int nz, double h, double deltaT, ffm_plume **out);
+int ffm_plume_destroy(ffm_plume *p);
+int ffm_plume_step(ffm_plume *p);
+int ffm_plume_ncells(const ffm_plume *p);
+int ffm_plume_nfaces(const ffm_plume *p);
+int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);
+int ffm_plume_nsolves(const ffm_plume *p);
+int ffm_plume_get_solve(const ffm_plume *p, int i, char *name16, ffm_perf *perf);
+ffm_ldu *ffm_plume_ldu(ffm_plume *p);
+
 /* ---------------------------------------------------------------- reductions */
 /* gSum / gMin / gMax / gSumProd / gSumMag over a device field (solver/YEEqn.H:
  * 73-78,117-118; solver/phrghEqn.H:54-55).  All-reduced when a communicator is

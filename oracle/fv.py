@@ -113,8 +113,9 @@ def surface_integrate(mesh, ssf, bssf):
     """fvc::surfaceIntegrate == fvc::div(ssf): owner += , neighbour -= in face order, then the
     boundary faces patch by patch, then divide by V."""
     out = np.zeros(mesh.nCells)
-    np.add.at(out, mesh.l, ssf)
+    # a cell meets its faces in face order: first those where it is the neighbour, then those it owns
     np.subtract.at(out, mesh.u, ssf)
+    np.add.at(out, mesh.l, ssf)
     for p, b in zip(mesh.patches, bssf):
         np.add.at(out, p.faceCells, b)
     return out / mesh.V
@@ -134,8 +135,8 @@ class ScalarMatrix:
 
     def neg_sum_diag(self):
         lo = self.upper if self.lower is None else self.lower
-        np.subtract.at(self.diag, self.mesh.l, lo)
         np.subtract.at(self.diag, self.mesh.u, self.upper)
+        np.subtract.at(self.diag, self.mesh.l, lo)
 
     def solve_ready(self):
         """fvMatrix::solveSegregated preamble: diag + addBoundaryDiag, source + addBoundarySource."""
@@ -163,4 +164,210 @@ def laplacian(mesh, gamma_f, gamma_b, bcs):
             gi = np.zeros(p.size); gb = np.zeros(p.size)
         M.internalCoeffs[q] = pGamma * gi
         M.boundaryCoeffs[q] = -pGamma * gb
+    return M
+
+
+# =====================================================================================
+# Everything below: operators for the full outer iteration (UEqn / YEEqn / pEqn / rhoEqn).
+# Boundary conditions are carried in OpenFOAM's `mixed` form (mixedFvPatchField.C):
+#   value_b = f*refValue + (1-f)*(cell + refGrad/delta)
+#   valueInternalCoeffs = 1-f ; valueBoundaryCoeffs = f*ref + (1-f)*refGrad/delta
+#   gradientInternalCoeffs = -f*delta ; gradientBoundaryCoeffs = f*delta*ref + (1-f)*refGrad
+# fixedValue (f=1), zeroGradient (f=0, refGrad=0), fixedGradient (f=0), inletOutlet
+# (f = 1-pos0(phi_b)) are special cases.
+# =====================================================================================
+class MixedBC:
+    """Per-patch lists of arrays f, ref, refGrad (one entry per boundary face)."""
+
+    def __init__(self, mesh, f=None, ref=None, refGrad=None):
+        z = lambda: [np.zeros(p.size) for p in mesh.patches]
+        self.f = f if f is not None else z()
+        self.ref = ref if ref is not None else z()
+        self.refGrad = refGrad if refGrad is not None else z()
+
+    def values(self, mesh, vf):
+        return [f * r + (1.0 - f) * (vf[p.faceCells] + g / p.deltaCoeffs)
+                for p, f, r, g in zip(mesh.patches, self.f, self.ref, self.refGrad)]
+
+    def value_internal(self):
+        return [1.0 - f for f in self.f]
+
+    def value_boundary(self, mesh):
+        return [f * r + (1.0 - f) * g / p.deltaCoeffs for p, f, r, g in zip(mesh.patches, self.f, self.ref, self.refGrad)]
+
+    def grad_internal(self, mesh):
+        return [-f * p.deltaCoeffs for p, f in zip(mesh.patches, self.f)]
+
+    def grad_boundary(self, mesh):
+        return [f * p.deltaCoeffs * r + (1.0 - f) * g for p, f, r, g in zip(mesh.patches, self.f, self.ref, self.refGrad)]
+
+
+def pos0(x):
+    return (x >= 0).astype(float)
+
+
+def surface_sum(mesh, ssf, bssf):
+    """fvc::surfaceSum: owner += , neighbour += , boundary += (no division by V)."""
+    out = np.zeros(mesh.nCells)
+    np.add.at(out, mesh.u, ssf)
+    np.add.at(out, mesh.l, ssf)
+    for p, b in zip(mesh.patches, bssf):
+        np.add.at(out, p.faceCells, b)
+    return out
+
+
+def grad(mesh, vf, bvals):
+    """fvc::grad, Gauss linear (cases/steckler/system/fvSchemes:23-26): (1/V) sum_f Sf*vf_f."""
+    ff, fb = interpolate(mesh, vf, bvals)
+    out = np.zeros((mesh.nCells, 3))
+    for d in range(3):
+        out[:, d] = surface_integrate(mesh, mesh.Sf[:, d] * ff, [p.Sf[:, d] * b for p, b in zip(mesh.patches, fb)])
+    return out
+
+
+def reconstruct(mesh, ssf, bssf):
+    """fvc::reconstruct(ssf) = inv(surfaceSum(Sf (x) Sf/magSf)) & surfaceSum((Sf/magSf)*ssf)."""
+    N = mesh.nCells
+    T = np.zeros((N, 3, 3)); v = np.zeros((N, 3))
+    for a in range(3):
+        v[:, a] = surface_sum(mesh, mesh.Sf[:, a] / mesh.magSf * ssf, [p.Sf[:, a] / p.magSf * b for p, b in zip(mesh.patches, bssf)])
+        for b_ in range(3):
+            T[:, a, b_] = surface_sum(mesh, mesh.Sf[:, a] * mesh.Sf[:, b_] / mesh.magSf,
+                                      [p.Sf[:, a] * p.Sf[:, b_] / p.magSf for p in mesh.patches])
+    return np.einsum("nab,nb->na", np.linalg.inv(T), v)
+
+
+def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
+    """Face weights of upwind / linear / limitedLinear k / limitedLinear01 k
+    (limitedSurfaceInterpolationScheme::weights, NVDTVD::r, limitedLinearLimiter, LimitedLimiter)."""
+    w = mesh.weights
+    if scheme == "linear":
+        return w.copy()
+    if scheme == "upwind":
+        return pos0(phi)
+    P, Nn = vf[mesh.l], vf[mesh.u]
+    d = mesh.C[mesh.u] - mesh.C[mesh.l]
+    gradf = Nn - P
+    gradcf = np.where(phi > 0, np.einsum("fd,fd->f", d, gradvf[mesh.l]), np.einsum("fd,fd->f", d, gradvf[mesh.u]))
+    big = np.abs(gradcf) >= 1000.0 * np.abs(gradf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.where(big, 2.0 * 1000.0 * np.sign(gradcf) * np.sign(gradf) - 1.0, 2.0 * (gradcf / gradf) - 1.0)
+    twoByk = 2.0 / max(k, 1e-15)
+    lim = np.maximum(np.minimum(twoByk * r, 1.0), 0.0)
+    if scheme == "limitedLinear01":
+        lo, hi = bounds
+        off = ((phi > 0) & ((P < lo) | (Nn > hi))) | ((phi < 0) & ((Nn < lo) | (P > hi)))
+        lim = np.where(off, 0.0, lim)
+    elif scheme != "limitedLinear":
+        raise ValueError(scheme)
+    return lim * w + (1.0 - lim) * pos0(phi)
+
+
+class Matrix:
+    """fvMatrix<Type> with nc components sharing diag/upper/lower (Type = scalar: nc=1, vector: nc=3)."""
+
+    def __init__(self, mesh, nc=1):
+        self.mesh, self.nc = mesh, nc
+        self.diag = np.zeros(mesh.nCells)
+        self.upper = np.zeros(mesh.nFaces)
+        self.lower = np.zeros(mesh.nFaces)
+        self.source = np.zeros((nc, mesh.nCells))
+        self.internalCoeffs = [np.zeros((nc, p.size)) for p in mesh.patches]
+        self.boundaryCoeffs = [np.zeros((nc, p.size)) for p in mesh.patches]
+
+    def neg_sum_diag(self):
+        np.subtract.at(self.diag, self.mesh.u, self.upper)
+        np.subtract.at(self.diag, self.mesh.l, self.lower)
+
+    def __iadd__(self, o):
+        self.diag += o.diag; self.upper += o.upper; self.lower += o.lower; self.source += o.source
+        for q in range(len(self.internalCoeffs)):
+            self.internalCoeffs[q] += o.internalCoeffs[q]; self.boundaryCoeffs[q] += o.boundaryCoeffs[q]
+        return self
+
+    def __isub__(self, o):
+        self.diag -= o.diag; self.upper -= o.upper; self.lower -= o.lower; self.source -= o.source
+        for q in range(len(self.internalCoeffs)):
+            self.internalCoeffs[q] -= o.internalCoeffs[q]; self.boundaryCoeffs[q] -= o.boundaryCoeffs[q]
+        return self
+
+    def add_su(self, su):
+        """`M == su` / `M - su` for a volField su: source += V*su."""
+        self.source += self.mesh.V * np.atleast_2d(su)
+        return self
+
+    def solve_system(self, cmpt=0):
+        d = self.diag.copy(); s = self.source[cmpt].copy()
+        for p, ic, bc in zip(self.mesh.patches, self.internalCoeffs, self.boundaryCoeffs):
+            np.add.at(d, p.faceCells, ic[cmpt]); np.add.at(s, p.faceCells, bc[cmpt])
+        return d, s
+
+    def A(self):
+        """fvMatrix::A(): (diag + cmptAv boundary diag)/V."""
+        d = self.diag.copy()
+        for p, ic in zip(self.mesh.patches, self.internalCoeffs):
+            np.add.at(d, p.faceCells, ic.mean(axis=0))
+        return d / self.mesh.V
+
+    def H(self, psi):
+        """fvMatrix::H(): (source + boundarySource - sum offdiag*psi_nb + (avgBD - BD_cmpt)*psi)/V."""
+        m = self.mesh
+        out = np.zeros((self.nc, m.nCells))
+        for c in range(self.nc):
+            bd = np.zeros(m.nCells); bda = np.zeros(m.nCells)
+            for p, ic in zip(m.patches, self.internalCoeffs):
+                np.add.at(bd, p.faceCells, ic[c]); np.add.at(bda, p.faceCells, ic.mean(axis=0))
+            h = (bda - bd) * psi[c]
+            hl = np.zeros(m.nCells)
+            np.subtract.at(hl, m.u, self.lower * psi[c][m.l])
+            np.subtract.at(hl, m.l, self.upper * psi[c][m.u])
+            h += hl + self.source[c]
+            for p, bc in zip(m.patches, self.boundaryCoeffs):
+                np.add.at(h, p.faceCells, bc[c])
+            out[c] = h / m.V
+        return out
+
+    def flux(self, psi, cmpt=0):
+        """fvMatrix::flux(): internal upper*psi_u - lower*psi_l; boundary internalCoeffs*psi_c - boundaryCoeffs."""
+        m = self.mesh
+        fi = self.upper * psi[m.u] - self.lower * psi[m.l]
+        fb = [ic[cmpt] * psi[p.faceCells] - bc[cmpt] for p, ic, bc in zip(m.patches, self.internalCoeffs, self.boundaryCoeffs)]
+        return fi, fb
+
+
+def fvm_ddt(mesh, rDeltaT, rho, rho0, vf0):
+    """EulerDdtScheme::fvmDdt(rho, vf): diag = rDeltaT*rho*V; source = rDeltaT*rho0*vf0*V."""
+    vf0 = np.atleast_2d(vf0)
+    M = Matrix(mesh, vf0.shape[0])
+    M.diag = rDeltaT * rho * mesh.V
+    M.source = rDeltaT * rho0 * vf0 * mesh.V
+    return M
+
+
+def fvm_div(mesh, phi, phib, w, bcs):
+    """gaussConvectionScheme::fvmDiv; bcs = list of MixedBC, one per component."""
+    M = Matrix(mesh, len(bcs))
+    M.lower = -w * phi
+    M.upper = M.lower + phi
+    M.neg_sum_diag()
+    for c, bc in enumerate(bcs):
+        vi, vb = bc.value_internal(), bc.value_boundary(mesh)
+        for q in range(len(mesh.patches)):
+            M.internalCoeffs[q][c] = phib[q] * vi[q]
+            M.boundaryCoeffs[q][c] = -phib[q] * vb[q]
+    return M
+
+
+def fvm_laplacian(mesh, gamma_f, gamma_b, bcs):
+    """gaussLaplacianScheme::fvmLaplacianUncorrected; bcs = list of MixedBC, one per component."""
+    M = Matrix(mesh, len(bcs))
+    M.upper = gamma_f * mesh.magSf * mesh.deltaCoeffs
+    M.lower = M.upper.copy()
+    M.neg_sum_diag()
+    for c, bc in enumerate(bcs):
+        gi, gb = bc.grad_internal(mesh), bc.grad_boundary(mesh)
+        for q, p in enumerate(mesh.patches):
+            pG = gamma_b[q] * p.magSf
+            M.internalCoeffs[q][c] = pG * gi[q]
+            M.boundaryCoeffs[q][c] = -pG * gb[q]
     return M

@@ -1,0 +1,314 @@
+"""ORACLE (test infrastructure): one fireFoam time step (PIMPLE, nOuterCorrectors 1, nCorrectors 2,
+nNonOrthogonalCorrectors 0 -- reference cases/steckler/system/fvSolution:84-89) on the synthetic
+buoyant-plume box of SURVEY 8(d), restated in numpy with oracle/fv.py operators and the C solvers.
+
+It follows the reference's equation snippets term by term:
+  rhoEqn   solver/rhoEqn.H:33-43      fvm::ddt(rho) + fvc::div(phi) == 0                  (diagonalSolver)
+  UEqn     solver/UEqn.H:3-33         fvm::ddt(rho,U) + fvm::div(phi,U) + divDevRhoReff(U); solve(UEqn ==
+                                      fvc::reconstruct((-ghf*snGrad(rho) - snGrad(p_rgh))*magSf)); K
+  YEEqn    solver/YEEqn.H:37-71       per specie: ddt + mvConvection->fvmDiv - laplacian(dEff) == R(Yi); max(0); inert
+           solver/YEEqn.H:84-118      he: ddt + fvmDiv + fvc::ddt(rho,K) + fvc::div(phi,K) - dpdt - laplacian(alphaEff)
+                                      == Qdot; thermo.correct()
+  pEqn     solver/pEqn.H:1-60         rAU, rhorAUf, HbyA, phig, phiHbyA (flux + ddtCorr), constrainPressure, p_rghEqn,
+                                      phi, U, p, rhoEqn, K, dpdt                              (x2; second uses p_rghFinal)
+  start-up solver/phrghEqn.H:25-56    hydrostatic initialisation, 5 correctors
+The physics plug-ins the reference gets from other libraries are replaced by documented stand-ins
+(SURVEY 2.2 U18, section 7 step 6): perfect gas with constant Cp and per-cell mixture molecular
+weight; constant mu, Pr, Le = 1 (laminar: divDevRhoReff(U) = -fvm::laplacian(mu,U)); an
+EDC-shaped single-step source R = rho*min(Yfuel, YO2/s)/tau; no radiation, spray or film; boundary
+values of the thermo fields (rho, psi, T-derived) are zero-gradient copies of the cell values.
+Schemes: Euler; Gauss limitedLinear 1 for U (through magSqr(U), as LimitedScheme<vector,...,magSqr>),
+K and h; limitedLinear01 1 for species; Gauss linear uncorrected laplacians; linear interpolation
+(cases/steckler/system/fvSchemes:18-76 with LUST replaced by limitedLinear for div(phi,U)).
+"""
+import numpy as np
+
+from . import fv, oracle as O
+
+RR = 8314.47
+SPECIES = ["O2", "H2O", "C3H8", "CO2", "N2"]          # N2 inert (cases/steckler/constant/thermophysicalProperties:28)
+WMOL = np.array([31.9988, 18.0153, 44.0962, 44.01, 28.0134])
+Y_AMB = np.array([0.23301, 0.0, 0.0, 0.0, 0.76699])    # cases/steckler/0/{O2,N2}
+Y_IN = np.array([0.0, 0.0, 1.0, 0.0, 0.0])            # pure fuel at the inlet patch
+INERT = 4
+CP, TREF, PREF = 1005.0, 298.15, 101325.0
+MU, PR = 1.8e-5, 0.7
+S_O2 = 3.6282945                                        # golden log: stoichiometric oxygen-fuel ratio
+HC = 46357151.0                                         # golden log: fuel heat of combustion
+TAU = 0.05                                              # mixing time of the EDC-shaped stand-in [s]
+# products per kg fuel (C3H8 + 5 O2 -> 3 CO2 + 4 H2O)
+NU = np.array([-S_O2, 4 * 18.0153 / 44.0962, -1.0, 3 * 44.01 / 44.0962, 0.0])
+T_IN, U_IN = 600.0, 0.5
+G = np.array([0.0, -9.81, 0.0])
+
+
+def make_mesh(n, h=0.05):
+    nx, ny, nz = n
+    m = fv.HexMesh(n, (0, 0, 0), (nx * h, ny * h, nz * h))
+    # split ymin into inlet (central patch, 1 m^2 or the central quarter on small boxes) and floor
+    ymin = m._bdefs["ymin"]
+    Lx, Lz = nx * h, nz * h
+    hw = (min(0.5, Lx / 4), min(0.5, Lz / 4))
+    cen = ymin.Cf
+    isin = (np.abs(cen[:, 0] - Lx / 2) < hw[0]) & (np.abs(cen[:, 2] - Lz / 2) < hw[1])
+    for name, sel in (("inlet_part", isin), ("floor_part", ~isin)):
+        m._bdefs[name] = fv.Patch(name, ymin.faceCells[sel], ymin.Sf[sel], ymin.Cf[sel], ymin.deltaCoeffs[sel])
+    m.set_patches([("inlet", ["inlet_part"]), ("floor", ["floor_part"]), ("top", ["ymax"]),
+                   ("sides", ["xmin", "xmax", "zmin", "zmax"])])
+    return m
+
+
+class Solvers:
+    """lduMatrix::solver selection as in fvSolution; `solve(kind, mesh, diag, upper, lower, source, psi0)`."""
+    CONTROLS = {
+        "p_rgh": dict(solver="PCG", pre="DIC", tolerance=1e-6, relTol=0.01),
+        "p_rghFinal": dict(solver="PCG", pre="DIC", tolerance=1e-6, relTol=0.0),
+        "ph_rgh": dict(solver="PCG", pre="DIC", tolerance=1e-6, relTol=0.01),
+        "U": dict(solver="PBICGSTAB", pre="DILU", tolerance=1e-6, relTol=0.0),
+        "Yi": dict(solver="PBICGSTAB", pre="DILU", tolerance=1e-8, relTol=0.0),
+        "h": dict(solver="PBICGSTAB", pre="DILU", tolerance=1e-8, relTol=0.0),
+    }
+
+    def __init__(self):
+        self.log = []
+
+    def solve(self, kind, name, mesh, diag, upper, lower, source, psi0):
+        c = self.CONTROLS[kind]
+        A = O.Ldu(mesh.nCells, mesh.l, mesh.u).set_coeffs(diag, upper, None if c["solver"] == "PCG" else lower)
+        psi, perf = A.solve(getattr(O, c["solver"]), getattr(O, c["pre"]), psi0, source, tolerance=c["tolerance"], relTol=c["relTol"])
+        self.log.append((name, perf))
+        return psi
+
+
+class Plume:
+    def __init__(self, n, h=0.05, dt=1e-3, solvers=None):
+        self.m = m = make_mesh(n, h)
+        self.dt, self.rDeltaT = dt, 1.0 / dt
+        self.sol = solvers or Solvers()
+        N = m.nCells
+        self.names = [p.name for p in m.patches]
+        self.ghRef = -np.linalg.norm(G) * (n[1] * h)            # hRef = top of the box
+        self.gh = m.C @ G - self.ghRef
+        self.ghf = m.Cf @ G - self.ghRef
+        self.Y = np.tile(Y_AMB[:, None], (1, N))
+        self.T = np.full(N, TREF)
+        self.h = CP * (self.T - TREF)
+        self.U = np.zeros((3, N))
+        self.p = np.full(N, PREF)
+        self.p_rgh = np.zeros(N)
+        self.psi = self.calc_psi()
+        self.rho = self.psi * self.p
+        self.phi = np.zeros(m.nFaces); self.phib = [np.zeros(p.size) for p in m.patches]
+        self.K = np.zeros(N); self.dpdt = np.zeros(N)
+        self.hydrostatic_init()
+        self.time = 0.0
+
+    # ---- thermo stand-in -------------------------------------------------------------------
+    def calc_psi(self):
+        return 1.0 / (RR * self.T * (self.Y / WMOL[:, None]).sum(axis=0))
+
+    def thermo_correct(self):
+        self.T = TREF + self.h / CP
+        self.psi = self.calc_psi()
+
+    def zg(self, vf):            # zero-gradient boundary copy of a cell field
+        return [vf[p.faceCells] for p in self.m.patches]
+
+    # ---- boundary conditions (mixed form) --------------------------------------------------
+    def bc_U(self):
+        m = self.m
+        bcs = [fv.MixedBC(m) for _ in range(3)]
+        for q, p in enumerate(m.patches):
+            for c in range(3):
+                if p.name == "inlet":
+                    bcs[c].f[q][:] = 1.0; bcs[c].ref[q][:] = U_IN if c == 1 else 0.0
+                elif p.name == "floor":
+                    bcs[c].f[q][:] = 1.0
+                else:   # pressureInletOutletVelocity: tangential components fixed 0 on inflow, normal zeroGradient
+                    nrm = np.abs(p.Sf[:, c]) > 0
+                    bcs[c].f[q] = np.where(nrm, 0.0, 1.0 - fv.pos0(self.phib[q]))
+        return bcs
+
+    def bc_scalar(self, inlet, ambient, floor_fixed=None):
+        m = self.m
+        bc = fv.MixedBC(m)
+        for q, p in enumerate(m.patches):
+            if p.name == "inlet":
+                bc.f[q][:] = 1.0; bc.ref[q][:] = inlet
+            elif p.name == "floor":
+                if floor_fixed is not None:
+                    bc.f[q][:] = 1.0; bc.ref[q][:] = floor_fixed
+            else:       # inletOutlet
+                bc.f[q] = 1.0 - fv.pos0(self.phib[q]); bc.ref[q][:] = ambient
+        return bc
+
+    def bc_p_rgh(self, gradients):
+        """fixedFluxPressure on inlet/floor (gradient from constrainPressure); prghTotalHydrostaticPressure
+        on top/sides: p_rgh = ph_rgh - 0.5*rho*(1-pos0(phi))*|U|^2."""
+        m = self.m
+        bc = fv.MixedBC(m)
+        Ub = [np.stack(v) for v in zip(*[b.values(m, self.U[c]) for c, b in enumerate(self.bc_U())])]
+        rhob = self.zg(self.rho)
+        for q, p in enumerate(m.patches):
+            if p.name in ("inlet", "floor"):
+                bc.refGrad[q] = gradients[q]
+            else:
+                bc.f[q][:] = 1.0
+                bc.ref[q] = self.ph_rgh_b[q] - 0.5 * rhob[q] * (1.0 - fv.pos0(self.phib[q])) * (Ub[q] ** 2).sum(axis=0)
+        return bc
+
+    # ---- solver/phrghEqn.H ----------------------------------------------------------------
+    def hydrostatic_init(self, nCorr=5):
+        m = self.m
+        ph = np.zeros(m.nCells)
+        self.p = ph + self.rho * self.gh + PREF
+        self.thermo_correct(); self.rho = self.psi * self.p
+        for _ in range(nCorr):
+            rhof, rhofb = fv.interpolate(m, self.rho, self.zg(self.rho))
+            sg, _ = fv.snGrad(m, self.rho, self.zg(self.rho))
+            phig = -rhof * self.ghf * sg * m.magSf
+            phigb = [np.zeros(p.size) for p in m.patches]
+            bc = fv.MixedBC(m)
+            for q, p in enumerate(m.patches):
+                if p.name == "top":
+                    bc.f[q][:] = 1.0
+            M = fv.fvm_laplacian(m, rhof, rhofb, [bc])
+            M.add_su(fv.surface_integrate(m, phig, phigb))
+            d, s = M.solve_system()
+            ph = self.sol.solve("ph_rgh", "ph_rgh", m, d, M.upper, M.lower, s, ph)
+            self.p = ph + self.rho * self.gh + PREF
+            self.thermo_correct(); self.rho = self.psi * self.p
+        self.ph_rgh = ph
+        self.ph_rgh_b = fv.MixedBC(m, f=bc.f).values(m, ph)
+        self.p_rgh = ph.copy()
+
+    # ---- one time step (solver/fireFoam.C:76-121) -----------------------------------------
+    def rho_eqn(self):
+        m = self.m
+        d = self.rDeltaT * m.V
+        s = self.rDeltaT * self.rho0 * m.V - m.V * fv.surface_integrate(m, self.phi, self.phib)
+        self.rho = s / d            # diagonalSolver
+
+    def step(self):
+        m, rdt = self.m, self.rDeltaT
+        self.sol.log = []
+        # oldTime fields
+        self.rho0, self.U0, self.h0, self.Y0 = self.rho.copy(), self.U.copy(), self.h.copy(), self.Y.copy()
+        self.K0, self.p0, self.psi0, self.p_rgh0 = self.K.copy(), self.p.copy(), self.psi.copy(), self.p_rgh.copy()
+        self.phi0, self.phib0 = self.phi.copy(), [b.copy() for b in self.phib]
+        self.rho_eqn()
+        # ---- UEqn.H
+        bcU = self.bc_U()
+        muf = np.full(m.nFaces, MU); mub = [np.full(p.size, MU) for p in m.patches]
+        magSqrU = (self.U ** 2).sum(axis=0)
+        Ub = [b.values(m, self.U[c]) for c, b in enumerate(bcU)]
+        magSqrUb = [sum(Ub[c][q] ** 2 for c in range(3)) for q in range(len(m.patches))]
+        wU = fv.limited_weights(m, "limitedLinear", self.phi, magSqrU, fv.grad(m, magSqrU, magSqrUb), 1.0)
+        UEqn = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.U0)
+        UEqn += fv.fvm_div(m, self.phi, self.phib, wU, bcU)
+        UEqn -= fv.fvm_laplacian(m, muf, mub, bcU)
+        rhob = self.zg(self.rho)
+        sgr, _ = fv.snGrad(m, self.rho, rhob)
+        bcp = self.bc_p_rgh([np.zeros(p.size) for p in m.patches])
+        sgp, sgpb = fv.snGrad(m, self.p_rgh, bcp.values(m, self.p_rgh))
+        rec = fv.reconstruct(m, (-self.ghf * sgr - sgp) * m.magSf, [-s * p.magSf for s, p in zip(sgpb, m.patches)])
+        for c in range(3):
+            d, s = UEqn.solve_system(c)
+            s = s + m.V * rec[:, c]
+            self.U[c] = self.sol.solve("U", "U" + "xyz"[c], m, d, UEqn.upper, UEqn.lower, s, self.U[c])
+        self.K = 0.5 * (self.U ** 2).sum(axis=0)
+        # ---- YEEqn.H
+        alphaEff = np.full(m.nCells, MU / PR)
+        af, afb = fv.interpolate(m, alphaEff, self.zg(alphaEff))
+        fuel, o2 = self.Y[2], self.Y[0]
+        wFuel = self.rho * np.minimum(fuel, o2 / S_O2) / TAU            # combustion->correct()
+        Qdot = wFuel * HC
+        Yt = np.zeros(m.nCells)
+        for i in range(len(SPECIES)):
+            if i == INERT:
+                continue
+            bc = self.bc_scalar(Y_IN[i], Y_AMB[i])
+            Yb = bc.values(m, self.Y[i])
+            w = fv.limited_weights(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0)
+            E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.Y0[i])
+            E += fv.fvm_div(m, self.phi, self.phib, w, [bc])
+            E -= fv.fvm_laplacian(m, af, afb, [bc])
+            E.add_su(NU[i] * wFuel)                                      # == combustion->R(Yi)
+            d, s = E.solve_system()
+            self.Y[i] = np.maximum(self.sol.solve("Yi", SPECIES[i], m, d, E.upper, E.lower, s, self.Y[i]), 0.0)
+            Yt += self.Y[i]
+        self.Y[INERT] = np.maximum(1.0 - Yt, 0.0)
+        bch = self.bc_scalar(CP * (T_IN - TREF), 0.0, floor_fixed=0.0)
+        hb = bch.values(m, self.h)
+        wh = fv.limited_weights(m, "limitedLinear", self.phi, self.h, fv.grad(m, self.h, hb), 1.0)
+        Ub = [b.values(m, self.U[c]) for c, b in enumerate(bcU)]      # U.correctBoundaryConditions() after the solve
+        Kb = [0.5 * sum(Ub[c][q] ** 2 for c in range(3)) for q in range(len(m.patches))]
+        wK = fv.limited_weights(m, "limitedLinear", self.phi, self.K, fv.grad(m, self.K, Kb), 1.0)
+        Kf = wK * self.K[m.l] + (1.0 - wK) * self.K[m.u]
+        E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.h0)
+        E += fv.fvm_div(m, self.phi, self.phib, wh, [bch])
+        E -= fv.fvm_laplacian(m, af, afb, [bch])
+        expl = rdt * (self.rho * self.K - self.rho0 * self.K0) \
+            + fv.surface_integrate(m, self.phi * Kf, [pb * kb for pb, kb in zip(self.phib, Kb)]) - self.dpdt
+        E.source -= m.V * expl                                           # explicit terms on the LHS
+        E.add_su(Qdot)
+        d, s = E.solve_system()
+        self.h = self.sol.solve("h", "h", m, d, E.upper, E.lower, s, self.h)
+        self.thermo_correct()
+        # ---- pEqn.H, nCorrectors = 2
+        for corr in range(2):
+            self.p_corrector(UEqn, final=(corr == 1))
+        self.rho = self.psi * self.p
+        self.time += self.dt
+
+    def p_corrector(self, UEqn, final):
+        m, rdt = self.m, self.rDeltaT
+        self.rho = self.psi * self.p
+        rAU = 1.0 / UEqn.A()
+        rhorAU = self.rho * rAU
+        rhorAUf, rhorAUfb = fv.interpolate(m, rhorAU, self.zg(rhorAU))
+        HbyA = rAU * UEqn.H(self.U)
+        bcU = self.bc_U()
+        Ub = [b.values(m, self.U[c]) for c, b in enumerate(bcU)]
+        # constrainHbyA: fixed-value patches take U_b, the others the extrapolated cell value
+        HbyAb = [[Ub[c][q] if p.name in ("inlet", "floor") else HbyA[c][p.faceCells] for q, p in enumerate(m.patches)] for c in range(3)]
+        rhob = self.zg(self.rho)
+        sgr, _ = fv.snGrad(m, self.rho, rhob)
+        phig = -rhorAUf * self.ghf * sgr * m.magSf
+        rhoH = self.rho * HbyA
+        flux = sum(fv.interpolate(m, rhoH[c], [rhob[q] * HbyAb[c][q] for q in range(len(m.patches))])[0] * m.Sf[:, c] for c in range(3))
+        fluxb = [sum(rhob[q] * HbyAb[c][q] * p.Sf[:, c] for c in range(3)) for q, p in enumerate(m.patches)]
+        # fvc::ddtCorr(rho, U, phi), Euler; zero on boundaries
+        rhoU0 = self.rho0 * self.U0
+        phiCorr = self.phi0 - sum((m.weights * rhoU0[c][m.l] + (1 - m.weights) * rhoU0[c][m.u]) * m.Sf[:, c] for c in range(3))
+        coeff = 1.0 - np.minimum(np.abs(phiCorr) / (np.abs(self.phi0) + 1e-15), 1.0)
+        phiHbyA = flux + rhorAUf * (coeff * rdt * phiCorr) + phig
+        phiHbyAb = fluxb
+        # constrainPressure on the fixedFluxPressure patches
+        grads = [(phiHbyAb[q] - rhob[q] * sum(p.Sf[:, c] * Ub[c][q] for c in range(3))) / (p.magSf * rhorAUfb[q])
+                 for q, p in enumerate(m.patches)]
+        bcp = self.bc_p_rgh(grads)
+        E = fv.fvm_ddt(m, rdt, self.psi, self.psi0, self.p_rgh0)
+        expl = rdt * (self.psi * self.rho - self.psi0 * self.rho0) * self.gh + rdt * (self.psi - self.psi0) * PREF \
+            + fv.surface_integrate(m, phiHbyA, phiHbyAb)
+        E.source -= m.V * expl
+        E -= fv.fvm_laplacian(m, rhorAUf, rhorAUfb, [bcp])
+        d, s = E.solve_system()
+        self.p_rgh = self.sol.solve("p_rghFinal" if final else "p_rgh", "p_rgh", m, d, E.upper, E.lower, s, self.p_rgh)
+        fl, flb = E.flux(self.p_rgh)
+        self.phi = phiHbyA + fl
+        self.phib = [a + b for a, b in zip(phiHbyAb, flb)]
+        rec = fv.reconstruct(m, (fl + phig) / rhorAUf, [b / r for b, r in zip(flb, rhorAUfb)])
+        self.U = HbyA + rAU * rec.T
+        self.p = self.p_rgh + self.rho * self.gh + PREF
+        self.rho_eqn()
+        self.K = 0.5 * (self.U ** 2).sum(axis=0)
+        self.dpdt = rdt * (self.p - self.p0)
+
+    def fields(self):
+        out = {"rho": self.rho, "p": self.p, "p_rgh": self.p_rgh, "T": self.T, "h": self.h, "phi": self.phi, "K": self.K}
+        for c in range(3):
+            out["U" + "xyz"[c]] = self.U[c]
+        for i, s in enumerate(SPECIES):
+            out[s] = self.Y[i]
+        return out
