@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""bench.py -- PIMPLE outer-iterations/s of the fireFoam hot path on the synthetic hex box.
+
+One "step" = one fireFoam time step with nOuterCorrectors 1 (= one PIMPLE outer iteration,
+solver/fireFoam.C:97-119): rhoEqn, UEqn (3 PBiCGStab+DILU solves), YEEqn (4 species + h), 2 x pEqn
+(PCG+DIC, relTol 0.01 then 0), assembly included, on the synthetic buoyant-plume box of SURVEY 8(d)
+(ffm_plume_* in include/ffm.h).  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1            # 400^3 = 64 M cells on one MI355X
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus `roofline` (the pEqn PCG SpMV
+kernel against the 8 TB/s HBM peak, algorithmic bytes 24 N + 16 F) and `cpu_baseline` (the oracle
+port on one host core, bounded sample, scaled by cell count).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=400, help="cells per box edge (400 -> 64 M cells, BASELINE.json config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=96)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from ffm_import import ffm
+    ctx = ffm.Context(local)
+    n = args.n
+    if world > 1:
+        raise SystemExit("bench.py: the decomposed (N>1) outer iteration is not wired into the plume driver yet; "
+                         "the decomposed linear solvers are (tests/test_decomposed_*.py)")
+    t0 = time.time()
+    case = ffm.Plume(ctx, (n, n, n), h=0.05, deltaT=1e-3)
+    setup_s = time.time() - t0
+    N, F = case.nCells, case.nFaces
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        case.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        case.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    solves = case.solves()
+    pIters = [pf["nIterations"] for nm, pf in solves if nm == "p_rgh"]
+
+    # ---- roofline: the PCG SpMV kernel (lduMatrix::Amul) on the p_rgh matrix left by the last corrector,
+    # HIP events on the library's stream (ffm_bench_spmv), algorithmic bytes 24 N + 16 F
+    import ctypes as C
+    x = ctx.to_device(ffm.hexmesh.hash_u(0xF4, __import__("numpy").arange(N)))
+    y = ctx.empty(N)
+    ms = C.c_double()
+    L = ffm.lib()
+    rc = L.ffm_bench_spmv(case.ldu_handle(), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 20, C.byref(ms))
+    if rc:
+        raise SystemExit("ffm_bench_spmv failed: %s" % L.ffm_last_error().decode())
+    alg_bytes = 24 * N + 16 * F
+    achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_rows<0,*> (lduMatrix::Amul, symmetric p_rgh matrix)", "achieved": round(achieved, 1),
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(ms.value, 5)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import plume as oplume       # test infrastructure, used here only as the timed CPU baseline
+        cn = args.cpu_n
+        ref = oplume.Plume((cn, cn, cn))
+        ref.step()
+        t1 = time.perf_counter()
+        nst = 2
+        for _ in range(nst):
+            ref.step()
+        cdt = (time.perf_counter() - t1) / nst
+        cell_steps = cn ** 3 / cdt
+        cpu = {"value": round(cell_steps / N, 6), "unit": "outer-iterations/s", "cores": 1, "kind": "port",
+               "sample": "oracle/plume.py (numpy assembly + C solvers, 1 core): %d^3 cells, %d steps, %.2f s/step = %.3g cell-steps/s, "
+                         "scaled by cell count to %d cells" % (cn, nst, cdt, cell_steps, N)}
+
+    if rank == 0:
+        out = {
+            "metric": "PIMPLE outer-iterations/sec on 64M-cell hex mesh; pEqn SpMV GB/s vs HBM peak",
+            "value": round(args.steps / dt, 4), "unit": "outer-iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic %d^3 hex box (%d cells), buoyant plume + 5-species EDC-shaped source, "
+                                   "PIMPLE 1/2/0: rhoEqn + UEqn + YEEqn(4 Yi + h) + 2 pEqn per step" % (n, N),
+                       "cells": N, "faces": F, "deltaT": 1e-3, "parallelism": "1 GPU" if world == 1 else "%d-way block decomposition" % world,
+                       "p_rgh_iterations_last_step": pIters, "setup_s": round(setup_s, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    case.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
