@@ -36,6 +36,8 @@ class Perf(C.Structure):
 
 
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+HOST_EXCHANGE2_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                C.POINTER(C.c_double), C.POINTER(C.c_double))
 HOST_EXCHANGE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double))
 
@@ -122,6 +124,7 @@ def lib():
         "ffm_plume_create": ([vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(vp)], C.c_int),
         "ffm_plume_destroy": ([vp], C.c_int),
         "ffm_plume_step": ([vp], C.c_int),
+        "ffm_plume_set_tight": ([vp, C.c_int], C.c_int),
         "ffm_plume_ncells": ([vp], C.c_int),
         "ffm_plume_nfaces": ([vp], C.c_int),
         "ffm_plume_get_field": ([vp, C.c_char_p, hp], C.c_int),
@@ -131,6 +134,13 @@ def lib():
         "ffm_comm_unique_id": ([vp], C.c_int),
         "ffm_comm_init": ([vp, C.c_int, C.c_int, vp], C.c_int),
         "ffm_comm_init_host": ([vp, C.c_int, C.c_int, vp, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN], C.c_int),
+        "ffm_comm_set_host_exchange2": ([vp, HOST_EXCHANGE2_FN], C.c_int),
+        "ffm_plume_create_block": ([vp, C.c_int, C.c_int, C.c_int, ip, ip, ip, C.c_double, C.c_double, C.POINTER(vp)], C.c_int),
+        "ffm_ldu_create_ext": ([vp, C.c_int, C.c_int, C.c_int, ip, ip, C.POINTER(vp)], C.c_int),
+        "ffm_renumber_levels_ext": ([C.c_int, C.c_int, C.c_int, ip, ip, ip, ip], C.c_int),
+        "ffm_ldu_set_ghost_exchange": ([vp, C.c_int, ip, ip, ip, ip], C.c_int),
+        "ffm_halo_refresh_d": ([vp, dp], C.c_int),
+        "ffm_ldu_nowned": ([vp], C.c_int),
         "ffm_comm_rank": ([vp], C.c_int),
         "ffm_comm_size": ([vp], C.c_int),
     }
@@ -222,8 +232,22 @@ class Context:
             tot = sum(sizes)
             exchange(sizes, ranks, offs, np.ctypeslib.as_array(send, shape=(tot,)),
                      np.ctypeslib.as_array(recv, shape=(tot,)))
-        self._cb = (HOST_ALLREDUCE_FN(_ar), HOST_EXCHANGE_FN(_ex))
+        def _ex2(user, nN, rank_, soff, roff, send, recv):
+            ranks = [rank_[i] for i in range(nN)]
+            so = [soff[i] for i in range(nN + 1)]
+            ro = [roff[i] for i in range(nN + 1)]
+            sizes_s = [so[i + 1] - so[i] for i in range(nN)]
+            sb = np.ctypeslib.as_array(send, shape=(max(so[-1], 1),))
+            rb = np.ctypeslib.as_array(recv, shape=(max(ro[-1], 1),))
+            # express the variable-count exchange through the same python callback, one neighbour at a time
+            for q in range(nN):
+                tmp_s = np.ascontiguousarray(sb[so[q]:so[q + 1]])
+                tmp_r = np.empty(ro[q + 1] - ro[q])
+                exchange([len(tmp_s)], [ranks[q]], [0], tmp_s, tmp_r) if len(tmp_s) == len(tmp_r) else exchange_var(ranks[q], tmp_s, tmp_r)
+                rb[ro[q]:ro[q + 1]] = tmp_r
+        self._cb = (HOST_ALLREDUCE_FN(_ar), HOST_EXCHANGE_FN(_ex), HOST_EXCHANGE2_FN(_ex2))
         _check(lib().ffm_comm_init_host(self.h, rank, nRanks, None, self._cb[0], self._cb[1]), "ffm_comm_init_host")
+        _check(lib().ffm_comm_set_host_exchange2(self.h, self._cb[2]), "ffm_comm_set_host_exchange2")
 
     def _reduce(self, fn, *tensors):
         self._ready()
@@ -390,10 +414,17 @@ class lduMatrix:
 class Plume:
     """The synthetic buoyant-plume case (ffm_plume_*): one fireFoam time step per step()."""
 
-    def __init__(self, ctx, n, h=0.05, deltaT=1e-3):
+    def __init__(self, ctx, n, h=0.05, deltaT=1e-3, lo=None, hi=None, nbrRank=None):
+        """Whole box (default) or one rank's block [lo,hi) with neighbour ranks (-x,+x,-y,+y,-z,+z; -1 = boundary)."""
         self.ctx = ctx
         hnd = C.c_void_p()
-        _check(lib().ffm_plume_create(ctx.h, int(n[0]), int(n[1]), int(n[2]), float(h), float(deltaT), C.byref(hnd)), "ffm_plume_create")
+        if lo is None:
+            _check(lib().ffm_plume_create(ctx.h, int(n[0]), int(n[1]), int(n[2]), float(h), float(deltaT), C.byref(hnd)), "ffm_plume_create")
+        else:
+            lo_ = (C.c_int * 3)(*[int(v) for v in lo]); hi_ = (C.c_int * 3)(*[int(v) for v in hi])
+            nb_ = (C.c_int * 6)(*[int(v) for v in nbrRank])
+            _check(lib().ffm_plume_create_block(ctx.h, int(n[0]), int(n[1]), int(n[2]), lo_, hi_, nb_, float(h), float(deltaT),
+                                                C.byref(hnd)), "ffm_plume_create_block")
         self.h = hnd
         self.nCells = lib().ffm_plume_ncells(hnd)
         self.nFaces = lib().ffm_plume_nfaces(hnd)
@@ -402,6 +433,9 @@ class Plume:
         if getattr(self, "h", None):
             lib().ffm_plume_destroy(self.h)
             self.h = None
+
+    def set_tight(self, on=True):
+        _check(lib().ffm_plume_set_tight(self.h, 1 if on else 0), "ffm_plume_set_tight")
 
     def step(self):
         _check(lib().ffm_plume_step(self.h), "ffm_plume_step")

@@ -233,3 +233,69 @@ int ffm_halo_update(ffm_ldu *A, const double *x, double *y, const double *coeffs
     FFM_TRY(ffm_halo_exchange(A, x));
     return ffm_halo_apply(A, y, coeffs, A->haloRecv, sign);
 }
+
+// ------------------------------------------------------------ ghost-cell halo ---
+// Native decomposed path: the rank's mesh carries one layer of ghost cells (copies of the neighbour
+// ranks' boundary cells) appended after its owned cells, and the cut faces are ordinary faces
+// between an owned and a ghost cell.  Every FV kernel and Amul then run unchanged; what this
+// section adds is the refresh of the ghost entries of a cell field: one pack kernel gathers the
+// owned cells each neighbour needs, one ncclGroup of Send/Recv moves them, and the receive lands
+// directly in the (contiguous) ghost range of the field -- no unpack kernel.
+extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRank, const int *sendCount,
+                                          const int *sendCells, const int *recvCount)
+{
+    if (!A || nNbr < 0 || (nNbr && (!nbrRank || !sendCount || !sendCells || !recvCount))) return FFM_ERR_ARG;
+    if (!A->identity) { ffm_set_error("ghost exchange needs the library's cell order"); return FFM_ERR_UNSUPPORTED; }
+    hipStreamSynchronize(A->ctx->stream);
+    hipFree(A->ghSendCells); hipFree(A->ghSendBuf); A->ghSendCells = nullptr; A->ghSendBuf = nullptr;
+    if (A->ghSendBuf_h) { hipHostFree(A->ghSendBuf_h); A->ghSendBuf_h = nullptr; }
+    if (A->ghRecvBuf_h) { hipHostFree(A->ghRecvBuf_h); A->ghRecvBuf_h = nullptr; }
+    A->ghNbrRank.assign(nbrRank, nbrRank + nNbr);
+    A->ghSendOff.assign(nNbr + 1, 0); A->ghRecvOff.assign(nNbr + 1, 0);
+    for (int q = 0; q < nNbr; q++) { A->ghSendOff[q + 1] = A->ghSendOff[q] + sendCount[q]; A->ghRecvOff[q + 1] = A->ghRecvOff[q] + recvCount[q]; }
+    if (A->ghRecvOff[nNbr] != A->nCells - A->nOwned) { ffm_set_error("ghost exchange: receive counts (%d) != ghost cells (%d)", A->ghRecvOff[nNbr], A->nCells - A->nOwned); A->ghNbrRank.clear(); return FFM_ERR_ARG; }
+    const int nSend = A->ghSendOff[nNbr];
+    for (int i = 0; i < nSend; i++) if (sendCells[i] < 0 || sendCells[i] >= A->nOwned) { ffm_set_error("ghost exchange: send cell out of range"); A->ghNbrRank.clear(); return FFM_ERR_ARG; }
+    FFM_HIP(hipMalloc((void **)&A->ghSendCells, sizeof(int) * std::max(nSend, 1)));
+    FFM_HIP(hipMalloc((void **)&A->ghSendBuf, sizeof(double) * std::max(nSend, 1)));
+    FFM_HIP(hipMemcpy(A->ghSendCells, sendCells, sizeof(int) * nSend, hipMemcpyHostToDevice));
+    FFM_HIP(hipHostMalloc((void **)&A->ghSendBuf_h, sizeof(double) * std::max(nSend, 1), hipHostMallocDefault));
+    FFM_HIP(hipHostMalloc((void **)&A->ghRecvBuf_h, sizeof(double) * std::max(A->ghRecvOff[nNbr], 1), hipHostMallocDefault));
+    return FFM_OK;
+}
+
+int ffm_ghost_exchange(ffm_ldu *A, double *x)
+{
+    ffm_ctx *c = A->ctx;
+    const int nNbr = (int)A->ghNbrRank.size();
+    if (!nNbr) return FFM_OK;
+    const int nSend = A->ghSendOff[nNbr], nRecv = A->ghRecvOff[nNbr];
+    if (nSend) hipLaunchKernelGGL(k_halo_pack, dim3(std::max(1, std::min(ffm_grid(nSend, 256), 1024))), dim3(256), 0, c->stream,
+                                  nSend, A->ghSendCells, x, A->ghSendBuf);
+    FFM_HIP(hipGetLastError());
+    double *ghost = x + A->nOwned;
+    if (c->comm) {
+        FFM_NCCL(ncclGroupStart());
+        for (int q = 0; q < nNbr; q++) {
+            const int ns = A->ghSendOff[q + 1] - A->ghSendOff[q], nr = A->ghRecvOff[q + 1] - A->ghRecvOff[q];
+            if (ns) FFM_NCCL(ncclSend(A->ghSendBuf + A->ghSendOff[q], ns, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
+            if (nr) FFM_NCCL(ncclRecv(ghost + A->ghRecvOff[q], nr, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
+        }
+        FFM_NCCL(ncclGroupEnd());
+        return FFM_OK;
+    }
+    if (!c->hostExchange2) { ffm_set_error("ghost cells set but no communicator attached"); return FFM_ERR_COMM; }
+    FFM_HIP(hipMemcpyAsync(A->ghSendBuf_h, A->ghSendBuf, sizeof(double) * nSend, hipMemcpyDeviceToHost, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    c->hostExchange2(c->hostUser, nNbr, A->ghNbrRank.data(), A->ghSendOff.data(), A->ghRecvOff.data(), A->ghSendBuf_h, A->ghRecvBuf_h);
+    FFM_HIP(hipMemcpyAsync(ghost, A->ghRecvBuf_h, sizeof(double) * nRecv, hipMemcpyHostToDevice, c->stream));
+    return FFM_OK;
+}
+
+extern "C" int ffm_halo_refresh_d(ffm_ldu *A, double *field_d)
+{
+    if (!A || !field_d) return FFM_ERR_ARG;
+    return ffm_ghost_exchange(A, field_d);
+}
+
+extern "C" int ffm_comm_set_host_exchange2(ffm_ctx *c, ffm_host_exchange2_fn fn) { if (!c) return FFM_ERR_ARG; c->hostExchange2 = fn; return FFM_OK; }

@@ -72,7 +72,7 @@ __device__ __forceinline__ double block_max(double v, double *sm)
 // ------------------------------------------------------ sliced owner-ELL view ---
 // Passed by value to every kernel that walks matrix rows (layout: ffm_internal.hpp).
 struct LduView {
-    int N;
+    int N;                      // number of ROWS (owned cells); column indices may reach the ghost cells beyond
     const int *upOff, *loOff;   // [nSlices+1]
     const int *upNbr;           // [upTotal]
     const int *loEnt;           // [loTotal]
@@ -111,7 +111,8 @@ __device__ __forceinline__ void load_lower(const LduView &v, int c, RowEnt<W> &R
     }
 }
 
-template <int W>
+// MASK_GHOST: drop upper neighbours that are ghost cells (index >= v.N): block-Jacobi sweeps
+template <int W, bool MASK_GHOST = false>
 __device__ __forceinline__ void load_upper(const LduView &v, int c, RowEnt<W> &R)
 {
     const int sl = c >> 6, lane = c & 63;
@@ -120,7 +121,7 @@ __device__ __forceinline__ void load_upper(const LduView &v, int c, RowEnt<W> &R
     for (int s = 0; s < W; s++) {
         const int idx = ub + s * 64 + lane;
         const int n = (s < uw) ? v.upNbr[idx] : -1;
-        R.on[s] = n >= 0;
+        R.on[s] = n >= 0 && (!MASK_GHOST || n < v.N);
         R.nb[s] = R.on[s] ? n : c;
         R.f[s] = R.on[s] ? idx : 0;
     }

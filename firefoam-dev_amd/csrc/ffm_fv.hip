@@ -337,12 +337,12 @@ __global__ void k_grad(MeshView q, const double *__restrict__ vf, const double *
 
 // fvc::reconstruct(ssf) = inv(surfaceSum(Sf (x) Sf/magSf)) & surfaceSum((Sf/magSf) ssf)
 template <int W>
-__global__ void k_reconstruct(MeshView q, const double *__restrict__ invT, const double *__restrict__ bMagSf,
+__global__ void k_reconstruct(MeshView q, long invStride, const double *__restrict__ invT, const double *__restrict__ bMagSf,
                               const double *__restrict__ ssf, const double *__restrict__ ssb, double *__restrict__ ox,
                               double *__restrict__ oy, double *__restrict__ oz)
 {
     GRID_STRIDE(ci, q.v.N) {
-        const int c = (int)ci; const long N = q.v.N;
+        const int c = (int)ci; const long N = invStride;      // invT is [6][nCells] (owned + ghost)
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         double vx = 0, vy = 0, vz = 0;
 #pragma unroll
@@ -531,7 +531,7 @@ extern "C" int ffm_fvc_surface_sum(ffm_mesh *m, const double *ssf, const double 
 extern "C" int ffm_fvc_grad(ffm_mesh *m, const double *vf, const double *vb, double *gx, double *gy, double *gz)
 { CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_grad<W>, m->N, mview(m), vf, vb, gx, gy, gz)); DONE(); }
 extern "C" int ffm_fvc_reconstruct(ffm_mesh *m, const double *ssf, const double *ssb, double *ox, double *oy, double *oz)
-{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_reconstruct<W>, m->N, mview(m), m->invT, m->bMagSf, ssf, ssb, ox, oy, oz)); DONE(); }
+{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_reconstruct<W>, m->N, mview(m), (long)m->N, m->invT, m->bMagSf, ssf, ssb, ox, oy, oz)); DONE(); }
 extern "C" int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double hi, const double *phi_f,
                                       const double *vf, const double *gx, const double *gy, const double *gz, double *out_w)
 {

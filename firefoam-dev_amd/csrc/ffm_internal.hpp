@@ -61,6 +61,7 @@ struct ffm_ctx {
     void *hostUser = nullptr;
     ffm_host_allreduce_fn hostAllreduce = nullptr;
     ffm_host_exchange_fn hostExchange = nullptr;
+    ffm_host_exchange2_fn hostExchange2 = nullptr;
     int cuCount = 256;
 };
 
@@ -78,7 +79,8 @@ struct ffm_iface {
 
 struct ffm_ldu {
     ffm_ctx *ctx = nullptr;
-    int nCells = 0, nFaces = 0;
+    int nCells = 0, nFaces = 0;        // nCells = owned + ghost cells (array length of every cell field)
+    int nOwned = 0;                    // rows of this rank; ghost cells [nOwned, nCells) are copies of neighbour-rank cells
     long globalCells = 0;
     bool identity = true;           // caller numbering == internal numbering
     bool symmetric = true;
@@ -140,6 +142,12 @@ struct ffm_ldu {
     int nIfCells = 0;
     int *ifCell = nullptr, *ifCellStart = nullptr, *ifItem = nullptr;
 
+    // ghost-cell halo plan (native decomposed path): for neighbour q, send x[ghSendCells[ghSendOff[q]..]] and receive
+    // straight into x[nOwned + ghRecvOff[q] ..]
+    std::vector<int> ghNbrRank, ghSendOff, ghRecvOff;   // offsets have nNbr+1 entries
+    int *ghSendCells = nullptr;
+    double *ghSendBuf = nullptr, *ghSendBuf_h = nullptr, *ghRecvBuf_h = nullptr;
+
     // cached hipGraphs of level-scheduled sweeps
     std::map<SweepGraphKey, hipGraphExec_t> graphs;
 };
@@ -162,7 +170,8 @@ void ffm_comm_finalize_i(ffm_ctx *ctx);
 int ffm_precond_setup_i(ffm_ldu *A, int precond);
 int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
 int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b);
-int ffm_halo_exchange(ffm_ldu *A, const double *x);          // pack x[faceCells], exchange into haloRecv
+int ffm_halo_exchange(ffm_ldu *A, const double *x);
+int ffm_ghost_exchange(ffm_ldu *A, double *x);                 // refresh x[nOwned..nCells) from the neighbour ranks          // pack x[faceCells], exchange into haloRecv
 int ffm_read_scalars(ffm_ctx *ctx);  // scal_d -> scal_h, synchronises the stream
 
 // reductions into device scalar slots (local partial sums; caller all-reduces)

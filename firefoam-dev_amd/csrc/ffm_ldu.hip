@@ -45,7 +45,10 @@ struct LduAnalysis {
     bool identity = true, bwdContig = true;
 };
 
-static int analyse(int N, int F, const int *l, const int *u, bool renumber, bool sortByNewNeighbour, LduAnalysis &a)
+// nOwn < N: cells [nOwn, N) are ghost cells (copies of neighbour-rank cells).  They own no faces, stay at the end of the
+// numbering in their given order, take no part in the level structure, and faces towards them are ignored by the
+// backward levels (block-Jacobi sweeps).
+static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renumber, bool sortByNewNeighbour, LduAnalysis &a)
 {
     for (int f = 0; f < F; f++) {
         if (l[f] < 0 || u[f] >= N || l[f] >= u[f]) {
@@ -56,30 +59,32 @@ static int analyse(int N, int F, const int *l, const int *u, bool renumber, bool
             ffm_set_error("LDU addressing: faces not sorted by owner at face %d", f);
             return FFM_ERR_ADDR;
         }
+        if (l[f] >= nOwn) { ffm_set_error("LDU addressing: face %d is owned by a ghost cell", f); return FFM_ERR_ADDR; }
     }
     // forward levels
     std::vector<int> lev(N, 0);
-    for (int f = 0; f < F; f++) lev[u[f]] = std::max(lev[u[f]], lev[l[f]] + 1);
+    for (int f = 0; f < F; f++) if (u[f] < nOwn) lev[u[f]] = std::max(lev[u[f]], lev[l[f]] + 1);
     int nLev = 0;
-    for (int c = 0; c < N; c++) nLev = std::max(nLev, lev[c] + 1);
-    if (N == 0) nLev = 0;
+    for (int c = 0; c < nOwn; c++) nLev = std::max(nLev, lev[c] + 1);
+    if (nOwn == 0) nLev = 0;
     a.newToOldCell.resize(N); a.oldToNewCell.resize(N);
     if (renumber) {
         std::vector<int> start(nLev + 1, 0);
-        for (int c = 0; c < N; c++) start[lev[c] + 1]++;
+        for (int c = 0; c < nOwn; c++) start[lev[c] + 1]++;
         for (int i = 0; i < nLev; i++) start[i + 1] += start[i];
         a.fwdLevelStart = start;
         std::vector<int> pos(start.begin(), start.end() - (nLev ? 1 : 0));
         if (!nLev) pos.clear();
-        for (int c = 0; c < N; c++) { int p = pos[lev[c]]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
+        for (int c = 0; c < nOwn; c++) { int p = pos[lev[c]]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
+        for (int c = nOwn; c < N; c++) { a.newToOldCell[c] = c; a.oldToNewCell[c] = c; }
     } else {
         // caller insists on its numbering: only legal if it is level-major already
         std::iota(a.newToOldCell.begin(), a.newToOldCell.end(), 0);
         a.oldToNewCell = a.newToOldCell;
         a.fwdLevelStart.assign(nLev + 1, 0);
-        for (int c = 0; c < N; c++) a.fwdLevelStart[lev[c] + 1]++;
+        for (int c = 0; c < nOwn; c++) a.fwdLevelStart[lev[c] + 1]++;
         for (int i = 0; i < nLev; i++) a.fwdLevelStart[i + 1] += a.fwdLevelStart[i];
-        for (int c = 1; c < N; c++) if (lev[c] < lev[c - 1]) { ffm_set_error("numbering is not level-major"); return FFM_ERR_ARG; }
+        for (int c = 1; c < nOwn; c++) if (lev[c] < lev[c - 1]) { ffm_set_error("numbering is not level-major"); return FFM_ERR_ARG; }
     }
     a.identity = true;
     for (int c = 0; c < N; c++) if (a.newToOldCell[c] != c) { a.identity = false; break; }
@@ -109,18 +114,18 @@ static int analyse(int N, int F, const int *l, const int *u, bool renumber, bool
     }
     // backward levels (new numbering)
     std::vector<int> bl(N, 0);
-    for (int f = F - 1; f >= 0; f--) bl[a.l[f]] = std::max(bl[a.l[f]], bl[a.u[f]] + 1);
+    for (int f = F - 1; f >= 0; f--) if (a.u[f] < nOwn) bl[a.l[f]] = std::max(bl[a.l[f]], bl[a.u[f]] + 1);
     int nB = 0;
-    for (int c = 0; c < N; c++) nB = std::max(nB, bl[c] + 1);
-    if (N == 0) nB = 0;
+    for (int c = 0; c < nOwn; c++) nB = std::max(nB, bl[c] + 1);
+    if (nOwn == 0) nB = 0;
     a.bwdLevelStart.assign(nB + 1, 0);
-    for (int c = 0; c < N; c++) a.bwdLevelStart[bl[c] + 1]++;
+    for (int c = 0; c < nOwn; c++) a.bwdLevelStart[bl[c] + 1]++;
     for (int i = 0; i < nB; i++) a.bwdLevelStart[i + 1] += a.bwdLevelStart[i];
-    a.bwdOrder.resize(N);
+    a.bwdOrder.resize(nOwn);
     {
         std::vector<int> pos(a.bwdLevelStart.begin(), a.bwdLevelStart.end() - (nB ? 1 : 0));
         if (!nB) pos.clear();
-        for (int c = 0; c < N; c++) a.bwdOrder[pos[bl[c]]++] = c;
+        for (int c = 0; c < nOwn; c++) a.bwdOrder[pos[bl[c]]++] = c;
     }
     a.bwdContig = true;
     for (int b = 0; b < nB && a.bwdContig; b++) {
@@ -130,12 +135,23 @@ static int analyse(int N, int F, const int *l, const int *u, bool renumber, bool
     return FFM_OK;
 }
 
+extern "C" int ffm_renumber_levels_ext(int nOwned, int nGhost, int nFaces, const int *l, const int *u,
+                                       int *newToOldCell, int *newToOldFace)
+{
+    if (nOwned < 0 || nGhost < 0 || nFaces < 0 || (nFaces && (!l || !u))) return FFM_ERR_ARG;
+    LduAnalysis a;
+    FFM_TRY(analyse(nOwned + nGhost, nOwned, nFaces, l, u, true, true, a));
+    if (newToOldCell) std::copy(a.newToOldCell.begin(), a.newToOldCell.end(), newToOldCell);
+    if (newToOldFace) std::copy(a.newToOldFace.begin(), a.newToOldFace.end(), newToOldFace);
+    return FFM_OK;
+}
+
 extern "C" int ffm_renumber_levels(int nCells, int nFaces, const int *l, const int *u,
                                    int *newToOldCell, int *newToOldFace)
 {
     if (nCells < 0 || nFaces < 0 || (nFaces && (!l || !u))) return FFM_ERR_ARG;
     LduAnalysis a;
-    FFM_TRY(analyse(nCells, nFaces, l, u, true, true, a));
+    FFM_TRY(analyse(nCells, nCells, nFaces, l, u, true, true, a));
     if (newToOldCell) std::copy(a.newToOldCell.begin(), a.newToOldCell.end(), newToOldCell);
     if (newToOldFace) std::copy(a.newToOldFace.begin(), a.newToOldFace.end(), newToOldFace);
     return FFM_OK;
@@ -151,28 +167,32 @@ static int upload(ffm_ctx *c, T **dst, const std::vector<T> &v, size_t minCount 
 }
 
 extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const int *u, ffm_ldu **out)
+{ return ffm_ldu_create_ext(ctx, N, 0, F, l, u, out); }
+
+extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int *l, const int *u, ffm_ldu **out)
 {
-    if (!ctx || !out || N < 0 || F < 0 || (F && (!l || !u))) { ffm_set_error("ffm_ldu_create: bad argument"); return FFM_ERR_ARG; }
+    const int N = nOwn + nGhost;
+    if (!ctx || !out || nOwn < 0 || nGhost < 0 || F < 0 || (F && (!l || !u))) { ffm_set_error("ffm_ldu_create: bad argument"); return FFM_ERR_ARG; }
     FFM_HIP(hipSetDevice(ctx->device));
     LduAnalysis a;
-    FFM_TRY(analyse(N, F, l, u, true, false, a));
+    FFM_TRY(analyse(N, nOwn, F, l, u, true, false, a));
     ffm_ldu *A = new ffm_ldu();
-    A->ctx = ctx; A->nCells = N; A->nFaces = F; A->globalCells = N;
+    A->ctx = ctx; A->nCells = N; A->nOwned = nOwn; A->nFaces = F; A->globalCells = nOwn;
     A->identity = a.identity; A->bwdContig = a.bwdContig;
     A->nLevels = (int)a.fwdLevelStart.size() - 1; if (A->nLevels < 0) A->nLevels = 0;
     A->nBwdLevels = (int)a.bwdLevelStart.size() - 1; if (A->nBwdLevels < 0) A->nBwdLevels = 0;
     A->h_fwdLevelStart = a.fwdLevelStart; A->h_bwdLevelStart = a.bwdLevelStart;
     A->h_newToOldCell = a.newToOldCell; A->h_newToOldFace = a.newToOldFace;
     // derived addressing: sliced owner-ELL
-    const int nSl = (N + 63) / 64;
+    const int nSl = (nOwn + 63) / 64;                 // rows exist for owned cells only
     A->nSlices = nSl;
     std::vector<int> upCnt(N, 0), loCnt(N, 0);
-    for (int f = 0; f < F; f++) { upCnt[a.l[f]]++; loCnt[a.u[f]]++; }
+    for (int f = 0; f < F; f++) { upCnt[a.l[f]]++; if (a.u[f] < nOwn) loCnt[a.u[f]]++; }
     std::vector<int> upOff(nSl + 1, 0), loOff(nSl + 1, 0);
     int uniform = -2, uniformLo = -2, maxW = 0;
     for (int sl = 0; sl < nSl; sl++) {
         int wu = 0, wl = 0;
-        for (int c = sl * 64; c < std::min(N, sl * 64 + 64); c++) { wu = std::max(wu, upCnt[c]); wl = std::max(wl, loCnt[c]); }
+        for (int c = sl * 64; c < std::min(nOwn, sl * 64 + 64); c++) { wu = std::max(wu, upCnt[c]); wl = std::max(wl, loCnt[c]); }
         if (wu > 16 || wl > 16) { ffm_set_error("a cell owns %d faces (>16): not supported by the packed layout", wu); delete A; return FFM_ERR_UNSUPPORTED; }
         upOff[sl + 1] = upOff[sl] + wu * 64; loOff[sl + 1] = loOff[sl] + wl * 64;
         uniform = (uniform == -2) ? wu : (uniform == wu ? wu : -1);
@@ -204,6 +224,7 @@ extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const in
         std::vector<int> fill(N, 0);
         for (int of = 0; of < F; of++) {
             const int f = oldToNewFace[of], c = a.u[f];
+            if (c >= nOwn) continue;                      // ghost cells have no rows
             const int q = loOff[c >> 6] + fill[c]++ * 64 + (c & 63);
             loEnt[q] = (a.l[f] << 4) | slotOfFace[f];
         }
@@ -247,6 +268,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     for (int i = 0; i < 3; i++) hipFree(A->permIn[i]);
     hipFree(A->upOff); hipFree(A->loOff); hipFree(A->upNbr); hipFree(A->loEnt); hipFree(A->faceSrc);
     hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative);
+    hipFree(A->ghSendCells); hipFree(A->ghSendBuf); if (A->ghSendBuf_h) hipHostFree(A->ghSendBuf_h); if (A->ghRecvBuf_h) hipHostFree(A->ghRecvBuf_h);
     hipFree(A->diag); hipFree(A->upper); hipFree(A->lowerBuf); hipFree(A->rD);
     hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);
     hipFree(A->ifCell); hipFree(A->ifCellStart); hipFree(A->ifItem);
@@ -255,6 +277,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
 }
 
 extern "C" int ffm_ldu_ncells(const ffm_ldu *A) { return A ? A->nCells : FFM_ERR_ARG; }
+extern "C" int ffm_ldu_nowned(const ffm_ldu *A) { return A ? A->nOwned : FFM_ERR_ARG; }
 extern "C" int ffm_ldu_nfaces(const ffm_ldu *A) { return A ? A->nFaces : FFM_ERR_ARG; }
 extern "C" int ffm_ldu_nlevels(const ffm_ldu *A) { return A ? A->nLevels : FFM_ERR_ARG; }
 extern "C" int ffm_ldu_is_native_order(const ffm_ldu *A) { return A ? (A->identity ? 1 : 0) : FFM_ERR_ARG; }
@@ -271,7 +294,7 @@ extern "C" int ffm_ldu_get_face_map(const ffm_ldu *A, int *callerToNative)
     std::copy(A->h_callerToNative.begin(), A->h_callerToNative.end(), callerToNative);
     return FFM_OK;
 }
-extern "C" int ffm_ldu_set_global_cells(ffm_ldu *A, long g) { if (!A || g < A->nCells) return FFM_ERR_ARG; A->globalCells = g; return FFM_OK; }
+extern "C" int ffm_ldu_set_global_cells(ffm_ldu *A, long g) { if (!A || g < A->nOwned) return FFM_ERR_ARG; A->globalCells = g; return FFM_OK; }
 
 int ffm_ldu_work(ffm_ldu *A, int idx, double **out)
 {
@@ -382,7 +405,7 @@ extern "C" int ffm_ldu_set_coeffs_native_d(ffm_ldu *A, const double *diag_d, con
 
 LduView ffm_view(const ffm_ldu *A)
 {
-    LduView v; v.N = A->nCells; v.upOff = A->upOff; v.loOff = A->loOff; v.upNbr = A->upNbr; v.loEnt = A->loEnt;
+    LduView v; v.N = A->nOwned; v.upOff = A->upOff; v.loOff = A->loOff; v.upNbr = A->upNbr; v.loEnt = A->loEnt;
     v.upW = A->upWidthUniform; v.loW = A->loWidthUniform;
     return v;
 }
@@ -447,10 +470,11 @@ __global__ __launch_bounds__(1024) void k_sum_partials(int n, const double *__re
     if (threadIdx.x == 0) scal[slot] = r;
 }
 
-static inline int rows_grid(const ffm_ldu *A) { return stream_grid(A->nCells); }
+static inline int rows_grid(const ffm_ldu *A) { return stream_grid(A->nOwned); }
 
 int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
 {
+    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));   // refresh ghost columns
     const double *up = transpose ? A->lower : A->upper, *lo = transpose ? A->upper : A->lower;
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
                                                A->diag, up, lo, x, (const double *)nullptr, y, (double *)nullptr));
@@ -461,9 +485,10 @@ int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
 
 int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
 {
+    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));
     if (!A->ifaces.empty()) {  // the halo term changes y after the row kernel: separate dot
         FFM_TRY(ffm_k_spmv(A, x, y, false));
-        return ffm_k_dot(A->ctx, y, x, A->nCells, slot);
+        return ffm_k_dot(A->ctx, y, x, A->nOwned, slot);
     }
     const int g = rows_grid(A);
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, true, W>), dim3(g), dim3(256), 0, A->ctx->stream, ffm_view(A), A->diag,
@@ -475,6 +500,7 @@ int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
 
 int ffm_k_residual(ffm_ldu *A, const double *x, const double *b, double *r)
 {
+    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<1, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
                                                A->diag, A->upper, A->lower, x, b, r, (double *)nullptr));
     FFM_HIP(hipGetLastError());

@@ -63,7 +63,7 @@ struct SolveLog { char name[16]; ffm_perf perf; };
 
 struct ffm_plume {
     ffm_ctx *ctx = nullptr; ffm_ldu *A = nullptr; ffm_mesh *mesh = nullptr;
-    int nx = 0, ny = 0, nz = 0, N = 0, F = 0, nNat = 0, B = 0;
+    int nx = 0, ny = 0, nz = 0, N = 0, nOwn = 0, F = 0, nNat = 0, B = 0;   // N = owned + ghost cells
     double h = 0.05, dt = 1e-3, rdt = 1e3, time = 0.0;
     std::vector<int> newToOld;             // library cell order -> natural blockMesh cell id
     std::vector<double *> pool;            // every device buffer, for destroy
@@ -80,6 +80,7 @@ struct ffm_plume {
     // UEqn kept for pEqn (A, H)
     double *Udiag, *Uupper, *Ulower, *Usrc[3], *Uic[3], *Ubc[3];
     std::vector<SolveLog> log;
+    bool tight = false;                    // tests: every solve to 1e-13 / relTol 0 (removes the stopping-rule noise)
 };
 
 #define PL_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ffm_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e_)); return FFM_ERR_HIP; } } while (0)
@@ -104,6 +105,9 @@ template <class Fn> static void forN(ffm_plume *P, long n, Fn f)
 }
 static void dcopy(ffm_plume *P, double *d, const double *s, long n)
 { hipMemcpyAsync(d, s, sizeof(double) * n, hipMemcpyDeviceToDevice, P->ctx->stream); }
+
+// refresh the ghost-cell entries of a cell field from the neighbour ranks (no-op on a single rank)
+static int HX(ffm_plume *P, double *f) { return (P->N > P->nOwn) ? ffm_halo_refresh_d(P->A, f) : FFM_OK; }
 
 // ---- stand-in physics (not part of the reproduced hot path) -----------------------------------
 static void standin_thermo(ffm_plume *P)
@@ -132,6 +136,7 @@ static int solve_named(ffm_plume *P, const char *name, int solver, int pre, doub
 {
     FFM_TRY(ffm_ldu_set_coeffs_native_d(P->A, d, up, lo));
     SolveLog L; memset(&L, 0, sizeof(L)); strncpy(L.name, name, sizeof(L.name) - 1);
+    if (P->tight) { tol = 1e-13; relTol = 0.0; }
     FFM_TRY(ffm_solve_d(P->A, solver, pre, tol, relTol, 0, 1000, 1, psi, src, &L.perf));
     P->log.push_back(L);
     return FFM_OK;
@@ -173,8 +178,8 @@ static int rho_eqn(ffm_plume *P)
     double *div = P->wN[0];
     FFM_TRY(ffm_fvc_surface_integrate(P->mesh, P->phi, P->phib, div));
     const double *V = ffm_mesh_geom(P->mesh, 0), *rho0 = P->rho0; double *rho = P->rho; const double rdt = P->rdt;
-    forN(P, P->N, [=] __device__(long i) { rho[i] = (rdt * rho0[i] * V[i] - V[i] * div[i]) / (rdt * V[i]); });
-    return FFM_OK;
+    forN(P, P->nOwn, [=] __device__(long i) { rho[i] = (rdt * rho0[i] * V[i] - V[i] * div[i]) / (rdt * V[i]); });
+    return HX(P, rho);
 }
 
 static int hydrostatic_init(ffm_plume *P)
@@ -203,6 +208,7 @@ static int hydrostatic_init(ffm_plume *P)
         }
         FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, P->src[0], nullptr, P->dWork, P->sWork));
         FFM_TRY(solve_named(P, "ph_rgh", FFM_PCG, FFM_DIC, 1e-6, 0.01, P->dWork, P->upper, nullptr, ph, P->sWork));
+        FFM_TRY(HX(P, ph));
         forN(P, N, [=] __device__(long i) { p[i] = ph[i] + rho[i] * gh[i] + PREF; });
         standin_thermo(P); mul(P, rho, psi, p, N);
     }
@@ -219,6 +225,7 @@ static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *
     double *vb = P->wB[2], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *w = P->wF[3];
     FFM_TRY(ffm_bc_values(m, fBC, ref, P->zeroB, vf, vb));
     FFM_TRY(ffm_fvc_grad(m, vf, vb, gx, gy, gz));
+    FFM_TRY(HX(P, gx)); FFM_TRY(HX(P, gy)); FFM_TRY(HX(P, gz));
     FFM_TRY(ffm_fv_limited_weights(m, scheme, 1.0, 0.0, 1.0, P->phi, vf, gx, gy, gz, w));
     FFM_TRY(ffm_fvm_transport(m, P->rdt, P->rho, P->phi, w, gamma_f, -1, P->diag, P->upper, P->lower));
     FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, gamma_b, -1, fBC, ref, P->zeroB, P->ic[0], P->bc[0]));
@@ -230,7 +237,8 @@ static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *
     if (su) { forN(P, N, [=] __device__(long i) { s2[i] = s[i] + V[i] * su[i]; }); }
     else s2 = s;
     FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, s2, nullptr, P->dWork, P->sWork));
-    return solve_named(P, name, FFM_PBICGSTAB, FFM_DILU, tol, 0.0, P->dWork, P->upper, P->lower, vf, P->sWork);
+    FFM_TRY(solve_named(P, name, FFM_PBICGSTAB, FFM_DILU, tol, 0.0, P->dWork, P->upper, P->lower, vf, P->sWork));
+    return HX(P, vf);
 }
 
 static int p_corrector(ffm_plume *P, bool final)
@@ -243,14 +251,17 @@ static int p_corrector(ffm_plume *P, bool final)
     mul(P, rho, psi, p, N);                                                        // rho = thermo.rho()
     double *rAU = P->wN[0], *rhorAU = P->wN[1], *HbyA[3] = {P->wN[2], P->wN[3], P->wN[4]};
     FFM_TRY(ffm_fvm_A(m, 3, P->Udiag, P->Uic[0], P->Uic[1], P->Uic[2], rAU));
-    forN(P, N, [=] __device__(long i) { rAU[i] = 1.0 / rAU[i]; rhorAU[i] = rho[i] * rAU[i]; });
+    forN(P, P->nOwn, [=] __device__(long i) { rAU[i] = 1.0 / rAU[i]; });
+    FFM_TRY(HX(P, rAU));
+    forN(P, N, [=] __device__(long i) { rhorAU[i] = rho[i] * rAU[i]; });
     double *rhorAUf = P->wF[0], *rhorAUfb = P->wB[0];
     FFM_TRY(ffm_fvc_interpolate(m, nullptr, rhorAU, rhorAUf));
     zg(P, rhorAUfb, rhorAU);
     for (int c = 0; c < 3; c++) {
         FFM_TRY(ffm_fvm_H(m, 3, c, P->Uupper, P->Ulower, P->Usrc[c], P->Uic[0], P->Uic[1], P->Uic[2], P->Ubc[c], P->U[c], HbyA[c]));
         double *Hc = HbyA[c];
-        forN(P, N, [=] __device__(long i) { Hc[i] = rAU[i] * Hc[i]; });
+        forN(P, P->nOwn, [=] __device__(long i) { Hc[i] = rAU[i] * Hc[i]; });
+        FFM_TRY(HX(P, Hc));
     }
     FFM_TRY(update_bcs(P));
     double *Ub[3] = {P->wB[1], P->wB[2], P->wB[3]};
@@ -313,6 +324,7 @@ static int p_corrector(ffm_plume *P, bool final)
     }
     FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, P->src[0], nullptr, P->dWork, P->sWork));
     FFM_TRY(solve_named(P, "p_rgh", FFM_PCG, FFM_DIC, 1e-6, final ? 0.0 : 0.01, P->dWork, P->upper, nullptr, P->p_rgh, P->sWork));
+    FFM_TRY(HX(P, P->p_rgh));
     // phi = phiHbyA + p_rghEqn.flux(); U = HbyA + rAU*reconstruct((flux + phig)/rhorAUf)
     double *fl = P->wF[4], *flb = P->wB[7];
     FFM_TRY(ffm_fvm_flux(m, P->upper, P->lower, P->ic[0], P->bc[0], P->p_rgh, fl, flb));
@@ -324,11 +336,12 @@ static int p_corrector(ffm_plume *P, bool final)
         FFM_TRY(ffm_fvc_reconstruct(m, t, tb, rx, ry, rz));
         double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2]; const double *h0 = HbyA[0], *h1 = HbyA[1], *h2 = HbyA[2];
         double *K = P->K, *dpdt = P->dpdt; const double *p_rgh = P->p_rgh, *gh = P->gh, *p0 = P->p0;
-        forN(P, N, [=] __device__(long i) {
+        forN(P, P->nOwn, [=] __device__(long i) {
             const double a = h0[i] + rAU[i] * rx[i], b = h1[i] + rAU[i] * ry[i], c = h2[i] + rAU[i] * rz[i];
             U0[i] = a; U1[i] = b; U2[i] = c;
-            p[i] = p_rgh[i] + rho[i] * gh[i] + PREF;
         });
+        FFM_TRY(HX(P, U0)); FFM_TRY(HX(P, U1)); FFM_TRY(HX(P, U2));
+        forN(P, N, [=] __device__(long i) { p[i] = p_rgh[i] + rho[i] * gh[i] + PREF; });
         FFM_TRY(rho_eqn(P));
         forN(P, N, [=] __device__(long i) {
             K[i] = 0.5 * ((U0[i] * U0[i] + U1[i] * U1[i]) + U2[i] * U2[i]);
@@ -361,6 +374,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         forN(P, B, [=] __device__(long k) { mag2b[k] = (b0[k] * b0[k] + b1[k] * b1[k]) + b2[k] * b2[k]; });
     }
     FFM_TRY(ffm_fvc_grad(m, mag2, mag2b, gx, gy, gz));
+    FFM_TRY(HX(P, gx)); FFM_TRY(HX(P, gy)); FFM_TRY(HX(P, gz));
     FFM_TRY(ffm_fv_limited_weights(m, 2, 1.0, 0.0, 1.0, P->phi, mag2, gx, gy, gz, wU));
     double *muf = P->wF[0], *mub = P->wB[4];
     forN(P, nNat, [=] __device__(long e) { muf[e] = MU; });
@@ -391,11 +405,13 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         FFM_TRY(ffm_fvm_add_boundary(m, P->Uic[c], P->Ubc[c], P->Udiag, P->Usrc[c], rec[c], P->dWork, P->sWork));
         const char *nm[3] = {"Ux", "Uy", "Uz"};
         FFM_TRY(solve_named(P, nm[c], FFM_PBICGSTAB, FFM_DILU, 1e-6, 0.0, P->dWork, P->Uupper, P->Ulower, P->U[c], P->sWork));
+        FFM_TRY(HX(P, P->U[c]));
     }
     {
         double *K = P->K; const double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2];
         forN(P, N, [=] __device__(long i) { K[i] = 0.5 * ((U0[i] * U0[i] + U1[i] * U1[i]) + U2[i] * U2[i]); });
     }
+    { const char *st = getenv("FFM_PLUME_STOP"); if (st && atoi(st) == 1) { PL_HIP(hipStreamSynchronize(P->ctx->stream)); return FFM_OK; } }
     // ---------------- YEEqn.H
     double *af = P->wF[0], *afb = P->wB[4];
     forN(P, nNat, [=] __device__(long e) { af[e] = 0.5 * (MU / PR) + (1.0 - 0.5) * (MU / PR); });
@@ -424,6 +440,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         const double *b0 = Ub[0], *b1 = Ub[1], *b2 = Ub[2];
         forN(P, B, [=] __device__(long k) { Kb[k] = 0.5 * ((b0[k] * b0[k] + b1[k] * b1[k]) + b2[k] * b2[k]); });
         FFM_TRY(ffm_fvc_grad(m, P->K, Kb, kgx, kgy, kgz));
+        FFM_TRY(HX(P, kgx)); FFM_TRY(HX(P, kgy)); FFM_TRY(HX(P, kgz));
         FFM_TRY(ffm_fv_limited_weights(m, 2, 1.0, 0.0, 1.0, P->phi, P->K, kgx, kgy, kgz, wK));
         FFM_TRY(ffm_fvc_interpolate(m, wK, P->K, Kf));
         const double *phi = P->phi, *phib = P->phib;
@@ -436,8 +453,10 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8));
     }
     standin_thermo(P);
+    { const char *st = getenv("FFM_PLUME_STOP"); if (st && atoi(st) == 2) { PL_HIP(hipStreamSynchronize(P->ctx->stream)); return FFM_OK; } }
     // ---------------- pEqn.H x 2
     FFM_TRY(p_corrector(P, false));
+    { const char *st = getenv("FFM_PLUME_STOP"); if (st && atoi(st) == 3) { PL_HIP(hipStreamSynchronize(P->ctx->stream)); return FFM_OK; } }
     FFM_TRY(p_corrector(P, true));
     mul(P, P->rho, P->psi, P->p, N);
     P->time += P->dt;
@@ -447,54 +466,112 @@ extern "C" int ffm_plume_step(ffm_plume *P)
 
 extern "C" int ffm_plume_create(ffm_ctx *ctx, int nx, int ny, int nz, double h, double dt, ffm_plume **out)
 {
-    if (!ctx || !out || nx < 2 || ny < 2 || nz < 2) return FFM_ERR_ARG;
+    const int lo[3] = {0, 0, 0}, hi[3] = {nx, ny, nz}, nbr[6] = {-1, -1, -1, -1, -1, -1};
+    return ffm_plume_create_block(ctx, nx, ny, nz, lo, hi, nbr, h, dt, out);
+}
+
+// One rank's block [lo,hi) of the global (gx,gy,gz) box.  nbrRank[6] = rank across the -x,+x,-y,+y,-z,+z side of the
+// block, or -1 where that side is a physical boundary of the box.  Ghost layers carry the neighbour ranks' cells.
+extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, const int *lo, const int *hi, const int *nbrRank,
+                                      double h, double dt, ffm_plume **out)
+{
+    if (!ctx || !out || !lo || !hi || !nbrRank) return FFM_ERR_ARG;
+    const int nx = hi[0] - lo[0], ny = hi[1] - lo[1], nz = hi[2] - lo[2];
+    if (nx < 2 || ny < 2 || nz < 2) { ffm_set_error("plume block must be at least 2 cells wide in every direction"); return FFM_ERR_ARG; }
+    for (int d = 0; d < 3; d++) {
+        const int G = d == 0 ? gx : d == 1 ? gy : gz;
+        if ((lo[d] == 0) != (nbrRank[2 * d] < 0) || (hi[d] == G) != (nbrRank[2 * d + 1] < 0)) { ffm_set_error("plume block: neighbour ranks inconsistent with the block position"); return FFM_ERR_ARG; }
+    }
     PL_HIP(hipSetDevice(ctx->device));
     ffm_plume *P = new ffm_plume();
     P->ctx = ctx; P->nx = nx; P->ny = ny; P->nz = nz; P->h = h; P->dt = dt; P->rdt = 1.0 / dt;
-    const long N = (long)nx * ny * nz;
-    P->N = (int)N;
-    // ---- natural blockMesh LDU
-    std::vector<int> l, u; std::vector<signed char> fd;
-    l.reserve(3 * N); u.reserve(3 * N); fd.reserve(3 * N);
+    P->tight = getenv("FFM_PLUME_TIGHT") != nullptr;      // tests only: see ffm_plume_set_tight
+    const long nOwn = (long)nx * ny * nz;
+    // ---- ghost layers, one per coupled side, in side order -x,+x,-y,+y,-z,+z; inside a layer in natural order
+    const int cnt[6] = {ny * nz, ny * nz, nx * nz, nx * nz, nx * ny, nx * ny};
+    int gOff[7]; gOff[0] = 0;
+    for (int s6 = 0; s6 < 6; s6++) gOff[s6 + 1] = gOff[s6] + (nbrRank[s6] >= 0 ? cnt[s6] : 0);
+    const long nGhost = gOff[6], N = nOwn + nGhost;
+    P->N = (int)N; P->nOwn = (int)nOwn;
+    auto cellOf = [&](int i, int j, int k) { return i + nx * (j + ny * k); };
+    auto ghostOf = [&](int side, int i, int j, int k) -> int {     // ghost across `side` of owned cell (i,j,k)
+        switch (side >> 1) {
+        case 0: return (int)nOwn + gOff[side] + j + ny * k;
+        case 1: return (int)nOwn + gOff[side] + i + nx * k;
+        default: return (int)nOwn + gOff[side] + i + nx * j;
+        }
+    };
+    // ---- LDU in local natural order + cut faces owned by the owned cell (ghost index > every owned index)
+    std::vector<int> l, u; std::vector<signed char> fd, fsgn;
+    l.reserve(3 * nOwn + nGhost); u.reserve(3 * nOwn + nGhost); fd.reserve(3 * nOwn + nGhost); fsgn.reserve(3 * nOwn + nGhost);
     for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) {
-        const int c = i + nx * (j + ny * k);
-        if (i < nx - 1) { l.push_back(c); u.push_back(c + 1); fd.push_back(0); }
-        if (j < ny - 1) { l.push_back(c); u.push_back(c + nx); fd.push_back(1); }
-        if (k < nz - 1) { l.push_back(c); u.push_back(c + nx * ny); fd.push_back(2); }
+        const int c = cellOf(i, j, k);
+        if (i < nx - 1) { l.push_back(c); u.push_back(c + 1); fd.push_back(0); fsgn.push_back(1); }
+        if (j < ny - 1) { l.push_back(c); u.push_back(c + nx); fd.push_back(1); fsgn.push_back(1); }
+        if (k < nz - 1) { l.push_back(c); u.push_back(c + nx * ny); fd.push_back(2); fsgn.push_back(1); }
+        const int at[6] = {i == 0, i == nx - 1, j == 0, j == ny - 1, k == 0, k == nz - 1};
+        for (int s6 = 0; s6 < 6; s6++) if (at[s6] && nbrRank[s6] >= 0) {    // ascending ghost index = ascending side
+            l.push_back(c); u.push_back(ghostOf(s6, i, j, k)); fd.push_back((signed char)(s6 >> 1)); fsgn.push_back((s6 & 1) ? 1 : -1);
+        }
     }
     const int F = (int)l.size(); P->F = F;
     // ---- renumber once to the library's cell order (no permutation pass ever after)
     std::vector<int> c2(N), f2(F);
-    FFM_TRY(ffm_renumber_levels((int)N, F, l.data(), u.data(), c2.data(), f2.data()));
+    FFM_TRY(ffm_renumber_levels_ext((int)nOwn, (int)nGhost, F, l.data(), u.data(), c2.data(), f2.data()));
     P->newToOld = c2;
     std::vector<int> oldToNew(N);
     for (long c = 0; c < N; c++) oldToNew[c2[c]] = (int)c;
-    std::vector<int> l2(F), u2(F); std::vector<signed char> fd2(F);
-    for (int f = 0; f < F; f++) { l2[f] = oldToNew[l[f2[f]]]; u2[f] = oldToNew[u[f2[f]]]; fd2[f] = fd[f2[f]]; }
-    FFM_TRY(ffm_ldu_create(ctx, (int)N, F, l2.data(), u2.data(), &P->A));
+    std::vector<int> l2(F), u2(F); std::vector<signed char> fd2(F), sg2(F);
+    for (int f = 0; f < F; f++) { l2[f] = oldToNew[l[f2[f]]]; u2[f] = oldToNew[u[f2[f]]]; fd2[f] = fd[f2[f]]; sg2[f] = fsgn[f2[f]]; }
+    FFM_TRY(ffm_ldu_create_ext(ctx, (int)nOwn, (int)nGhost, F, l2.data(), u2.data(), &P->A));
     if (!P->A->identity) { ffm_set_error("plume: renumbered mesh is not native"); return FFM_ERR_ADDR; }
+    FFM_TRY(ffm_ldu_set_global_cells(P->A, (long)gx * gy * gz));
     P->nNat = P->A->upTotal;
-    // ---- geometry
-    auto ijk = [&](int cOld, int &i, int &j, int &k) { i = cOld % nx; j = (cOld / nx) % ny; k = cOld / (nx * ny); };
+    // ---- geometry (global coordinates)
     std::vector<double> V(N, h * h * h), C(3 * N), Sf(3 * (size_t)F, 0.0), magSf(F, h * h), wgt(F, 0.5), del(F, 1.0 / h), Cfy(F);
-    for (long c = 0; c < N; c++) { int i, j, k; ijk(c2[c], i, j, k); C[c] = (i + 0.5) * h; C[N + c] = (j + 0.5) * h; C[2 * N + c] = (k + 0.5) * h; }
-    for (int f = 0; f < F; f++) { Sf[(size_t)fd2[f] * F + f] = h * h; Cfy[f] = C[N + l2[f]] + (fd2[f] == 1 ? 0.5 * h : 0.0); }
-    // ---- patches: inlet, floor, top, sides(xmin,xmax,zmin,zmax)
-    const double Lx = nx * h, Lz = nz * h, hwx = std::min(0.5, Lx / 4), hwz = std::min(0.5, Lz / 4);
+    for (long cn = 0; cn < N; cn++) {
+        const int co = c2[cn];
+        int i, j, k;
+        if (co < nOwn) { i = co % nx; j = (co / nx) % ny; k = co / (nx * ny); }
+        else {
+            int side = 0; while (co - nOwn >= gOff[side + 1]) side++;
+            const int r = co - (int)nOwn - gOff[side];
+            switch (side >> 1) {
+            case 0: j = r % ny; k = r / ny; i = (side & 1) ? nx : -1; break;
+            case 1: i = r % nx; k = r / nx; j = (side & 1) ? ny : -1; break;
+            default: i = r % nx; j = r / nx; k = (side & 1) ? nz : -1; break;
+            }
+        }
+        C[cn] = (lo[0] + i + 0.5) * h; C[N + cn] = (lo[1] + j + 0.5) * h; C[2 * N + cn] = (lo[2] + k + 0.5) * h;
+    }
+    for (int f = 0; f < F; f++) { Sf[(size_t)fd2[f] * F + f] = sg2[f] * h * h; Cfy[f] = C[N + l2[f]] + (fd2[f] == 1 ? sg2[f] * 0.5 * h : 0.0); }
+    // ---- ghost exchange plan: side s sends the owned layer adjacent to it, receives the ghost layer across it
+    {
+        std::vector<int> ranks, sc, rc, cells;
+        for (int s6 = 0; s6 < 6; s6++) if (nbrRank[s6] >= 0) {
+            ranks.push_back(nbrRank[s6]); sc.push_back(cnt[s6]); rc.push_back(cnt[s6]);
+            const int d = s6 >> 1, pos = (s6 & 1) ? (d == 0 ? nx : d == 1 ? ny : nz) - 1 : 0;
+            if (d == 0) for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) cells.push_back(oldToNew[cellOf(pos, j, k)]);
+            else if (d == 1) for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) cells.push_back(oldToNew[cellOf(i, pos, k)]);
+            else for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) cells.push_back(oldToNew[cellOf(i, j, pos)]);
+        }
+        if (!ranks.empty()) FFM_TRY(ffm_ldu_set_ghost_exchange(P->A, (int)ranks.size(), ranks.data(), sc.data(), cells.data(), rc.data()));
+    }
+    // ---- patches on the physical sides of the block: inlet, floor, top, sides(xmin,xmax,zmin,zmax)
+    const double Lx = gx * h, Lz = gz * h, hwx = std::min(0.5, Lx / 4), hwz = std::min(0.5, Lz / 4);
     std::vector<int> pc[4]; std::vector<double> pS[4][3];
     auto addFace = [&](int patch, int cOld, double sx, double sy, double sz) {
         pc[patch].push_back(oldToNew[cOld]); pS[patch][0].push_back(sx); pS[patch][1].push_back(sy); pS[patch][2].push_back(sz);
     };
-    for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) {          // ymin in natural cell order
-        const int c = i + nx * (0 + ny * k);
-        const bool in = std::fabs((i + 0.5) * h - Lx / 2) < hwx && std::fabs((k + 0.5) * h - Lz / 2) < hwz;
-        addFace(in ? P_INLET : P_FLOOR, c, 0, -h * h, 0);
+    if (nbrRank[2] < 0) for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) {          // ymin in natural cell order
+        const bool in = std::fabs((lo[0] + i + 0.5) * h - Lx / 2) < hwx && std::fabs((lo[2] + k + 0.5) * h - Lz / 2) < hwz;
+        addFace(in ? P_INLET : P_FLOOR, cellOf(i, 0, k), 0, -h * h, 0);
     }
-    for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) addFace(P_TOP, i + nx * ((ny - 1) + ny * k), 0, h * h, 0);
-    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) addFace(P_SIDES, 0 + nx * (j + ny * k), -h * h, 0, 0);
-    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) addFace(P_SIDES, (nx - 1) + nx * (j + ny * k), h * h, 0, 0);
-    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) addFace(P_SIDES, i + nx * (j + ny * 0), 0, 0, -h * h);
-    for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) addFace(P_SIDES, i + nx * (j + ny * (nz - 1)), 0, 0, h * h);
+    if (nbrRank[3] < 0) for (int k = 0; k < nz; k++) for (int i = 0; i < nx; i++) addFace(P_TOP, cellOf(i, ny - 1, k), 0, h * h, 0);
+    if (nbrRank[0] < 0) for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) addFace(P_SIDES, cellOf(0, j, k), -h * h, 0, 0);
+    if (nbrRank[1] < 0) for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) addFace(P_SIDES, cellOf(nx - 1, j, k), h * h, 0, 0);
+    if (nbrRank[4] < 0) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) addFace(P_SIDES, cellOf(i, j, 0), 0, 0, -h * h);
+    if (nbrRank[5] < 0) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) addFace(P_SIDES, cellOf(i, j, nz - 1), 0, 0, h * h);
     int sizes[4]; const int *fcs[4]; const double *pSf[4]; const double *pDel[4];
     std::vector<double> pSflat[4], pD[4];
     int Btot = 0;
@@ -505,6 +582,7 @@ extern "C" int ffm_plume_create(ffm_ctx *ctx, int nx, int ny, int nz, double h, 
     }
     P->B = Btot;
     FFM_TRY(ffm_mesh_create(P->A, V.data(), C.data(), Sf.data(), magSf.data(), wgt.data(), del.data(), 4, sizes, fcs, pSf, pDel, &P->mesh));
+    const int ny_glob = gy;
     const int B = Btot; const long nNat = P->nNat;
     // ---- fields
     auto NN = [&]() { return dalloc(P, N); };
@@ -515,7 +593,7 @@ extern "C" int ffm_plume_create(ffm_ctx *ctx, int nx, int ny, int nz, double h, 
     P->rho = NN(); P->rho0 = NN(); P->K = NN(); P->K0 = NN(); P->dpdt = NN(); P->ph_rgh = NN();
     P->phi = dalloc(P, nNat); P->phi0 = dalloc(P, nNat); P->phib = dalloc(P, B); P->phib0 = dalloc(P, B); P->ph_rgh_b = dalloc(P, B);
     {
-        const double ghRef = -9.81 * (ny * h);
+        const double ghRef = -9.81 * (ny_glob * h);
         std::vector<double> gh(N), ghf(std::max<long>(nNat, 1), 0.0);
         for (long c = 0; c < N; c++) gh[c] = -9.81 * C[N + c] - ghRef;
         for (int f = 0; f < F; f++) ghf[P->A->h_callerToNative[f]] = -9.81 * Cfy[f] - ghRef;
@@ -573,7 +651,8 @@ extern "C" int ffm_plume_destroy(ffm_plume *P)
     return FFM_OK;
 }
 
-extern "C" int ffm_plume_ncells(const ffm_plume *P) { return P ? P->N : FFM_ERR_ARG; }
+extern "C" int ffm_plume_set_tight(ffm_plume *P, int on) { if (!P) return FFM_ERR_ARG; P->tight = on != 0; return FFM_OK; }
+extern "C" int ffm_plume_ncells(const ffm_plume *P) { return P ? P->nOwn : FFM_ERR_ARG; }
 extern "C" int ffm_plume_nfaces(const ffm_plume *P) { return P ? P->F : FFM_ERR_ARG; }
 
 // copy a cell field to the host in NATURAL blockMesh cell order; name in rho,p,p_rgh,T,h,K,Ux,Uy,Uz,psi,<specie>
@@ -590,7 +669,7 @@ extern "C" int ffm_plume_get_field(ffm_plume *P, const char *name, double *out)
     std::vector<double> v(P->N);
     PL_HIP(hipStreamSynchronize(P->ctx->stream));
     PL_HIP(hipMemcpy(v.data(), src, sizeof(double) * P->N, hipMemcpyDeviceToHost));
-    for (int c = 0; c < P->N; c++) out[P->newToOld[c]] = v[c];
+    for (int c = 0; c < P->nOwn; c++) out[P->newToOld[c]] = v[c];      // owned cells, local natural (blockMesh) order
     return FFM_OK;
 }
 

@@ -288,7 +288,7 @@ __global__ void k_bwd_level(int p0, int p1, const int *__restrict__ order, LduVi
     int c;
     if (order) { const int p = p0 + blockIdx.x * blockDim.x + threadIdx.x; if (p >= p1) return; c = order[p]; }
     else { c = (p0 & ~63) + blockIdx.x * blockDim.x + threadIdx.x; if (c < p0 || c >= p1) return; }
-    RowEnt<W> U; load_upper<W>(v, c, U);
+    RowEnt<W> U; load_upper<W, true>(v, c, U);          // block-Jacobi: ghost neighbours are ignored
     const double rd = rD[c];
     double wc = w[c];
     double a[W], wn[W];
@@ -389,7 +389,7 @@ static int calc_rD(ffm_ldu *A)
             FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL(k_rD_level<W>, dim3(level_grid(c0, c1)), dim3(256), 0, s, c0, c1, ffm_view(A),
                                A->upper, A->lower, A->diag, A->rD));
         }
-        hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->rD, A->rD);
+        hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nOwned)), dim3(256), 0, s, (long)A->nOwned, A->rD, A->rD);
         FFM_HIP(hipGetLastError());
         return FFM_OK;
     }));
@@ -407,7 +407,7 @@ int ffm_precond_setup_i(ffm_ldu *A, int precond)
         FFM_TRY(calc_rD(A)); break;
     case FFM_DILU: FFM_TRY(calc_rD(A)); break;
     case FFM_DIAGONALP:
-        hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nCells)), dim3(256), 0, s, (long)A->nCells, A->rD, A->diag);
+        hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nOwned)), dim3(256), 0, s, (long)A->nOwned, A->rD, A->diag);
         FFM_HIP(hipGetLastError());
         break;
     default: ffm_set_error("unknown preconditioner %d", precond); return FFM_ERR_UNSUPPORTED;
@@ -419,7 +419,7 @@ int ffm_precond_setup_i(ffm_ldu *A, int precond)
 int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r, double *w)
 {
     hipStream_t s = A->ctx->stream;
-    const long N = A->nCells;
+    const long N = A->nOwned;
     if (precond == FFM_NONE) { hipLaunchKernelGGL(k_copy, dim3(sgrid(N)), dim3(256), 0, s, N, w, r); FFM_HIP(hipGetLastError()); return FFM_OK; }
     if (precond == FFM_DIAGONALP) { hipLaunchKernelGGL(k_mul, dim3(sgrid(N)), dim3(256), 0, s, N, w, A->rD, r); FFM_HIP(hipGetLastError()); return FFM_OK; }
     // DIC: fwd upper / bwd upper.  DILU: fwd lower / bwd upper.  DILU^T: fwd upper / bwd lower.
@@ -448,7 +448,7 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
 int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b)
 {
     hipStream_t s = A->ctx->stream;
-    const long N = A->nCells;
+    const long N = A->nOwned;
     double *bP, *bSave;
     FFM_TRY(ffm_ldu_work(A, 10, &bP)); FFM_TRY(ffm_ldu_work(A, 11, &bSave));
     for (int sw = 0; sw < nSweeps; sw++) {
@@ -492,7 +492,7 @@ static inline bool check_convergence(ffm_perf *p, const Controls &k)
 static int norm_and_initial(ffm_ldu *A, const double *psi, const double *source, const double *Apsi, double *tmp,
                             const double *rA, ffm_perf *perf)
 {
-    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells;
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned;
     FFM_TRY(ffm_k_sum(c, psi, N, S_TMP0));
     FFM_TRY(finish_dot(c, OP_XREF, 1, (double)A->globalCells));
     FFM_TRY(ffm_k_sumA(A, tmp));
@@ -512,7 +512,7 @@ static int norm_and_initial(ffm_ldu *A, const double *psi, const double *source,
 // PCG::solve
 static int pcg(ffm_ldu *A, int precond, const Controls &k, double *psi, const double *source, ffm_perf *perf)
 {
-    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned; const int g = sgrid(N);
     double *pA, *wA, *rA;
     FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &wA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
     FFM_TRY(scalar_op(c, OP_RESET));
@@ -542,7 +542,7 @@ static int pcg(ffm_ldu *A, int precond, const Controls &k, double *psi, const do
 // PBiCGStab::solve
 static int pbicgstab(ffm_ldu *A, int precond, const Controls &k, double *psi, const double *source, ffm_perf *perf)
 {
-    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned; const int g = sgrid(N);
     double *yA, *rA, *pA, *AyA, *sA, *zA, *tA, *rA0;
     FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &yA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
     FFM_TRY(scalar_op(c, OP_RESET));
@@ -591,7 +591,7 @@ static int pbicgstab(ffm_ldu *A, int precond, const Controls &k, double *psi, co
 // PBiCG::solve
 static int pbicg(ffm_ldu *A, int precond, const Controls &k, double *psi, const double *source, ffm_perf *perf)
 {
-    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned; const int g = sgrid(N);
     double *pA, *pT, *wA, *wT, *rA, *rT;
     FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &wA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
     FFM_TRY(ffm_ldu_work(A, 4, &pT)); FFM_TRY(ffm_ldu_work(A, 5, &wT)); FFM_TRY(ffm_ldu_work(A, 6, &rT));
@@ -630,7 +630,7 @@ static int pbicg(ffm_ldu *A, int precond, const Controls &k, double *psi, const 
 static int smooth(ffm_ldu *A, int smoother, const Controls &k, double *psi, const double *source, ffm_perf *perf)
 {
     if (smoother != FFM_GS && smoother != FFM_SYMGS) { ffm_set_error("smoothSolver: smoother must be GaussSeidel or symGaussSeidel"); return FFM_ERR_UNSUPPORTED; }
-    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nCells; const int g = sgrid(N);
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned; const int g = sgrid(N);
     const int nSweeps = k.nSweeps > 0 ? k.nSweeps : 1;
     double *Apsi, *tmp, *res;
     FFM_TRY(ffm_ldu_work(A, 1, &Apsi)); FFM_TRY(ffm_ldu_work(A, 2, &tmp)); FFM_TRY(ffm_ldu_work(A, 3, &res));
@@ -653,7 +653,7 @@ static int smooth(ffm_ldu *A, int smoother, const Controls &k, double *psi, cons
 
 static int diagonal(ffm_ldu *A, double *psi, const double *source, ffm_perf *perf)
 {
-    hipLaunchKernelGGL(k_diag_solve, dim3(sgrid(A->nCells)), dim3(256), 0, A->ctx->stream, (long)A->nCells, psi, source, A->diag);
+    hipLaunchKernelGGL(k_diag_solve, dim3(sgrid(A->nOwned)), dim3(256), 0, A->ctx->stream, (long)A->nOwned, psi, source, A->diag);
     FFM_HIP(hipGetLastError());
     perf->initialResidual = perf->finalResidual = 0.0; perf->nIterations = 0; perf->converged = 1; perf->singular = 0;
     return FFM_OK;
@@ -705,10 +705,10 @@ extern "C" int ffm_solve(ffm_ldu *A, int solver, int precond, double tol, double
     double *p = nullptr, *b = nullptr;
     const size_t nb = sizeof(double) * (size_t)std::max(A->nCells, 1);
     FFM_HIP(hipMalloc((void **)&p, nb)); FFM_HIP(hipMalloc((void **)&b, nb));
-    FFM_HIP(hipMemcpy(p, psi, sizeof(double) * A->nCells, hipMemcpyHostToDevice));
-    FFM_HIP(hipMemcpy(b, source, sizeof(double) * A->nCells, hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(p, psi, sizeof(double) * A->nOwned, hipMemcpyHostToDevice));
+    FFM_HIP(hipMemcpy(b, source, sizeof(double) * A->nOwned, hipMemcpyHostToDevice));
     int rc = ffm_solve_d(A, solver, precond, tol, relTol, minIter, maxIter, nSweeps, p, b, out);
-    if (!rc && hipMemcpy(psi, p, sizeof(double) * A->nCells, hipMemcpyDeviceToHost) != hipSuccess) rc = FFM_ERR_HIP;
+    if (!rc && hipMemcpy(psi, p, sizeof(double) * A->nOwned, hipMemcpyDeviceToHost) != hipSuccess) rc = FFM_ERR_HIP;
     hipFree(p); hipFree(b);
     return rc;
 }

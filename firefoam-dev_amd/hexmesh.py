@@ -173,3 +173,18 @@ def apply_renumbering(nCells, l, u, cellOrder, faceOrder):
     oldToNew = np.empty(nCells, np.int64)
     oldToNew[cellOrder] = np.arange(nCells)
     return oldToNew[l[faceOrder]].astype(np.int32), oldToNew[u[faceOrder]].astype(np.int32), oldToNew
+
+
+def block_of_rank(glob, grid, rank):
+    """Block [lo,hi) of `rank` (r = bx + gx*(by + gy*bz)) and its six neighbour ranks (-x,+x,-y,+y,-z,+z; -1 = none)."""
+    gx, gy, gz = grid
+    b = (rank % gx, (rank // gx) % gy, rank // (gx * gy))
+    cuts = [np.linspace(0, glob[d], grid[d] + 1).astype(int) for d in range(3)]
+    lo = tuple(int(cuts[d][b[d]]) for d in range(3))
+    hi = tuple(int(cuts[d][b[d] + 1]) for d in range(3))
+    nbr = []
+    for d in range(3):
+        for side in (-1, 1):
+            bb = list(b); bb[d] += side
+            nbr.append(-1 if bb[d] < 0 or bb[d] >= grid[d] else bb[0] + gx * (bb[1] + gy * bb[2]))
+    return lo, hi, nbr

@@ -88,6 +88,22 @@ int ffm_memset(ffm_ctx *ctx, void *dst_d, int value, size_t bytes);
  * when the caller's numbering is already level-major).                       */
 int ffm_ldu_create(ffm_ctx *ctx, int nCells, int nFaces, const int *lowerAddr,
                    const int *upperAddr, ffm_ldu **out);
+/* Decomposed (one rank per GPU) form: cells [0,nOwned) are this rank's, cells
+ * [nOwned, nOwned+nGhost) are copies of neighbour-rank cells (one layer across the
+ * cut faces, which are ordinary faces owned by the owned cell).  Rows exist for owned
+ * cells only; DIC/DILU ignore faces towards ghosts (block-Jacobi, as OpenFOAM's
+ * processor interfaces); Amul refreshes the ghost entries of its argument first
+ * (ffm_ldu_set_ghost_exchange).  Cell fields have nOwned+nGhost entries.          */
+int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwned, int nGhost, int nFaces, const int *lowerAddr,
+                       const int *upperAddr, ffm_ldu **out);
+int ffm_renumber_levels_ext(int nOwned, int nGhost, int nFaces, const int *lowerAddr,
+                            const int *upperAddr, int *newToOldCell, int *newToOldFace);
+/* neighbour q (rank nbrRank[q]) receives this rank's cells sendCells[...] (sendCount[q] of
+ * them, concatenated) and fills recvCount[q] consecutive ghost cells, in neighbour order    */
+int ffm_ldu_set_ghost_exchange(ffm_ldu *ldu, int nNbr, const int *nbrRank, const int *sendCount,
+                               const int *sendCells, const int *recvCount);
+int ffm_halo_refresh_d(ffm_ldu *ldu, double *field_d);
+int ffm_ldu_nowned(const ffm_ldu *ldu);
 int ffm_ldu_destroy(ffm_ldu *ldu);
 int ffm_ldu_ncells(const ffm_ldu *ldu);
 int ffm_ldu_nfaces(const ffm_ldu *ldu);
@@ -235,8 +251,14 @@ int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lower, const do
  * the order of solver/fireFoam.C:97-119.  bench.py's workload.                */
 typedef struct ffm_plume ffm_plume;
 int ffm_plume_create(ffm_ctx *ctx, int nx, int ny, int nz, double h, double deltaT, ffm_plume **out);
+/* one rank's block [lo,hi) of the global box; nbrRank[6] = rank across the -x,+x,-y,+y,-z,+z side or -1
+ * (physical boundary).  Needs ffm_comm_init / ffm_comm_init_host when any neighbour exists.            */
+int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, const int *lo, const int *hi,
+                           const int *nbrRank, double h, double deltaT, ffm_plume **out);
 int ffm_plume_destroy(ffm_plume *p);
 int ffm_plume_step(ffm_plume *p);
+/* tests: run every linear solve to 1e-13 with relTol 0 instead of the fvSolution controls */
+int ffm_plume_set_tight(ffm_plume *p, int on);
 int ffm_plume_ncells(const ffm_plume *p);
 int ffm_plume_nfaces(const ffm_plume *p);
 int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);
@@ -272,6 +294,11 @@ typedef void (*ffm_host_exchange_fn)(void *user, int nPatches, const int *size,
 int ffm_comm_init_host(ffm_ctx *ctx, int rank, int nRanks, void *user,
                        ffm_host_allreduce_fn allreduce,
                        ffm_host_exchange_fn exchange);
+/* variable-count form used by the ghost-cell halo: neighbour q sends
+ * sendBuf[sendOff[q]..sendOff[q+1]) to nbrRank[q] and receives recvBuf[recvOff[q]..recvOff[q+1]) from it */
+typedef void (*ffm_host_exchange2_fn)(void *user, int nNbr, const int *nbrRank, const int *sendOff,
+                                      const int *recvOff, const double *sendBuf, double *recvBuf);
+int ffm_comm_set_host_exchange2(ffm_ctx *ctx, ffm_host_exchange2_fn fn);
 int ffm_comm_rank(const ffm_ctx *ctx);
 int ffm_comm_size(const ffm_ctx *ctx);
 
