@@ -28,9 +28,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=400, help="cells per box edge (400 -> 64 M cells, BASELINE.json config)")
+    ap.add_argument("--edge", dest="n", type=int, default=400, help="cells per box edge (400 -> 64 M cells, BASELINE.json config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=96)
+    ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
+                    help="rccl: one rank per GPU over xGMI (production); host: ranks share GPUs, halo through gloo (rehearsal)")
     args = ap.parse_args()
 
     import torch
@@ -40,20 +42,38 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    dev = local % max(ndev, 1)
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.transport == "rccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     from ffm_import import ffm
-    ctx = ffm.Context(local)
+    ctx = ffm.Context(dev)
     n = args.n
-    if world > 1:
-        raise SystemExit("bench.py: the decomposed (N>1) outer iteration is not wired into the plume driver yet; "
-                         "the decomposed linear solvers are (tests/test_decomposed_*.py)")
     t0 = time.time()
-    case = ffm.Plume(ctx, (n, n, n), h=0.05, deltaT=1e-3)
+    if world == 1:
+        case = ffm.Plume(ctx, (n, n, n), h=0.05, deltaT=1e-3)
+        grid = (1, 1, 1)
+    else:
+        # strong scaling: the same global box, block-decomposed (2x1x1, 2x2x1, 2x2x2), one block per rank
+        if args.transport == "rccl":
+            ids = [ffm.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.comm_init_rccl(rank, world, ids[0])
+        else:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
+            import gloo_comm
+            ctx.comm_init_host(rank, world, gloo_comm.allreduce, gloo_comm.exchange)
+        grid = ffm.hexmesh.grid_for(world)
+        lo, hi, nbr = ffm.hexmesh.block_of_rank((n, n, n), grid, rank)
+        case = ffm.Plume(ctx, (n, n, n), h=0.05, deltaT=1e-3, lo=lo, hi=hi, nbrRank=nbr)
     setup_s = time.time() - t0
-    N, F = case.nCells, case.nFaces
+    N, F = n ** 3, 3 * n * n * (n - 1)          # global cells / faces
+    Nloc, Floc = case.nCells, case.nFaces
 
     def barrier():
         if world > 1:
@@ -70,7 +90,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device="cuda" if args.transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     solves = case.solves()
@@ -79,14 +99,15 @@ def main():
     # ---- roofline: the PCG SpMV kernel (lduMatrix::Amul) on the p_rgh matrix left by the last corrector,
     # HIP events on the library's stream (ffm_bench_spmv), algorithmic bytes 24 N + 16 F
     import ctypes as C
-    x = ctx.to_device(ffm.hexmesh.hash_u(0xF4, __import__("numpy").arange(N)))
-    y = ctx.empty(N)
+    nExt = L_ncells = ffm.lib().ffm_ldu_ncells(case.ldu_handle())
+    x = ctx.to_device(ffm.hexmesh.hash_u(0xF4, __import__("numpy").arange(nExt)))
+    y = ctx.empty(nExt)
     ms = C.c_double()
     L = ffm.lib()
     rc = L.ffm_bench_spmv(case.ldu_handle(), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 20, C.byref(ms))
     if rc:
         raise SystemExit("ffm_bench_spmv failed: %s" % L.ffm_last_error().decode())
-    alg_bytes = 24 * N + 16 * F
+    alg_bytes = 24 * Nloc + 16 * Floc           # this rank's rows (N > 1: the timing then includes the halo refresh)
     achieved = alg_bytes / (ms.value * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "k_rows<0,*> (lduMatrix::Amul, symmetric p_rgh matrix)", "achieved": round(achieved, 1),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
@@ -116,7 +137,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic %d^3 hex box (%d cells), buoyant plume + 5-species EDC-shaped source, "
                                    "PIMPLE 1/2/0: rhoEqn + UEqn + YEEqn(4 Yi + h) + 2 pEqn per step" % (n, N),
-                       "cells": N, "faces": F, "deltaT": 1e-3, "parallelism": "1 GPU" if world == 1 else "%d-way block decomposition" % world,
+                       "cells": N, "faces": F, "deltaT": 1e-3, "parallelism": "1 GPU" if world == 1 else "%dx%dx%d block decomposition, one block per GPU, RCCL halo + all-reduce" % grid,
                        "p_rgh_iterations_last_step": pIters, "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
