@@ -148,6 +148,20 @@ struct ffm_ldu {
     int *ghSendCells = nullptr;
     double *ghSendBuf = nullptr, *ghSendBuf_h = nullptr, *ghRecvBuf_h = nullptr;
 
+    // ---- pipelined sweep plan (sweepMode == 1): cells are numbered group-major, level-major inside a group;
+    // group g = cells [grpCell[g], grpCell[g+1]); one workgroup sweeps one group level by level
+    int sweepMode = 0;              // 0: one launch per level (level-major numbering); 1: pipelined groups
+    int nGroups = 0;
+    bool bwdIsReverse = false;      // inside every group the backward order is the exact reverse of the forward order
+    int *grpCell = nullptr;         // [G+1]
+    int *fEntStart = nullptr, *fEntLevel = nullptr, *fEntCell = nullptr;   // [G+1], [E], [E+1]  forward entries (level, first cell)
+    int *fPredStart = nullptr, *fPreds = nullptr;                           // [G+1], [..] groups owning lower neighbours
+    int *bEntStart = nullptr, *bEntLevel = nullptr, *bEntPos = nullptr;    // backward entries: positions into bwdCells
+    int *bPredStart = nullptr, *bPreds = nullptr;                           // groups owning upper neighbours
+    int *bwdCells = nullptr;        // [nOwned] cells in (group, backward level) order
+    unsigned long long *pipeProgress = nullptr;   // [G] (epoch<<32 | levels done)
+    unsigned int *pipeTicket = nullptr;           // [2]: ticket counter, abort flag
+
     // cached hipGraphs of level-scheduled sweeps
     std::map<SweepGraphKey, hipGraphExec_t> graphs;
 };
@@ -169,6 +183,10 @@ int ffm_allreduce_minmax(ffm_ctx *ctx, int slot, int isMax);
 void ffm_comm_finalize_i(ffm_ctx *ctx);
 int ffm_precond_setup_i(ffm_ldu *A, int precond);
 int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
+int ffm_pipe_calc_rD(ffm_ldu *A);
+int ffm_pipe_precond(ffm_ldu *A, const double *cf, const double *cb, const double *r, double *w);
+int ffm_pipe_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSave);
+int ffm_pipe_check_abort(ffm_ldu *A);
 int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b);
 int ffm_halo_exchange(ffm_ldu *A, const double *x);
 int ffm_ghost_exchange(ffm_ldu *A, double *x);                 // refresh x[nOwned..nCells) from the neighbour ranks          // pack x[faceCells], exchange into haloRecv

@@ -43,13 +43,24 @@ struct LduAnalysis {
     std::vector<int> bwdLevelStart;        // [nBwd+1] into bwdOrder
     std::vector<int> bwdOrder;             // cells sorted by backward level
     bool identity = true, bwdContig = true;
+    // pipelined-sweep plan (mode 1)
+    int mode = 0, nGroups = 0; bool bwdIsReverse = false;
+    std::vector<int> grpCell, fEntStart, fEntLevel, fEntCell, fPredStart, fPreds, bEntStart, bEntLevel, bEntPos, bPredStart, bPreds, bwdCells;
 };
+
+// FFM_SWEEP=pipe selects the pipelined group sweep (ffm_pipe.hip); default is one launch per dependency level
+static int default_sweep_mode()
+{
+    const char *e = getenv("FFM_SWEEP");
+    return (e && (e[0] == 'p' || e[0] == 'P' || e[0] == '1')) ? 1 : 0;
+}
 
 // nOwn < N: cells [nOwn, N) are ghost cells (copies of neighbour-rank cells).  They own no faces, stay at the end of the
 // numbering in their given order, take no part in the level structure, and faces towards them are ignored by the
 // backward levels (block-Jacobi sweeps).
 static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renumber, bool sortByNewNeighbour, LduAnalysis &a)
 {
+    a.mode = default_sweep_mode();
     for (int f = 0; f < F; f++) {
         if (l[f] < 0 || u[f] >= N || l[f] >= u[f]) {
             ffm_set_error("LDU addressing: face %d has l=%d u=%d (need 0<=l<u<nCells=%d)", f, l[f], u[f], N);
@@ -68,7 +79,37 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
     for (int c = 0; c < nOwn; c++) nLev = std::max(nLev, lev[c] + 1);
     if (nOwn == 0) nLev = 0;
     a.newToOldCell.resize(N); a.oldToNewCell.resize(N);
-    if (renumber) {
+    std::vector<int> grpOfOld;            // mode 1: group of every owned cell (caller numbering)
+    if (renumber && a.mode == 1) {
+        // Groups = contiguous chunks of the caller's cell order: the caller's order is a topological order of the DAG,
+        // so every cross-group dependency points from a lower to a higher group (the group graph is acyclic and the
+        // pipelined sweep cannot deadlock).
+        // Chunk size depends only on (cells, levels), so renumbering a mesh that is already in this order changes nothing:
+        // about 48 cells per level of the whole DAG (a chunk of a box spans roughly a third of the levels, which gives
+        // ~100-150 cells per level and group), at most 1024 groups.
+        int B = std::max(2048, 48 * std::max(nLev, 1));
+        if (const char *e = getenv("FFM_PIPE_GROUP_CELLS")) B = std::max(1, atoi(e));     // tests: force many small groups
+        int G = nOwn ? (nOwn + B - 1) / B : 0;
+        if (G > 1024) { B = (nOwn + 1023) / 1024; G = (nOwn + B - 1) / B; }
+        a.nGroups = G;
+        grpOfOld.resize(nOwn);
+        a.grpCell.assign(G + 1, 0);
+        for (int g = 0; g < G; g++) a.grpCell[g + 1] = std::min(nOwn, (g + 1) * B);
+        // inside a group: stable sort by level (then caller index)
+        std::vector<int> cntL;
+        for (int g = 0; g < G; g++) {
+            const int c0 = a.grpCell[g], c1 = a.grpCell[g + 1];
+            int lo = nLev, hi = 0;
+            for (int c = c0; c < c1; c++) { grpOfOld[c] = g; lo = std::min(lo, lev[c]); hi = std::max(hi, lev[c]); }
+            cntL.assign(hi - lo + 2, 0);
+            for (int c = c0; c < c1; c++) cntL[lev[c] - lo + 1]++;
+            for (size_t i = 1; i < cntL.size(); i++) cntL[i] += cntL[i - 1];
+            for (int c = c0; c < c1; c++) { const int p = c0 + cntL[lev[c] - lo]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
+        }
+        for (int c = nOwn; c < N; c++) { a.newToOldCell[c] = c; a.oldToNewCell[c] = c; }
+        a.fwdLevelStart.assign(nLev + 1, 0);
+    } else if (renumber) {
+        a.mode = 0;
         std::vector<int> start(nLev + 1, 0);
         for (int c = 0; c < nOwn; c++) start[lev[c] + 1]++;
         for (int i = 0; i < nLev; i++) start[i + 1] += start[i];
@@ -78,6 +119,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         for (int c = 0; c < nOwn; c++) { int p = pos[lev[c]]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
         for (int c = nOwn; c < N; c++) { a.newToOldCell[c] = c; a.oldToNewCell[c] = c; }
     } else {
+        a.mode = 0;
         // caller insists on its numbering: only legal if it is level-major already
         std::iota(a.newToOldCell.begin(), a.newToOldCell.end(), 0);
         a.oldToNewCell = a.newToOldCell;
@@ -132,6 +174,53 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         int s = a.bwdLevelStart[b], e = a.bwdLevelStart[b + 1];
         if (e > s && a.bwdOrder[e - 1] - a.bwdOrder[s] != e - s - 1) a.bwdContig = false;
     }
+    if (a.mode == 1) {
+        const int G = a.nGroups;
+        // forward entries: runs of equal level inside each group (new numbering is level-major inside a group)
+        a.fEntStart.assign(G + 1, 0);
+        for (int g = 0; g < G; g++) {
+            int prev = -1;
+            for (int c = a.grpCell[g]; c < a.grpCell[g + 1]; c++) {
+                const int L = lev[a.newToOldCell[c]];
+                if (L != prev) { a.fEntLevel.push_back(L); a.fEntCell.push_back(c); prev = L; }
+            }
+            a.fEntStart[g + 1] = (int)a.fEntLevel.size();
+        }
+        a.fEntCell.push_back(nOwn);
+        // fix the end of each group's last entry: fEntCell[e+1] of the last entry of g must be grpCell[g+1]; since groups are
+        // contiguous and entries are appended in cell order, fEntCell[e+1] is the first cell of the next group's first entry = grpCell[g+1]
+        // predecessors / successors between groups
+        std::vector<std::vector<int>> fp(G), bp(G);
+        auto grpOfNew = [&](int c) { return grpOfOld[a.newToOldCell[c]]; };
+        for (int f = 0; f < F; f++) {
+            if (a.u[f] >= nOwn) continue;
+            const int gl = grpOfNew(a.l[f]), gu = grpOfNew(a.u[f]);
+            if (gl != gu) { fp[gu].push_back(gl); bp[gl].push_back(gu); }
+        }
+        a.fPredStart.assign(G + 1, 0); a.bPredStart.assign(G + 1, 0);
+        for (int g = 0; g < G; g++) {
+            std::sort(fp[g].begin(), fp[g].end()); fp[g].erase(std::unique(fp[g].begin(), fp[g].end()), fp[g].end());
+            std::sort(bp[g].begin(), bp[g].end()); bp[g].erase(std::unique(bp[g].begin(), bp[g].end()), bp[g].end());
+            a.fPreds.insert(a.fPreds.end(), fp[g].begin(), fp[g].end()); a.fPredStart[g + 1] = (int)a.fPreds.size();
+            a.bPreds.insert(a.bPreds.end(), bp[g].begin(), bp[g].end()); a.bPredStart[g + 1] = (int)a.bPreds.size();
+            for (int q : fp[g]) if (q >= g) { ffm_set_error("internal: group graph not acyclic"); return FFM_ERR_ADDR; }
+        }
+        // backward order inside each group: by backward level, then descending cell index
+        a.bwdCells.resize(nOwn); a.bEntStart.assign(G + 1, 0); a.bwdIsReverse = true;
+        for (int g = 0; g < G; g++) {
+            const int c0 = a.grpCell[g], c1 = a.grpCell[g + 1];
+            for (int c = c0; c < c1; c++) a.bwdCells[c0 + (c1 - 1 - c)] = c;      // descending cell index
+            std::stable_sort(a.bwdCells.begin() + c0, a.bwdCells.begin() + c1, [&](int x, int y) { return bl[x] < bl[y]; });
+            int prev = -1;
+            for (int p = c0; p < c1; p++) {
+                if (a.bwdCells[p] != c1 - 1 - (p - c0)) a.bwdIsReverse = false;
+                const int L = bl[a.bwdCells[p]];
+                if (L != prev) { a.bEntLevel.push_back(L); a.bEntPos.push_back(p); prev = L; }
+            }
+            a.bEntStart[g + 1] = (int)a.bEntLevel.size();
+        }
+        a.bEntPos.push_back(nOwn);
+    }
     return FFM_OK;
 }
 
@@ -179,6 +268,7 @@ extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, con
     ffm_ldu *A = new ffm_ldu();
     A->ctx = ctx; A->nCells = N; A->nOwned = nOwn; A->nFaces = F; A->globalCells = nOwn;
     A->identity = a.identity; A->bwdContig = a.bwdContig;
+    A->sweepMode = a.mode; A->nGroups = a.nGroups; A->bwdIsReverse = a.bwdIsReverse;
     A->nLevels = (int)a.fwdLevelStart.size() - 1; if (A->nLevels < 0) A->nLevels = 0;
     A->nBwdLevels = (int)a.bwdLevelStart.size() - 1; if (A->nBwdLevels < 0) A->nBwdLevels = 0;
     A->h_fwdLevelStart = a.fwdLevelStart; A->h_bwdLevelStart = a.bwdLevelStart;
@@ -229,7 +319,7 @@ extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, con
             loEnt[q] = (a.l[f] << 4) | slotOfFace[f];
         }
     }
-    if (A->bwdContig) {
+    if (A->sweepMode == 0 && A->bwdContig) {
         // keep only the first cell of every backward level: ranges are [first, first+count)
         A->h_bwdFirstCell.resize(A->nBwdLevels);
         for (int b = 0; b < A->nBwdLevels; b++) {
@@ -244,7 +334,25 @@ extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, con
         if ((rc = upload(ctx, &A->upNbr, upNbr))) break;
         if ((rc = upload(ctx, &A->loEnt, loEnt))) break;
         if ((rc = upload(ctx, &A->faceSrc, faceSrc))) break;
-        if (!A->bwdContig && (rc = upload(ctx, &A->bwdOrder, a.bwdOrder))) break;
+        if (A->sweepMode == 0 && !A->bwdContig && (rc = upload(ctx, &A->bwdOrder, a.bwdOrder))) break;
+        if (A->sweepMode == 1) {
+            if ((rc = upload(ctx, &A->grpCell, a.grpCell))) break;
+            if ((rc = upload(ctx, &A->fEntStart, a.fEntStart))) break;
+            if ((rc = upload(ctx, &A->fEntLevel, a.fEntLevel))) break;
+            if ((rc = upload(ctx, &A->fEntCell, a.fEntCell))) break;
+            if ((rc = upload(ctx, &A->fPredStart, a.fPredStart))) break;
+            if ((rc = upload(ctx, &A->fPreds, a.fPreds))) break;
+            if ((rc = upload(ctx, &A->bEntStart, a.bEntStart))) break;
+            if ((rc = upload(ctx, &A->bEntLevel, a.bEntLevel))) break;
+            if ((rc = upload(ctx, &A->bEntPos, a.bEntPos))) break;
+            if ((rc = upload(ctx, &A->bPredStart, a.bPredStart))) break;
+            if ((rc = upload(ctx, &A->bPreds, a.bPreds))) break;
+            if ((rc = upload(ctx, &A->bwdCells, a.bwdCells))) break;
+            if (hipMalloc((void **)&A->pipeProgress, sizeof(unsigned long long) * std::max(A->nGroups, 1)) != hipSuccess ||
+                hipMalloc((void **)&A->pipeTicket, 2 * sizeof(unsigned int)) != hipSuccess) { rc = FFM_ERR_HIP; break; }
+            hipMemsetAsync(A->pipeProgress, 0, sizeof(unsigned long long) * std::max(A->nGroups, 1), ctx->stream);
+            hipMemsetAsync(A->pipeTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
+        }
         if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
         size_t nb = sizeof(double) * (size_t)std::max(N, 1), fb = sizeof(double) * (size_t)std::max(A->upTotal, 1);
         if (hipMalloc((void **)&A->diag, nb) != hipSuccess || hipMalloc((void **)&A->upper, fb) != hipSuccess ||
@@ -268,6 +376,9 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     for (int i = 0; i < 3; i++) hipFree(A->permIn[i]);
     hipFree(A->upOff); hipFree(A->loOff); hipFree(A->upNbr); hipFree(A->loEnt); hipFree(A->faceSrc);
     hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative);
+    hipFree(A->grpCell); hipFree(A->fEntStart); hipFree(A->fEntLevel); hipFree(A->fEntCell); hipFree(A->fPredStart); hipFree(A->fPreds);
+    hipFree(A->bEntStart); hipFree(A->bEntLevel); hipFree(A->bEntPos); hipFree(A->bPredStart); hipFree(A->bPreds); hipFree(A->bwdCells);
+    hipFree(A->pipeProgress); hipFree(A->pipeTicket);
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); if (A->ghSendBuf_h) hipHostFree(A->ghSendBuf_h); if (A->ghRecvBuf_h) hipHostFree(A->ghRecvBuf_h);
     hipFree(A->diag); hipFree(A->upper); hipFree(A->lowerBuf); hipFree(A->rD);
     hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);

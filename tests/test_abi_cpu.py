@@ -30,23 +30,33 @@ def test_no_gpu_means_loud_failure_not_fallback(ffm):
 
 
 def test_renumber_levels_host_logic(ffm, O):
-    """ffm_renumber_levels (pure host code): a level-major topological order, faces stay upper-triangular."""
+    """ffm_renumber_levels (pure host code): the library's preferred cell order is a topological order of the
+    owner->neighbour DAG (so DIC/DILU are unchanged), faces stay upper-triangular, and it is idempotent."""
     H = ffm.hexmesh
     n = (5, 4, 6)
     N, l, u = H.hex_ldu(*n)
     No, lo, uo = O.hex_ldu(*n)
     assert N == No and np.array_equal(l, lo) and np.array_equal(u, uo)     # product mesh tool == oracle mesh
-    cOrd, fOrd = ffm.renumber_levels(N, l, u)
-    assert sorted(cOrd) == list(range(N)) and sorted(fOrd) == list(range(len(l)))
-    l2, u2, oldToNew = H.apply_renumbering(N, l, u, cOrd, fOrd)
-    assert np.all(l2 < u2) and np.all(np.diff(l2) >= 0)
-    i, j, k = np.unravel_index(cOrd, (n[2], n[1], n[0]))[::-1]
-    lev = i + j + k
-    assert np.all(np.diff(lev) >= 0)                                        # hyperplanes i+j+k, level-major
-    same = np.diff(lev) == 0
-    assert np.all(np.diff(cOrd)[same] > 0)                                  # sorted by caller index inside a level
-    c3, f3 = ffm.renumber_levels(N, l2, u2)                                 # idempotent
-    assert np.array_equal(c3, np.arange(N)) and np.array_equal(f3, np.arange(len(l)))
+    for env in ("pipe", "levels"):
+        import os
+        if env:
+            os.environ["FFM_SWEEP"] = env
+        try:
+            cOrd, fOrd = ffm.renumber_levels(N, l, u)
+            assert sorted(cOrd) == list(range(N)) and sorted(fOrd) == list(range(len(l)))
+            l2, u2, oldToNew = H.apply_renumbering(N, l, u, cOrd, fOrd)
+            assert np.all(l2 < u2) and np.all(np.diff(l2) >= 0)                 # owner < neighbour kept, owner-sorted
+            same = l2[1:] == l2[:-1]
+            assert np.all(u2[1:][same] > u2[:-1][same])                         # upper-triangular order
+            c3, f3 = ffm.renumber_levels(N, l2, u2)                             # idempotent
+            assert np.array_equal(c3, np.arange(N)) and np.array_equal(f3, np.arange(len(l)))
+            if env == "levels":
+                i, j, k = np.unravel_index(cOrd, (n[2], n[1], n[0]))[::-1]
+                lev = i + j + k
+                assert np.all(np.diff(lev) >= 0)                                # hyperplanes i+j+k, level-major
+                assert np.all(np.diff(cOrd)[np.diff(lev) == 0] > 0)             # sorted by caller index inside a level
+        finally:
+            os.environ.pop("FFM_SWEEP", None)
 
 
 def test_bad_addressing_is_rejected(ffm):

@@ -23,9 +23,26 @@ def meshes(O):
     return out
 
 
-@pytest.fixture(scope="module", params=["hex_natural", "hex_levelmajor", "dag_random", "chain", "plane"])
+@pytest.fixture(scope="module", params=["hex_natural", "hex_levelmajor", "dag_random", "chain", "plane",
+                                        "hex_natural_g37", "dag_random_g23", "chain_g64", "plane_g50", "hex_levelmajor_g41"])
 def case(request, O, ffm, ctx):
+    """`_gNN` variants force the pipelined sweep to split the mesh into groups of NN cells, so that the cross-workgroup
+    hand-off (progress words, sc1 loads/stores, LDS ring wrap-around) is exercised on small meshes too."""
+    import os
     name = request.param
+    grp = None
+    if "_g" in name:
+        name, grp = name.rsplit("_g", 1)
+        os.environ["FFM_PIPE_GROUP_CELLS"] = grp
+        os.environ["FFM_SWEEP"] = "pipe"
+    try:
+        yield from _make_case(name, grp, O, ffm, ctx)
+    finally:
+        os.environ.pop("FFM_PIPE_GROUP_CELLS", None)
+        os.environ.pop("FFM_SWEEP", None)
+
+
+def _make_case(name, grp, O, ffm, ctx):
     if name == "hex_levelmajor":
         N, l, u = O.hex_ldu(9, 7, 8)
         cOrd, fOrd = ffm.renumber_levels(N, l, u)
@@ -33,7 +50,8 @@ def case(request, O, ffm, ctx):
     else:
         N, l, u = meshes(O)[name]
     A = ffm.lduMatrix(ctx, N, l, u)
-    assert A.native_order == (name in ("hex_levelmajor", "chain"))
+    if grp is None:
+        assert A.native_order == (name in ("hex_levelmajor", "chain"))
     yield name, N, l, u, A
     A.close()
 
