@@ -84,13 +84,14 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         // Groups = contiguous chunks of the caller's cell order: the caller's order is a topological order of the DAG,
         // so every cross-group dependency points from a lower to a higher group (the group graph is acyclic and the
         // pipelined sweep cannot deadlock).
-        // Chunk size depends only on (cells, levels), so renumbering a mesh that is already in this order changes nothing:
-        // about 48 cells per level of the whole DAG (a chunk of a box spans roughly a third of the levels, which gives
-        // ~100-150 cells per level and group), at most 1024 groups.
-        int B = std::max(2048, 48 * std::max(nLev, 1));
-        if (const char *e = getenv("FFM_PIPE_GROUP_CELLS")) B = std::max(1, atoi(e));     // tests: force many small groups
+        // The chunk size depends only on the cell count, so renumbering a mesh that is already in this order changes nothing.
+        // at most 512 groups (all workgroups must be able to stay resident together: 256 threads + a 32 KiB LDS ring each)
+        // and at least 8192 cells per group.  Measured on MI355X (200^3): the sweep time is very sensitive to this choice
+        // and collapses once the groups no longer fit on the chip together -- see DESIGN.md, the kernel is experimental.
+        int B = std::max(8192, (nOwn + 511) / 512);
         int G = nOwn ? (nOwn + B - 1) / B : 0;
-        if (G > 1024) { B = (nOwn + 1023) / 1024; G = (nOwn + B - 1) / B; }
+        if (const char *e = getenv("FFM_PIPE_GROUP_CELLS")) B = std::max(1, atoi(e));     // tests: force many small groups
+        G = nOwn ? (nOwn + B - 1) / B : 0;
         a.nGroups = G;
         grpOfOld.resize(nOwn);
         a.grpCell.assign(G + 1, 0);

@@ -60,7 +60,7 @@ __device__ __forceinline__ void wait_preds(const PipeView &pl, int p0, int p1, u
             unsigned spins = 0;
             val = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (val < need) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(16);
                 if ((++spins & 255u) == 0u) {
                     if (__hip_atomic_load(&pl.ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { *shAbort = 1; break; }
                     if (spins > SPIN_LIMIT) {
