@@ -78,6 +78,7 @@ struct LduView {
     const int *loEnt;           // [loTotal]
     int upW;                    // uniform upper width of every slice, or -1
     int loW;                    // uniform lower width of every slice, or -1
+    const int *sched; int nSched;   // XCD-aware chunk schedule of the row kernels (256 rows per chunk)
 };
 
 // first native face index of the slice of cell c
@@ -95,14 +96,16 @@ __device__ __forceinline__ int face_of(const LduView &v, int cell, int slot) { r
 // addresses (own cell, face 0) and are masked out of the arithmetic.
 template <int W> struct RowEnt { int nb[W]; int f[W]; bool on[W]; };
 
-template <int W>
+// NT: index streams are read once per kernel -- load them non-temporally so they do not evict the gather targets
+// (x, coefficients) from the XCD's L2
+template <int W, bool NT = false>
 __device__ __forceinline__ void load_lower(const LduView &v, int c, RowEnt<W> &R)
 {
     const int sl = c >> 6, lane = c & 63;
     const int lb = lo_base(v, sl), lw = lo_width(v, sl);
     int e[W];
 #pragma unroll
-    for (int s = 0; s < W; s++) e[s] = (s < lw) ? v.loEnt[lb + s * 64 + lane] : -1;
+    for (int s = 0; s < W; s++) e[s] = (s < lw) ? (NT ? __builtin_nontemporal_load(&v.loEnt[lb + s * 64 + lane]) : v.loEnt[lb + s * 64 + lane]) : -1;
 #pragma unroll
     for (int s = 0; s < W; s++) {
         R.on[s] = e[s] >= 0;
@@ -112,7 +115,7 @@ __device__ __forceinline__ void load_lower(const LduView &v, int c, RowEnt<W> &R
 }
 
 // MASK_GHOST: drop upper neighbours that are ghost cells (index >= v.N): block-Jacobi sweeps
-template <int W, bool MASK_GHOST = false>
+template <int W, bool MASK_GHOST = false, bool NT = false>
 __device__ __forceinline__ void load_upper(const LduView &v, int c, RowEnt<W> &R)
 {
     const int sl = c >> 6, lane = c & 63;
@@ -120,7 +123,7 @@ __device__ __forceinline__ void load_upper(const LduView &v, int c, RowEnt<W> &R
 #pragma unroll
     for (int s = 0; s < W; s++) {
         const int idx = ub + s * 64 + lane;
-        const int n = (s < uw) ? v.upNbr[idx] : -1;
+        const int n = (s < uw) ? (NT ? __builtin_nontemporal_load(&v.upNbr[idx]) : v.upNbr[idx]) : -1;
         R.on[s] = n >= 0 && (!MASK_GHOST || n < v.N);
         R.nb[s] = R.on[s] ? n : c;
         R.f[s] = R.on[s] ? idx : 0;

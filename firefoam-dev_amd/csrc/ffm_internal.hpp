@@ -121,6 +121,12 @@ struct ffm_ldu {
     double *diag = nullptr, *upper = nullptr, *lower = nullptr;  // lower==upper when symmetric
     double *lowerBuf = nullptr;                                  // storage for asymmetric lower
 
+    // XCD-aware row schedule of the row kernels: list of 256-row chunks; entry i is processed by a workgroup with
+    // blockIdx % 8 == i % 8, i.e. (observed round-robin dispatch) always on the same XCD, and chunks with the same i % 8
+    // cover the same eighth of every dependency level, so a row's neighbours in the adjacent levels were touched by the
+    // same XCD and are found in its L2.  Speed only; correctness does not depend on the placement.
+    int *rowSched = nullptr; int nSched = 0;
+
     // preconditioner state
     double *rD = nullptr;          // reciprocal diagonal (DIC/DILU/diagonal)
     int rDKind = -1;               // which preconditioner rD currently holds

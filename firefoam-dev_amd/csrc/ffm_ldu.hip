@@ -355,6 +355,29 @@ extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, con
             hipMemsetAsync(A->pipeTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
         }
         if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
+        {
+            // XCD-aware schedule (see ffm_internal.hpp): chunks of 256 rows, binned by the eighth of their dependency level
+            const int nChunks = (nOwn + 255) / 256;
+            std::vector<std::vector<int>> seq(8);
+            if (A->sweepMode == 0 && A->nLevels > 0) {
+                int L = 0;
+                for (int ch = 0; ch < nChunks; ch++) {
+                    const int c0 = ch * 256;
+                    while (L + 1 < A->nLevels && a.fwdLevelStart[L + 1] <= c0) L++;
+                    const long ls = a.fwdLevelStart[L], le = a.fwdLevelStart[L + 1];
+                    int eighth = (le > ls) ? (int)(8L * (c0 - ls) / (le - ls)) : 0;
+                    seq[std::min(std::max(eighth, 0), 7)].push_back(ch);
+                }
+            } else {
+                for (int ch = 0; ch < nChunks; ch++) seq[ch & 7].push_back(ch);
+            }
+            size_t mx = 0;
+            for (auto &q : seq) mx = std::max(mx, q.size());
+            std::vector<int> sched(mx * 8, -1);
+            for (int x = 0; x < 8; x++) for (size_t k = 0; k < seq[x].size(); k++) sched[k * 8 + x] = seq[x][k];
+            A->nSched = (int)sched.size();
+            if ((rc = upload(ctx, &A->rowSched, sched))) break;
+        }
         size_t nb = sizeof(double) * (size_t)std::max(N, 1), fb = sizeof(double) * (size_t)std::max(A->upTotal, 1);
         if (hipMalloc((void **)&A->diag, nb) != hipSuccess || hipMalloc((void **)&A->upper, fb) != hipSuccess ||
             hipMalloc((void **)&A->rD, nb) != hipSuccess) { ffm_set_error("ffm_ldu_create: hipMalloc failed"); rc = FFM_ERR_HIP; break; }
@@ -379,7 +402,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative);
     hipFree(A->grpCell); hipFree(A->fEntStart); hipFree(A->fEntLevel); hipFree(A->fEntCell); hipFree(A->fPredStart); hipFree(A->fPreds);
     hipFree(A->bEntStart); hipFree(A->bEntLevel); hipFree(A->bEntPos); hipFree(A->bPredStart); hipFree(A->bPreds); hipFree(A->bwdCells);
-    hipFree(A->pipeProgress); hipFree(A->pipeTicket);
+    hipFree(A->pipeProgress); hipFree(A->pipeTicket); hipFree(A->rowSched);
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); if (A->ghSendBuf_h) hipHostFree(A->ghSendBuf_h); if (A->ghRecvBuf_h) hipHostFree(A->ghRecvBuf_h);
     hipFree(A->diag); hipFree(A->upper); hipFree(A->lowerBuf); hipFree(A->rD);
     hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);
@@ -518,7 +541,7 @@ extern "C" int ffm_ldu_set_coeffs_native_d(ffm_ldu *A, const double *diag_d, con
 LduView ffm_view(const ffm_ldu *A)
 {
     LduView v; v.N = A->nOwned; v.upOff = A->upOff; v.loOff = A->loOff; v.upNbr = A->upNbr; v.loEnt = A->loEnt;
-    v.upW = A->upWidthUniform; v.loW = A->loWidthUniform;
+    v.upW = A->upWidthUniform; v.loW = A->loWidthUniform; v.sched = A->rowSched; v.nSched = A->nSched;
     return v;
 }
 
@@ -535,11 +558,13 @@ __global__ __launch_bounds__(256) void k_rows(LduView v, const double *__restric
 {
     __shared__ double sm[4];
     double dot = 0.0;
-    const int stride = gridDim.x * blockDim.x;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < v.N; c += stride) {
+    for (int it = blockIdx.x; it < v.nSched; it += gridDim.x) {
+        const int chunk = v.sched[it];
+        const int c = chunk * 256 + (int)threadIdx.x;
+        if (chunk < 0 || c >= v.N) continue;
         RowEnt<W> L, U;
-        load_lower<W>(v, c, L);
-        load_upper<W>(v, c, U);
+        load_lower<W, true>(v, c, L);
+        load_upper<W, false, true>(v, c, U);
         double al[W], au[W], xl[W], xu[W];
 #pragma unroll
         for (int s = 0; s < W; s++) { al[s] = lower[L.f[s]]; au[s] = upper[U.f[s]]; }
@@ -549,9 +574,10 @@ __global__ __launch_bounds__(256) void k_rows(LduView v, const double *__restric
         }
         double xc = 0.0, acc;
         if (MODE != 2) xc = x[c];
-        if (MODE == 0) acc = diag[c] * xc;
-        else if (MODE == 1) acc = b[c] - diag[c] * xc;
-        else acc = diag[c];
+        const double dc = __builtin_nontemporal_load(&diag[c]);
+        if (MODE == 0) acc = dc * xc;
+        else if (MODE == 1) acc = __builtin_nontemporal_load(&b[c]) - dc * xc;
+        else acc = dc;
 #pragma unroll
         for (int s = 0; s < W; s++) if (L.on[s]) {
             if (MODE == 0) acc += al[s] * xl[s];
@@ -564,7 +590,7 @@ __global__ __launch_bounds__(256) void k_rows(LduView v, const double *__restric
             else if (MODE == 1) acc -= au[s] * xu[s];
             else acc += au[s];
         }
-        y[c] = acc;
+        __builtin_nontemporal_store(acc, &y[c]);
         if (DOT) dot += acc * xc;
     }
     if (DOT) {
@@ -582,7 +608,12 @@ __global__ __launch_bounds__(1024) void k_sum_partials(int n, const double *__re
     if (threadIdx.x == 0) scal[slot] = r;
 }
 
-static inline int rows_grid(const ffm_ldu *A) { return stream_grid(A->nOwned); }
+// grid of the row kernels: a multiple of 8 so that schedule entry i always meets blockIdx % 8 == i % 8
+static inline int rows_grid(const ffm_ldu *A)
+{
+    static const int cap = getenv("FFM_ROWS_GRID") ? std::min(atoi(getenv("FFM_ROWS_GRID")), RED_BLOCKS) : RED_BLOCKS;
+    int g = std::min(A->nSched, cap); g = (g + 7) & ~7; return std::max(g, 8);
+}
 
 int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
 {
