@@ -9,6 +9,6 @@ fallback: every compute entry point needs libffm.so and a GPU.
 """
 from .binding import (  # noqa: F401
     Context, lduMatrix, FfmError, lib, build, libpath, SOLVERS, PRECONDS,
-    renumber_levels, exported_symbols, declared_symbols, Plume,
+    renumber_levels, exported_symbols, declared_symbols, Plume, fvMesh,
 )
 from . import hexmesh  # noqa: F401

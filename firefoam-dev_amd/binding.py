@@ -121,6 +121,28 @@ def lib():
         "ffm_reduce_max": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_dot": ([vp, dp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_summag": ([vp, dp, C.c_long, hp], C.c_int),
+        "ffm_mesh_create": ([vp, hp, hp, hp, hp, hp, hp, C.c_int, ip, C.POINTER(ip), C.POINTER(hp), C.POINTER(hp), C.POINTER(vp)], C.c_int),
+        "ffm_mesh_destroy": ([vp], C.c_int),
+        "ffm_mesh_nboundary": ([vp], C.c_int),
+        "ffm_mesh_nnative": ([vp], C.c_int),
+        "ffm_faces_to_native": ([vp, hp, dp], C.c_int),
+        "ffm_faces_from_native": ([vp, dp, hp], C.c_int),
+        "ffm_fvc_interpolate": ([vp, dp, dp, dp], C.c_int),
+        "ffm_fvc_snGrad": ([vp, dp, dp], C.c_int),
+        "ffm_fvc_snGrad_b": ([vp, dp, dp, dp], C.c_int),
+        "ffm_fvc_flux": ([vp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvc_surface_integrate": ([vp, dp, dp, dp], C.c_int),
+        "ffm_fvc_surface_sum": ([vp, dp, dp, dp], C.c_int),
+        "ffm_fvc_grad": ([vp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvc_reconstruct": ([vp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fv_limited_weights": ([vp, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvm_transport": ([vp, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp, dp], C.c_int),
+        "ffm_fvm_boundary_coeffs": ([vp, dp, dp, C.c_int, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_bc_values": ([vp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvm_add_boundary": ([vp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvm_A": ([vp, C.c_int, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvm_H": ([vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvm_flux": ([vp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_plume_create": ([vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(vp)], C.c_int),
         "ffm_plume_destroy": ([vp], C.c_int),
         "ffm_plume_step": ([vp], C.c_int),
@@ -456,3 +478,59 @@ class Plume:
 
     def ldu_handle(self):
         return lib().ffm_plume_ldu(self.h)
+
+
+class fvMesh:
+    """Device fvMesh over an lduMatrix in the library's cell order (ffm_mesh_*): geometry in LDU face order on input,
+    face fields converted with to_native/from_native.  Thin wrapper for the operator-level parity tests."""
+
+    def __init__(self, ldu, V, C_, Sf, magSf, weights, deltaCoeffs, patches):
+        """patches: list of (faceCells[int32], Sf[3][n], deltaCoeffs[n])"""
+        self.ldu, self.ctx = ldu, ldu.ctx
+        f64 = lambda a: np.ascontiguousarray(a, np.float64)
+        V, C_, Sf, magSf, weights, deltaCoeffs = map(f64, (V, C_, Sf, magSf, weights, deltaCoeffs))
+        n = len(patches)
+        fc = [np.ascontiguousarray(p[0], np.int32) for p in patches]
+        ps = [f64(p[1]) for p in patches]
+        pd = [f64(p[2]) for p in patches]
+        sizes = (C.c_int * n)(*[len(a) for a in fc])
+        fcp = (C.POINTER(C.c_int) * n)(*[_ip(a) for a in fc])
+        psp = (C.POINTER(C.c_double) * n)(*[_hp(a) for a in ps])
+        pdp = (C.POINTER(C.c_double) * n)(*[_hp(a) for a in pd])
+        h = C.c_void_p()
+        _check(lib().ffm_mesh_create(ldu.h, _hp(V), _hp(C_), _hp(Sf), _hp(magSf), _hp(weights), _hp(deltaCoeffs), n, sizes, fcp, psp, pdp,
+                                     C.byref(h)), "ffm_mesh_create")
+        self.h = h
+        self.nNative = lib().ffm_mesh_nnative(h)
+        self.nBoundary = lib().ffm_mesh_nboundary(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ffm_mesh_destroy(self.h)
+            self.h = None
+
+    def to_native(self, faceField):
+        out = self.ctx.zeros(max(self.nNative, 1))
+        a = np.ascontiguousarray(faceField, np.float64)
+        _check(lib().ffm_faces_to_native(self.h, _hp(a), C.c_void_p(out.data_ptr())), "ffm_faces_to_native")
+        return out
+
+    def from_native(self, t):
+        self.ctx._ready()
+        out = np.empty(self.ldu.nFaces)
+        _check(lib().ffm_faces_from_native(self.h, C.c_void_p(t.data_ptr()), _hp(out)), "ffm_faces_from_native")
+        return out
+
+    def call(self, name, *args):
+        """ffm_<name>(mesh, *args): torch tensors -> device pointers, None -> NULL, numbers as is."""
+        self.ctx._ready()
+        conv = []
+        for a in args:
+            if a is None:
+                conv.append(None)
+            elif hasattr(a, "data_ptr"):
+                conv.append(C.c_void_p(a.data_ptr()))
+            else:
+                conv.append(a)
+        _check(getattr(lib(), "ffm_" + name)(self.h, *conv), "ffm_" + name)
+        self.ctx.sync()

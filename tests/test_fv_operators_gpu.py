@@ -1,0 +1,161 @@
+"""Operator-level parity of the fvc:: / fvm:: kernels through the C ABI against the numpy
+restatement oracle/fv.py, on a hex box with four patches and hashed fields.  Bars: interpolate, snGrad, flux,
+surfaceIntegrate, grad, limiter weights, matrix coefficients, boundary coefficients, A/H/flux accumulate in the
+reference's face order with FMA contraction off -> compared at 1e-14 relative (bitwise where the oracle's numpy
+expression order is identical); reconstruct inverts the cell tensor analytically (oracle: LAPACK) -> 1e-13."""
+import numpy as np
+import pytest
+
+from common import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(O, ffm, ctx):
+    from oracle import fv, plume
+    m = plume.make_mesh((7, 6, 5), h=0.1)
+    N, F = m.nCells, m.nFaces
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    assert A.native_order
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    yield dict(fv=fv, m=m, A=A, mesh=mesh, cOrd=cOrd, fOrd=fOrd, N=N, F=F, B=sum(p.size for p in m.patches))
+    mesh.close(); A.close()
+
+
+def cellf(s, ctx, a): return ctx.to_device(np.asarray(a)[s["cOrd"]])
+def facef(s, a): return s["mesh"].to_native(np.asarray(a)[s["fOrd"]])
+def bndf(ctx, lst): return ctx.to_device(np.concatenate(lst))
+def back_cell(s, t): out = np.empty(s["N"]); out[s["cOrd"]] = t.cpu().numpy(); return out
+def back_face(s, t): out = np.empty(s["F"]); out[s["fOrd"]] = s["mesh"].from_native(t); return out
+
+
+def fields(s, O):
+    N, F, m = s["N"], s["F"], s["m"]
+    vf = 0.2 + O.hash_u(31, np.arange(N))
+    phi = 0.3 * (O.hash_u(32, np.arange(F)) - 0.5)
+    vb = [0.1 + O.hash_u(33 + q, np.arange(p.size)) for q, p in enumerate(m.patches)]
+    return vf, phi, vb
+
+
+def test_fvc_operators(setup, O, ctx):
+    s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
+    vf, phi, vb = fields(s, O)
+    vfd, vbd = cellf(s, ctx, vf), bndf(ctx, vb)
+    out_f = ctx.zeros(mesh.nNative)
+    mesh.call("fvc_interpolate", None, vfd, out_f)
+    assert np.array_equal(back_face(s, out_f), fv.interpolate(m, vf, vb)[0])
+    mesh.call("fvc_snGrad", vfd, out_f)
+    sg, sgb = fv.snGrad(m, vf, vb)
+    assert np.array_equal(back_face(s, out_f), sg)
+    out_b = ctx.zeros(s["B"])
+    mesh.call("fvc_snGrad_b", vfd, vbd, out_b)
+    assert np.array_equal(out_b.cpu().numpy(), np.concatenate(sgb))
+    # surfaceIntegrate / surfaceSum
+    out_c = ctx.zeros(s["N"])
+    ssb = [0.05 * (O.hash_u(40 + q, np.arange(p.size)) - 0.5) for q, p in enumerate(m.patches)]
+    mesh.call("fvc_surface_integrate", facef(s, phi), bndf(ctx, ssb), out_c)
+    assert rel_l2(back_cell(s, out_c), fv.surface_integrate(m, phi, ssb)) < 1e-15
+    mesh.call("fvc_surface_sum", facef(s, phi), bndf(ctx, ssb), out_c)
+    assert rel_l2(back_cell(s, out_c), fv.surface_sum(m, phi, ssb)) < 1e-15
+    # grad
+    g = [ctx.zeros(s["N"]) for _ in range(3)]
+    mesh.call("fvc_grad", vfd, vbd, *g)
+    ref = fv.grad(m, vf, vb)
+    for d in range(3):
+        assert rel_l2(back_cell(s, g[d]), ref[:, d]) < 1e-14
+    # reconstruct
+    mesh.call("fvc_reconstruct", facef(s, phi), bndf(ctx, ssb), *g)
+    ref = fv.reconstruct(m, phi, ssb)
+    for d in range(3):
+        assert rel_l2(back_cell(s, g[d]), ref[:, d]) < 1e-13
+    # flux of a vector field
+    U = np.stack([O.hash_u(50 + d, np.arange(s["N"])) - 0.5 for d in range(3)])
+    mesh.call("fvc_flux", *[cellf(s, ctx, U[d]) for d in range(3)], out_f)
+    ref = sum(fv.interpolate(m, U[d], [np.zeros(p.size) for p in m.patches])[0] * m.Sf[:, d] for d in range(3))
+    assert rel_l2(back_face(s, out_f), ref) < 1e-15
+
+
+@pytest.mark.parametrize("scheme,code", [("upwind", 0), ("linear", 1), ("limitedLinear", 2), ("limitedLinear01", 3)])
+def test_limited_weights(setup, O, ctx, scheme, code):
+    s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
+    vf, phi, vb = fields(s, O)
+    if scheme == "limitedLinear01":
+        vf = vf * 1.1 - 0.2                      # some values outside [0,1] to exercise the bound test
+    grad = fv.grad(m, vf, vb)
+    w = ctx.zeros(mesh.nNative)
+    mesh.call("fv_limited_weights", code, 1.0, 0.0, 1.0, facef(s, phi), cellf(s, ctx, vf), *[cellf(s, ctx, grad[:, d]) for d in range(3)], w)
+    ref = fv.limited_weights(m, scheme, phi, vf, grad, 1.0)
+    got = back_face(s, w)
+    assert np.abs(got - ref).max() < 1e-13
+    assert got.min() >= 0.0 and got.max() <= 1.0
+
+
+def test_limiter_unit_vectors(O):
+    """T6: hand-computed 1-D stencils of limitedLinear(1): r = 2*(d.gradP)/(N-P) - 1, limiter = clamp(2r, 0, 1)."""
+    from oracle import fv
+    m = fv.HexMesh((4, 1, 1), (0, 0, 0), (4, 1, 1)).set_patches([])
+    vf = np.array([0.0, 1.0, 2.0, 3.0])                  # linear profile: centred gradient = downwind gradient -> r = 1 -> limiter 1
+    g = np.zeros((4, 3)); g[:, 0] = 1.0
+    w = fv.limited_weights(m, "limitedLinear", np.array([1.0, 1.0, 1.0]), vf, g, 1.0)
+    assert np.allclose(w, 0.5)                           # pure linear
+    vf = np.array([0.0, 0.0, 1.0, 1.0]); g[:, 0] = [0.0, 0.5, 0.5, 0.0]
+    w = fv.limited_weights(m, "limitedLinear", np.array([1.0, 1.0, 1.0]), vf, g, 1.0)
+    # face 1|2: gradf = 1, gradcf = d.gradP = 0.5 -> r = 0 -> limiter 0 -> upwind weight 1
+    assert w[1] == 1.0
+    w = fv.limited_weights(m, "limitedLinear", np.array([-1.0, -1.0, -1.0]), vf, g, 1.0)
+    assert w[1] == 0.0                                   # reversed flux: upwind = neighbour
+    # limitedLinear01: value out of [0,1] on the upwind side switches to upwind
+    vf = np.array([0.0, 1.2, 1.0, 1.0]); g[:, 0] = 0.3
+    w = fv.limited_weights(m, "limitedLinear01", np.array([1.0, 1.0, 1.0]), vf, g, 1.0)
+    assert w[1] == 1.0
+
+
+def test_fvm_assembly_and_matrix_ops(setup, O, ctx):
+    s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
+    N, F, B = s["N"], s["F"], s["B"]
+    vf, phi, vb = fields(s, O)
+    rho = 1.0 + O.hash_u(60, np.arange(N)); rho0 = 1.0 + O.hash_u(61, np.arange(N)); vf0 = O.hash_u(62, np.arange(N))
+    gam = 0.01 * (1 + O.hash_u(63, np.arange(F))); gamb = [0.01 * (1 + O.hash_u(64 + q, np.arange(p.size))) for q, p in enumerate(m.patches)]
+    phib = [0.2 * (O.hash_u(70 + q, np.arange(p.size)) - 0.5) for q, p in enumerate(m.patches)]
+    w = fv.limited_weights(m, "limitedLinear", phi, vf, fv.grad(m, vf, vb), 1.0)
+    bc = fv.MixedBC(m)
+    for q, p in enumerate(m.patches):
+        bc.f[q] = np.round(O.hash_u(80 + q, np.arange(p.size)) * 2) / 2          # 0, 0.5, 1
+        bc.ref[q] = O.hash_u(84 + q, np.arange(p.size)); bc.refGrad[q] = O.hash_u(88 + q, np.arange(p.size)) - 0.5
+    rdt = 1000.0
+    M = fv.fvm_ddt(m, rdt, rho, rho0, vf0)
+    M += fv.fvm_div(m, phi, phib, w, [bc])
+    M -= fv.fvm_laplacian(m, gam, gamb, [bc])
+    diag, up, lo = ctx.zeros(N), ctx.zeros(mesh.nNative), ctx.zeros(mesh.nNative)
+    mesh.call("fvm_transport", rdt, cellf(s, ctx, rho), facef(s, phi), facef(s, w), facef(s, gam), -1, diag, up, lo)
+    assert np.array_equal(back_face(s, up), M.upper) and np.array_equal(back_face(s, lo), M.lower)
+    assert rel_l2(back_cell(s, diag), M.diag) < 1e-15
+    ic, bcc = ctx.zeros(B), ctx.zeros(B)
+    fd, rd, gd = bndf(ctx, bc.f), bndf(ctx, bc.ref), bndf(ctx, bc.refGrad)
+    mesh.call("fvm_boundary_coeffs", bndf(ctx, phib), bndf(ctx, gamb), -1, fd, rd, gd, ic, bcc)
+    assert rel_l2(ic.cpu().numpy(), np.concatenate([a[0] for a in M.internalCoeffs])) < 1e-15
+    assert rel_l2(bcc.cpu().numpy(), np.concatenate([a[0] for a in M.boundaryCoeffs])) < 1e-15
+    vbd = ctx.zeros(B)
+    mesh.call("bc_values", fd, rd, gd, cellf(s, ctx, vf), vbd)
+    assert np.array_equal(vbd.cpu().numpy(), np.concatenate(bc.values(m, vf)))
+    # solve_system (addBoundaryDiag/Source), A, H, flux
+    srcd = cellf(s, ctx, M.source[0])
+    d2, s2 = ctx.zeros(N), ctx.zeros(N)
+    mesh.call("fvm_add_boundary", ic, bcc, diag, srcd, None, d2, s2)
+    dref, sref = M.solve_system()
+    assert rel_l2(back_cell(s, d2), dref) < 1e-15 and rel_l2(back_cell(s, s2), sref) < 1e-15
+    outA = ctx.zeros(N)
+    mesh.call("fvm_A", 1, diag, ic, ic, ic, outA)
+    assert rel_l2(back_cell(s, outA), M.A()) < 1e-15
+    psi = O.hash_u(90, np.arange(N))
+    outH = ctx.zeros(N)
+    mesh.call("fvm_H", 1, 0, up, lo, srcd, ic, ic, ic, bcc, cellf(s, ctx, psi), outH)
+    assert rel_l2(back_cell(s, outH), M.H(psi[None, :])[0]) < 1e-14
+    ff, fb = ctx.zeros(mesh.nNative), ctx.zeros(B)
+    mesh.call("fvm_flux", up, lo, ic, bcc, cellf(s, ctx, psi), ff, fb)
+    fi, fbr = M.flux(psi)
+    assert np.array_equal(back_face(s, ff), fi) and rel_l2(fb.cpu().numpy(), np.concatenate(fbr)) < 1e-15
