@@ -109,8 +109,17 @@ def main():
         raise SystemExit("ffm_bench_spmv failed: %s" % L.ffm_last_error().decode())
     alg_bytes = 24 * Nloc + 16 * Floc           # this rank's rows (N > 1: the timing then includes the halo refresh)
     achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+    # L2-side traffic per launch from the committed PMC passes (profiles/spmv_traffic.json); only quoted for the configuration
+    # it was measured on (rocprofv3 cannot wrap the bench's own timed region)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "spmv_traffic.json")))
+        if tj["edge"] == n and tj["n_gpus"] == world:
+            traffic = tj["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "k_rows<0,*> (lduMatrix::Amul, symmetric p_rgh matrix)", "achieved": round(achieved, 1),
-                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(ms.value, 5)}
 
     cpu = None
