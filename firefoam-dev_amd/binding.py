@@ -158,6 +158,8 @@ def lib():
         "ffm_comm_init_host": ([vp, C.c_int, C.c_int, vp, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN], C.c_int),
         "ffm_comm_set_host_exchange2": ([vp, HOST_EXCHANGE2_FN], C.c_int),
         "ffm_plume_create_block": ([vp, C.c_int, C.c_int, C.c_int, ip, ip, ip, C.c_double, C.c_double, C.POINTER(vp)], C.c_int),
+        "ffm_ldu_create_hint": ([vp, C.c_int, C.c_int, C.c_int, ip, ip, ip, C.POINTER(vp)], C.c_int),
+        "ffm_renumber_hint": ([C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip], C.c_int),
         "ffm_ldu_create_ext": ([vp, C.c_int, C.c_int, C.c_int, ip, ip, C.POINTER(vp)], C.c_int),
         "ffm_renumber_levels_ext": ([C.c_int, C.c_int, C.c_int, ip, ip, ip, ip], C.c_int),
         "ffm_ldu_set_ghost_exchange": ([vp, C.c_int, ip, ip, ip, ip], C.c_int),
@@ -186,13 +188,17 @@ def _hp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def renumber_levels(nCells, lowerAddr, upperAddr):
-    """Level-major renumbering (pure host code in libffm): returns (newToOldCell, newToOldFace)."""
+def renumber_levels(nCells, lowerAddr, upperAddr, groupHint=None):
+    """The library's preferred cell order (pure host code in libffm): returns (newToOldCell, newToOldFace)."""
     l = np.ascontiguousarray(lowerAddr, np.int32)
     u = np.ascontiguousarray(upperAddr, np.int32)
     c2 = np.empty(nCells, np.int32)
     f2 = np.empty(len(l), np.int32)
-    _check(lib().ffm_renumber_levels(nCells, len(l), _ip(l), _ip(u), _ip(c2), _ip(f2)), "ffm_renumber_levels")
+    if groupHint is None:
+        _check(lib().ffm_renumber_levels(nCells, len(l), _ip(l), _ip(u), _ip(c2), _ip(f2)), "ffm_renumber_levels")
+    else:
+        gh = np.ascontiguousarray(groupHint, np.int32)
+        _check(lib().ffm_renumber_hint(nCells, 0, len(l), _ip(l), _ip(u), _ip(gh), _ip(c2), _ip(f2)), "ffm_renumber_hint")
     return c2, f2
 
 
@@ -297,12 +303,16 @@ class Context:
 class lduMatrix:
     """Device lduMatrix over lduAddressing (lowerAddr, upperAddr)."""
 
-    def __init__(self, ctx, nCells, lowerAddr, upperAddr):
+    def __init__(self, ctx, nCells, lowerAddr, upperAddr, groupHint=None):
         self.ctx = ctx
         l = np.ascontiguousarray(lowerAddr, np.int32)
         u = np.ascontiguousarray(upperAddr, np.int32)
         h = C.c_void_p()
-        _check(lib().ffm_ldu_create(ctx.h, int(nCells), len(l), _ip(l), _ip(u), C.byref(h)), "ffm_ldu_create")
+        if groupHint is None:
+            _check(lib().ffm_ldu_create(ctx.h, int(nCells), len(l), _ip(l), _ip(u), C.byref(h)), "ffm_ldu_create")
+        else:
+            gh = np.ascontiguousarray(groupHint, np.int32)
+            _check(lib().ffm_ldu_create_hint(ctx.h, int(nCells), 0, len(l), _ip(l), _ip(u), _ip(gh), C.byref(h)), "ffm_ldu_create_hint")
         self.h = h
         self.nCells, self.nFaces = int(nCells), len(l)
 

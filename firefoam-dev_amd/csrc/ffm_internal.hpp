@@ -12,6 +12,7 @@
 #include "../../include/ffm.h"
 
 struct ncclComm;
+struct ffm_tile_plan;
 
 void ffm_set_error(const char *fmt, ...);
 
@@ -115,6 +116,7 @@ struct ffm_ldu {
     int *cellPerm = nullptr;                     // [N] new->old (only when !identity)
     int *faceSrc = nullptr;                      // [upTotal] native face -> caller face id (-1 padding)
     std::vector<int> h_callerToNative;           // [F] caller face id -> native face index
+    std::vector<int> h_upOff, h_loOff, h_loEnt, h_upNbr;   // host copies for the sweep planners (entries freed after use)
     int *callerToNative = nullptr;               // device copy (on demand)
 
     // coefficients (internal numbering / native face index)
@@ -167,6 +169,7 @@ struct ffm_ldu {
     int *bwdCells = nullptr;        // [nOwned] cells in (group, backward level) order
     unsigned long long *pipeProgress = nullptr;   // [G] (epoch<<32 | levels done)
     unsigned int *pipeTicket = nullptr;           // [2]: ticket counter, abort flag
+    ffm_tile_plan *tile = nullptr;                // tiled wavefront plan (sweepMode == 2)
 
     // cached hipGraphs of level-scheduled sweeps
     std::map<SweepGraphKey, hipGraphExec_t> graphs;
@@ -189,6 +192,11 @@ int ffm_allreduce_minmax(ffm_ctx *ctx, int slot, int isMax);
 void ffm_comm_finalize_i(ffm_ctx *ctx);
 int ffm_precond_setup_i(ffm_ldu *A, int precond);
 int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
+int ffm_tile_build(ffm_ldu *A, const std::vector<int> &l, const std::vector<int> &u, const std::vector<int> &lev,
+                   const std::vector<int> &bl, const std::vector<int> &grpCell);
+void ffm_tile_free(ffm_ldu *A);
+bool ffm_tile_usable(const ffm_ldu *A);
+int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
 int ffm_pipe_calc_rD(ffm_ldu *A);
 int ffm_pipe_precond(ffm_ldu *A, const double *cf, const double *cb, const double *r, double *w);
 int ffm_pipe_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSave);

@@ -45,20 +45,26 @@ struct LduAnalysis {
     bool identity = true, bwdContig = true;
     // pipelined-sweep plan (mode 1)
     int mode = 0, nGroups = 0; bool bwdIsReverse = false;
+    std::vector<int> levNew, blNew;         // forward / backward level of every owned cell (new numbering)
     std::vector<int> grpCell, fEntStart, fEntLevel, fEntCell, fPredStart, fPreds, bEntStart, bEntLevel, bEntPos, bPredStart, bPreds, bwdCells;
 };
 
-// FFM_SWEEP=pipe selects the pipelined group sweep (ffm_pipe.hip); default is one launch per dependency level
+// FFM_SWEEP=levels: one launch per dependency level (level-major numbering); =pipe: pipelined group sweep with per-level
+// hand-off (ffm_pipe.hip, experimental); =tile: tiled wavefront sweep with batched hand-off (ffm_tile.hip)
 static int default_sweep_mode()
 {
     const char *e = getenv("FFM_SWEEP");
-    return (e && (e[0] == 'p' || e[0] == 'P' || e[0] == '1')) ? 1 : 0;
+    if (!e) return 0;
+    if (e[0] == 'p' || e[0] == 'P' || e[0] == '1') return 1;
+    if (e[0] == 't' || e[0] == 'T' || e[0] == '2') return 2;
+    return 0;
 }
 
 // nOwn < N: cells [nOwn, N) are ghost cells (copies of neighbour-rank cells).  They own no faces, stay at the end of the
 // numbering in their given order, take no part in the level structure, and faces towards them are ignored by the
 // backward levels (block-Jacobi sweeps).
-static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renumber, bool sortByNewNeighbour, LduAnalysis &a)
+static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renumber, bool sortByNewNeighbour, LduAnalysis &a,
+                   const int *groupHint = nullptr)
 {
     a.mode = default_sweep_mode();
     for (int f = 0; f < F; f++) {
@@ -80,32 +86,59 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
     if (nOwn == 0) nLev = 0;
     a.newToOldCell.resize(N); a.oldToNewCell.resize(N);
     std::vector<int> grpOfOld;            // mode 1: group of every owned cell (caller numbering)
-    if (renumber && a.mode == 1) {
-        // Groups = contiguous chunks of the caller's cell order: the caller's order is a topological order of the DAG,
-        // so every cross-group dependency points from a lower to a higher group (the group graph is acyclic and the
-        // pipelined sweep cannot deadlock).
-        // The chunk size depends only on the cell count, so renumbering a mesh that is already in this order changes nothing.
-        // at most 512 groups (all workgroups must be able to stay resident together: 256 threads + a 32 KiB LDS ring each)
-        // and at least 8192 cells per group.  Measured on MI355X (200^3): the sweep time is very sensitive to this choice
-        // and collapses once the groups no longer fit on the chip together -- see DESIGN.md, the kernel is experimental.
-        int B = std::max(8192, (nOwn + 511) / 512);
-        int G = nOwn ? (nOwn + B - 1) / B : 0;
-        if (const char *e = getenv("FFM_PIPE_GROUP_CELLS")) B = std::max(1, atoi(e));     // tests: force many small groups
-        G = nOwn ? (nOwn + B - 1) / B : 0;
+    if (renumber && a.mode >= 1) {
+        // Groups.  With a hint (one label per owned cell, e.g. a 2-D tile of cell columns computed by the host from the cell
+        // centres) the groups are the label classes, provided their dependency graph is acyclic; they are then ranked in a
+        // topological order (ties by label).  Without a usable hint: contiguous chunks of the caller's cell order, which is
+        // a topological order of the DAG, so cross-group dependencies point from lower to higher groups by construction.
+        grpOfOld.assign(nOwn, 0);
+        int G = 0;
+        bool hinted = false;
+        if (groupHint && nOwn > 0) {
+            std::vector<int> labels(groupHint, groupHint + nOwn);
+            std::sort(labels.begin(), labels.end()); labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+            const int nl = (int)labels.size();
+            auto idOf = [&](int lab) { return (int)(std::lower_bound(labels.begin(), labels.end(), lab) - labels.begin()); };
+            std::vector<int> gid(nOwn);
+            for (int c = 0; c < nOwn; c++) gid[c] = idOf(groupHint[c]);
+            std::vector<std::pair<int, int>> edges;
+            for (int f = 0; f < F; f++) if (u[f] < nOwn && gid[l[f]] != gid[u[f]]) edges.emplace_back(gid[l[f]], gid[u[f]]);
+            std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+            std::vector<int> indeg(nl, 0), estart(nl + 1, 0);
+            for (auto &e : edges) { indeg[e.second]++; estart[e.first + 1]++; }
+            for (int i = 0; i < nl; i++) estart[i + 1] += estart[i];
+            std::vector<int> rank(nl, -1), heap;
+            auto cmp = [](int x, int y) { return x > y; };
+            for (int i = 0; i < nl; i++) if (!indeg[i]) heap.push_back(i);
+            std::make_heap(heap.begin(), heap.end(), cmp);
+            int done = 0;
+            while (!heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end(), cmp); const int x = heap.back(); heap.pop_back();
+                rank[x] = done++;
+                for (int k = estart[x]; k < estart[x + 1]; k++) { const int y = edges[k].second; if (--indeg[y] == 0) { heap.push_back(y); std::push_heap(heap.begin(), heap.end(), cmp); } }
+            }
+            if (done == nl) { hinted = true; G = nl; for (int c = 0; c < nOwn; c++) grpOfOld[c] = rank[gid[c]]; }
+        }
+        if (!hinted) {
+            // at most 512 groups and at least 8192 cells per group
+            int B = std::max(8192, (nOwn + 511) / 512);
+            if (const char *e = getenv("FFM_PIPE_GROUP_CELLS")) B = std::max(1, atoi(e));     // tests: force many small groups
+            G = nOwn ? (nOwn + B - 1) / B : 0;
+            for (int c = 0; c < nOwn; c++) grpOfOld[c] = c / B;
+        }
         a.nGroups = G;
-        grpOfOld.resize(nOwn);
         a.grpCell.assign(G + 1, 0);
-        for (int g = 0; g < G; g++) a.grpCell[g + 1] = std::min(nOwn, (g + 1) * B);
-        // inside a group: stable sort by level (then caller index)
-        std::vector<int> cntL;
-        for (int g = 0; g < G; g++) {
-            const int c0 = a.grpCell[g], c1 = a.grpCell[g + 1];
-            int lo = nLev, hi = 0;
-            for (int c = c0; c < c1; c++) { grpOfOld[c] = g; lo = std::min(lo, lev[c]); hi = std::max(hi, lev[c]); }
-            cntL.assign(hi - lo + 2, 0);
-            for (int c = c0; c < c1; c++) cntL[lev[c] - lo + 1]++;
-            for (size_t i = 1; i < cntL.size(); i++) cntL[i] += cntL[i - 1];
-            for (int c = c0; c < c1; c++) { const int p = c0 + cntL[lev[c] - lo]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
+        for (int c = 0; c < nOwn; c++) a.grpCell[grpOfOld[c] + 1]++;
+        for (int g = 0; g < G; g++) a.grpCell[g + 1] += a.grpCell[g];
+        // new numbering: group-major, then level, then caller index (two stable counting passes: by level, then by group)
+        {
+            std::vector<int> byLevel(nOwn), cnt(nLev + 1, 0);
+            for (int c = 0; c < nOwn; c++) cnt[lev[c] + 1]++;
+            for (int i = 0; i < nLev; i++) cnt[i + 1] += cnt[i];
+            for (int c = 0; c < nOwn; c++) byLevel[cnt[lev[c]]++] = c;
+            std::vector<int> pos(a.grpCell.begin(), a.grpCell.end() - (G ? 1 : 0));
+            if (!G) pos.clear();
+            for (int i = 0; i < nOwn; i++) { const int c = byLevel[i]; const int p = pos[grpOfOld[c]]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
         }
         for (int c = nOwn; c < N; c++) { a.newToOldCell[c] = c; a.oldToNewCell[c] = c; }
         a.fwdLevelStart.assign(nLev + 1, 0);
@@ -175,8 +208,10 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         int s = a.bwdLevelStart[b], e = a.bwdLevelStart[b + 1];
         if (e > s && a.bwdOrder[e - 1] - a.bwdOrder[s] != e - s - 1) a.bwdContig = false;
     }
-    if (a.mode == 1) {
+    if (a.mode >= 1) {
         const int G = a.nGroups;
+        a.levNew.resize(nOwn); a.blNew.assign(bl.begin(), bl.begin() + nOwn);
+        for (int c = 0; c < nOwn; c++) a.levNew[c] = lev[a.newToOldCell[c]];
         // forward entries: runs of equal level inside each group (new numbering is level-major inside a group)
         a.fEntStart.assign(G + 1, 0);
         for (int g = 0; g < G; g++) {
@@ -227,10 +262,14 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
 
 extern "C" int ffm_renumber_levels_ext(int nOwned, int nGhost, int nFaces, const int *l, const int *u,
                                        int *newToOldCell, int *newToOldFace)
+{ return ffm_renumber_hint(nOwned, nGhost, nFaces, l, u, nullptr, newToOldCell, newToOldFace); }
+
+extern "C" int ffm_renumber_hint(int nOwned, int nGhost, int nFaces, const int *l, const int *u, const int *groupHint,
+                                 int *newToOldCell, int *newToOldFace)
 {
     if (nOwned < 0 || nGhost < 0 || nFaces < 0 || (nFaces && (!l || !u))) return FFM_ERR_ARG;
     LduAnalysis a;
-    FFM_TRY(analyse(nOwned + nGhost, nOwned, nFaces, l, u, true, true, a));
+    FFM_TRY(analyse(nOwned + nGhost, nOwned, nFaces, l, u, true, true, a, groupHint));
     if (newToOldCell) std::copy(a.newToOldCell.begin(), a.newToOldCell.end(), newToOldCell);
     if (newToOldFace) std::copy(a.newToOldFace.begin(), a.newToOldFace.end(), newToOldFace);
     return FFM_OK;
@@ -260,12 +299,16 @@ extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const in
 { return ffm_ldu_create_ext(ctx, N, 0, F, l, u, out); }
 
 extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int *l, const int *u, ffm_ldu **out)
+{ return ffm_ldu_create_hint(ctx, nOwn, nGhost, F, l, u, nullptr, out); }
+
+extern "C" int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int *l, const int *u, const int *groupHint,
+                                   ffm_ldu **out)
 {
     const int N = nOwn + nGhost;
     if (!ctx || !out || nOwn < 0 || nGhost < 0 || F < 0 || (F && (!l || !u))) { ffm_set_error("ffm_ldu_create: bad argument"); return FFM_ERR_ARG; }
     FFM_HIP(hipSetDevice(ctx->device));
     LduAnalysis a;
-    FFM_TRY(analyse(N, nOwn, F, l, u, true, false, a));
+    FFM_TRY(analyse(N, nOwn, F, l, u, true, false, a, groupHint));
     ffm_ldu *A = new ffm_ldu();
     A->ctx = ctx; A->nCells = N; A->nOwned = nOwn; A->nFaces = F; A->globalCells = nOwn;
     A->identity = a.identity; A->bwdContig = a.bwdContig;
@@ -292,6 +335,7 @@ extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, con
     }
     if ((long)nSl * 16 * 64 > 0x7fffffffL || N >= (1 << 27)) { ffm_set_error("mesh too large for int32 packed entries"); delete A; return FFM_ERR_UNSUPPORTED; }
     A->upTotal = upOff[nSl]; A->loTotal = loOff[nSl];
+    A->h_upOff = upOff; A->h_loOff = loOff;
     A->upWidthUniform = (uniform >= 0) ? uniform : -1;
     A->loWidthUniform = (uniformLo >= 0) ? uniformLo : -1;
     A->maxW = maxW;
@@ -336,7 +380,7 @@ extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, con
         if ((rc = upload(ctx, &A->loEnt, loEnt))) break;
         if ((rc = upload(ctx, &A->faceSrc, faceSrc))) break;
         if (A->sweepMode == 0 && !A->bwdContig && (rc = upload(ctx, &A->bwdOrder, a.bwdOrder))) break;
-        if (A->sweepMode == 1) {
+        if (A->sweepMode >= 1) {
             if ((rc = upload(ctx, &A->grpCell, a.grpCell))) break;
             if ((rc = upload(ctx, &A->fEntStart, a.fEntStart))) break;
             if ((rc = upload(ctx, &A->fEntLevel, a.fEntLevel))) break;
@@ -355,6 +399,7 @@ extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, con
             hipMemsetAsync(A->pipeTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
         }
         if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
+        if (A->sweepMode == 2) { A->h_loEnt = loEnt; A->h_upNbr = upNbr; rc = ffm_tile_build(A, a.l, a.u, a.levNew, a.blNew, a.grpCell); A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit(); if (rc) break; }
         {
             // XCD-aware schedule (see ffm_internal.hpp): chunks of 256 rows, binned by the eighth of their dependency level
             const int nChunks = (nOwn + 255) / 256;
@@ -403,6 +448,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     hipFree(A->grpCell); hipFree(A->fEntStart); hipFree(A->fEntLevel); hipFree(A->fEntCell); hipFree(A->fPredStart); hipFree(A->fPreds);
     hipFree(A->bEntStart); hipFree(A->bEntLevel); hipFree(A->bEntPos); hipFree(A->bPredStart); hipFree(A->bPreds); hipFree(A->bwdCells);
     hipFree(A->pipeProgress); hipFree(A->pipeTicket); hipFree(A->rowSched);
+    ffm_tile_free(A);
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); if (A->ghSendBuf_h) hipHostFree(A->ghSendBuf_h); if (A->ghRecvBuf_h) hipHostFree(A->ghRecvBuf_h);
     hipFree(A->diag); hipFree(A->upper); hipFree(A->lowerBuf); hipFree(A->rD);
     hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);

@@ -381,7 +381,7 @@ static inline void bwd_range(const ffm_ldu *A, int b, int &p0, int &p1, const in
 static int calc_rD(ffm_ldu *A)
 {
     hipStream_t s = A->ctx->stream;
-    if (A->sweepMode == 1) {
+    if (A->sweepMode >= 1) {
         FFM_TRY(ffm_pipe_calc_rD(A));
         hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nOwned)), dim3(256), 0, s, (long)A->nOwned, A->rD, A->rD);
         FFM_HIP(hipGetLastError());
@@ -431,7 +431,8 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
     // DIC: fwd upper / bwd upper.  DILU: fwd lower / bwd upper.  DILU^T: fwd upper / bwd lower.
     const double *cf = (precond == FFM_DIC) ? A->upper : (transpose ? A->upper : A->lower);
     const double *cb = (precond == FFM_DIC) ? A->upper : (transpose ? A->lower : A->upper);
-    if (A->sweepMode == 1) return ffm_pipe_precond(A, cf, cb, r, w);
+    if (A->sweepMode == 2 && ffm_tile_usable(A)) return ffm_tile_precond(A, precond, transpose, r, w);
+    if (A->sweepMode >= 1) return ffm_pipe_precond(A, cf, cb, r, w);
     SweepGraphKey key{SW_PRECOND + 16 * (transpose ? 1 : 0) + 32 * precond, r, w, cf};
     return run_graphed(A, key, [&]() -> int {
         for (int L = 0; L < A->nLevels; L++) {
@@ -465,7 +466,7 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             FFM_TRY(ffm_halo_update(A, psi, bP, A->ifBou, +1.0));
             bUse = bP;
         }
-        if (A->sweepMode == 1) { FFM_TRY(ffm_pipe_gs(A, sym, psi, bUse, bSave)); continue; }
+        if (A->sweepMode >= 1) { FFM_TRY(ffm_pipe_gs(A, sym, psi, bUse, bSave)); continue; }
         SweepGraphKey key{sym ? SW_SYMGS : SW_GS, psi, bUse, A->lower};
         FFM_TRY(run_graphed(A, key, [&]() -> int {
             for (int L = 0; L < A->nLevels; L++) {
@@ -703,7 +704,7 @@ extern "C" int ffm_solve_d(ffm_ldu *A, int solver, int precond, double tol, doub
         FFM_TRY(ffm_from_internal(A, pi, psi_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
     return FFM_OK;
 }
 
@@ -729,7 +730,7 @@ extern "C" int ffm_precond_setup(ffm_ldu *A, int precond, double *rD_out_d)
     FFM_TRY(ffm_precond_setup_i(A, precond));
     if (rD_out_d) FFM_TRY(ffm_from_internal(A, A->rD, rD_out_d));
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
     return FFM_OK;
 }
 
@@ -745,7 +746,7 @@ extern "C" int ffm_precond_apply(ffm_ldu *A, int precond, int transpose, const d
         FFM_TRY(ffm_from_internal(A, wi, w_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
     return FFM_OK;
 }
 
@@ -760,6 +761,6 @@ extern "C" int ffm_gs_smooth(ffm_ldu *A, int symmetric_sweep, int nSweeps, doubl
         FFM_TRY(ffm_from_internal(A, A->permIn[2], psi_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
     return FFM_OK;
 }

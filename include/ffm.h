@@ -98,6 +98,13 @@ int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwned, int nGhost, int nFaces, const i
                        const int *upperAddr, ffm_ldu **out);
 int ffm_renumber_levels_ext(int nOwned, int nGhost, int nFaces, const int *lowerAddr,
                             const int *upperAddr, int *newToOldCell, int *newToOldFace);
+/* Same with a grouping hint for the sweeps: groupHint[c] = any label shared by owned cells that should be swept by one
+ * workgroup (e.g. a 2-D tile of cell columns, from the cell centres).  Used when the label classes form an acyclic
+ * dependency graph, ignored otherwise (NULL: the library chunks the caller's cell order).                         */
+int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwned, int nGhost, int nFaces, const int *lowerAddr,
+                        const int *upperAddr, const int *groupHint, ffm_ldu **out);
+int ffm_renumber_hint(int nOwned, int nGhost, int nFaces, const int *lowerAddr, const int *upperAddr,
+                      const int *groupHint, int *newToOldCell, int *newToOldFace);
 /* neighbour q (rank nbrRank[q]) receives this rank's cells sendCells[...] (sendCount[q] of
  * them, concatenated) and fills recvCount[q] consecutive ghost cells, in neighbour order    */
 int ffm_ldu_set_ghost_exchange(ffm_ldu *ldu, int nNbr, const int *nbrRank, const int *sendCount,

@@ -9,10 +9,12 @@ for n in [int(a) for a in sys.argv[1:]] or [100, 200]:
     t0 = time.time()
     blk = H.HexBlock((n, n, n))
     s = H.synth_p_rgh(blk)
-    cOrd, fOrd = ffm.renumber_levels(blk.nCells, blk.l, blk.u)
+    T = int(os.environ.get("FFM_TILE", "16"))
+    hint = (blk.j // T) + 10000 * (blk.k // T)          # 2-D tiles of cell columns (used by the tile/pipe sweeps)
+    cOrd, fOrd = ffm.renumber_levels(blk.nCells, blk.l, blk.u, groupHint=hint)
     l2, u2, _ = H.apply_renumbering(blk.nCells, blk.l, blk.u, cOrd, fOrd)
     t1 = time.time()
-    A = ffm.lduMatrix(ctx, blk.nCells, l2, u2)
+    A = ffm.lduMatrix(ctx, blk.nCells, l2, u2, groupHint=hint[cOrd])
     A.set_coeffs(s["diag"][cOrd], s["upper"][fOrd])
     t2 = time.time()
     N, F = blk.nCells, blk.nFaces

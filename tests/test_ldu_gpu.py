@@ -24,7 +24,8 @@ def meshes(O):
 
 
 @pytest.fixture(scope="module", params=["hex_natural", "hex_levelmajor", "dag_random", "chain", "plane",
-                                        "hex_natural_g37", "dag_random_g23", "chain_g64", "plane_g50", "hex_levelmajor_g41"])
+                                        "hex_natural_g37", "dag_random_g23", "chain_g64", "plane_g50", "hex_levelmajor_g41",
+                                        "hex_natural_t37", "dag_random_t23", "chain_t64", "plane_t50", "hex_natural_t500", "hex_tiles_t0"])
 def case(request, O, ffm, ctx):
     """`_gNN` variants force the pipelined sweep to split the mesh into groups of NN cells, so that the cross-workgroup
     hand-off (progress words, sc1 loads/stores, LDS ring wrap-around) is exercised on small meshes too."""
@@ -35,6 +36,11 @@ def case(request, O, ffm, ctx):
         name, grp = name.rsplit("_g", 1)
         os.environ["FFM_PIPE_GROUP_CELLS"] = grp
         os.environ["FFM_SWEEP"] = "pipe"
+    elif "_t" in name:                      # tiled wavefront sweep (ffm_tile.hip); t0 = 2-D tile hint instead of chunks
+        name, grp = name.rsplit("_t", 1)
+        if grp != "0":
+            os.environ["FFM_PIPE_GROUP_CELLS"] = grp
+        os.environ["FFM_SWEEP"] = "tile"
     try:
         yield from _make_case(name, grp, O, ffm, ctx)
     finally:
@@ -47,6 +53,15 @@ def _make_case(name, grp, O, ffm, ctx):
         N, l, u = O.hex_ldu(9, 7, 8)
         cOrd, fOrd = ffm.renumber_levels(N, l, u)
         l, u, _ = ffm.hexmesh.apply_renumbering(N, l, u, cOrd, fOrd)
+    elif name == "hex_tiles":
+        nx, ny, nz = 9, 7, 8
+        N, l, u = O.hex_ldu(nx, ny, nz)
+        c = np.arange(N)
+        hint = ((c // nx) % ny) // 3 + 10 * ((c // (nx * ny)) // 3)      # 3x3 tiles of cell columns (j,k)
+        A = ffm.lduMatrix(ctx, N, l, u, groupHint=hint)
+        yield name, N, l, u, A
+        A.close()
+        return
     else:
         N, l, u = meshes(O)[name]
     A = ffm.lduMatrix(ctx, N, l, u)
