@@ -516,14 +516,23 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     }
     const int F = (int)l.size(); P->F = F;
     // ---- renumber once to the library's cell order (no permutation pass ever after)
+    // group hint for the tiled sweeps: 2-D tiles of x-columns, FFM_TILE x FFM_TILE cells in (y,z) (ignored by the level mode)
+    int tileEdge = 16;
+    if (const char *e = getenv("FFM_TILE")) tileEdge = std::max(1, atoi(e));
+    std::vector<int> hint(nOwn);
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) hint[cellOf(i, j, k)] = (j / tileEdge) + 32768 * (k / tileEdge);
     std::vector<int> c2(N), f2(F);
-    FFM_TRY(ffm_renumber_levels_ext((int)nOwn, (int)nGhost, F, l.data(), u.data(), c2.data(), f2.data()));
+    FFM_TRY(ffm_renumber_hint((int)nOwn, (int)nGhost, F, l.data(), u.data(), hint.data(), c2.data(), f2.data()));
     P->newToOld = c2;
     std::vector<int> oldToNew(N);
     for (long c = 0; c < N; c++) oldToNew[c2[c]] = (int)c;
     std::vector<int> l2(F), u2(F); std::vector<signed char> fd2(F), sg2(F);
     for (int f = 0; f < F; f++) { l2[f] = oldToNew[l[f2[f]]]; u2[f] = oldToNew[u[f2[f]]]; fd2[f] = fd[f2[f]]; sg2[f] = fsgn[f2[f]]; }
-    FFM_TRY(ffm_ldu_create_ext(ctx, (int)nOwn, (int)nGhost, F, l2.data(), u2.data(), &P->A));
+    {
+        std::vector<int> hintNew(nOwn);
+        for (long c = 0; c < nOwn; c++) hintNew[c] = hint[c2[c]];
+        FFM_TRY(ffm_ldu_create_hint(ctx, (int)nOwn, (int)nGhost, F, l2.data(), u2.data(), hintNew.data(), &P->A));
+    }
     if (!P->A->identity) { ffm_set_error("plume: renumbered mesh is not native"); return FFM_ERR_ADDR; }
     FFM_TRY(ffm_ldu_set_global_cells(P->A, (long)gx * gy * gz));
     P->nNat = P->A->upTotal;
