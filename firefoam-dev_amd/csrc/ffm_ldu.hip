@@ -49,24 +49,114 @@ struct LduAnalysis {
     std::vector<int> grpCell, fEntStart, fEntLevel, fEntCell, fPredStart, fPreds, bEntStart, bEntLevel, bEntPos, bPredStart, bPreds, bwdCells;
 };
 
-// FFM_SWEEP=levels: one launch per dependency level (level-major numbering); =pipe: pipelined group sweep with per-level
-// hand-off (ffm_pipe.hip, experimental); =tile: tiled wavefront sweep with batched hand-off (ffm_tile.hip)
+// Sweep modes.  0 "levels": one launch per dependency level (level-major numbering).  1 "pipe": pipelined group sweep with
+// a hand-off per level (ffm_pipe.hip, experimental, FFM_SWEEP=pipe only).  2 "tile": tiled wavefront sweep (ffm_tile.hip).
+// Default (FFM_SWEEP unset or "auto"): tile when the caller gives a group hint or the mesh is a blockMesh-numbered box and
+// the plan is feasible, levels otherwise.  FFM_SWEEP=tile also tiles un-hinted meshes (chunks of the cell order; tests).
+enum { SWEEP_AUTO = 3 };
 static int default_sweep_mode()
 {
     const char *e = getenv("FFM_SWEEP");
-    if (!e) return 0;
+    if (!e || e[0] == 'a' || e[0] == 'A') return SWEEP_AUTO;
     if (e[0] == 'p' || e[0] == 'P' || e[0] == '1') return 1;
     if (e[0] == 't' || e[0] == 'T' || e[0] == '2') return 2;
     return 0;
+}
+
+// blockMesh single-block numbering (c = i + nx*(j + ny*k), faces of c in the order +x, +y, +z): returns true and the box
+static bool detect_box(int N, int F, const int *l, const int *u, int &nx, int &ny, int &nz)
+{
+    if (N < 8 || F < 3) return false;
+    // nx: first cell without a face to c+1
+    int f = 0; nx = 0;
+    for (int c = 0; c < N; c++) {
+        bool hasX = false;
+        while (f < F && l[f] == c) { if (u[f] == c + 1) hasX = true; f++; }
+        if (!hasX) { nx = c + 1; break; }
+    }
+    if (nx < 1 || N % nx) return false;
+    // ny: number of rows until a row start has no face to c+nx
+    std::vector<int> start(N + 1, 0);
+    for (int q = 0; q < F; q++) start[l[q] + 1]++;
+    for (int c = 0; c < N; c++) start[c + 1] += start[c];
+    ny = 0;
+    for (int j = 0; (long)j * nx < N; j++) {
+        const int c = j * nx; bool hasY = false;
+        for (int q = start[c]; q < start[c + 1]; q++) if (u[q] == c + nx) hasY = true;
+        if (!hasY) { ny = j + 1; break; }
+    }
+    if (ny < 1 || (N / nx) % ny) return false;
+    nz = N / nx / ny;
+    if ((long)F != (long)(nx - 1) * ny * nz + (long)nx * (ny - 1) * nz + (long)nx * ny * (nz - 1)) return false;
+    int q = 0;
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) {
+        const int c = i + nx * (j + ny * k);
+        if (i < nx - 1) { if (l[q] != c || u[q] != c + 1) return false; q++; }
+        if (j < ny - 1) { if (l[q] != c || u[q] != c + nx) return false; q++; }
+        if (k < nz - 1) { if (l[q] != c || u[q] != c + nx * ny) return false; q++; }
+    }
+    return q == F;
+}
+
+static int tile_edge()
+{
+    int t = 16;
+    if (const char *e = getenv("FFM_TILE")) t = std::max(1, atoi(e));
+    return t;
+}
+
+// ffm_renumber_* and ffm_ldu_create* are separate calls: the groups chosen by a renumbering (contiguous cell ranges of the
+// new numbering) are remembered under a fingerprint of the renumbered addressing, so that creating the matrix from that
+// addressing without a hint finds them again.
+struct GroupMemo { unsigned long long key; int N, F; std::vector<int> grpCell; };
+static std::vector<GroupMemo> g_groupMemo;
+static unsigned long long addr_fingerprint(int N, int F, const int *l, const int *u)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)N << 32) ^ (unsigned)F;
+    for (int f = 0; f < F; f++) { h ^= (unsigned long long)(unsigned)l[f] | ((unsigned long long)(unsigned)u[f] << 32); h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29; }
+    return h;
+}
+static void memo_put(int N, int F, const int *l, const int *u, const std::vector<int> &grpCell)
+{
+    GroupMemo m{addr_fingerprint(N, F, l, u), N, F, grpCell};
+    for (auto &x : g_groupMemo) if (x.key == m.key && x.N == N && x.F == F) { x = m; return; }
+    if (g_groupMemo.size() >= 8) g_groupMemo.erase(g_groupMemo.begin());
+    g_groupMemo.push_back(std::move(m));
+}
+static const std::vector<int> *memo_get(int N, int F, const int *l, const int *u)
+{
+    if (g_groupMemo.empty()) return nullptr;
+    const unsigned long long key = addr_fingerprint(N, F, l, u);
+    for (auto &x : g_groupMemo) if (x.key == key && x.N == N && x.F == F) return &x.grpCell;
+    return nullptr;
 }
 
 // nOwn < N: cells [nOwn, N) are ghost cells (copies of neighbour-rank cells).  They own no faces, stay at the end of the
 // numbering in their given order, take no part in the level structure, and faces towards them are ignored by the
 // backward levels (block-Jacobi sweeps).
 static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renumber, bool sortByNewNeighbour, LduAnalysis &a,
-                   const int *groupHint = nullptr)
+                   const int *groupHint = nullptr, int forceMode = -1)
 {
-    a.mode = default_sweep_mode();
+    a.mode = forceMode >= 0 ? forceMode : default_sweep_mode();
+    std::vector<int> autoHint;
+    const bool autoMode = a.mode == SWEEP_AUTO;
+    if (a.mode == SWEEP_AUTO) {
+        a.mode = 0;
+        if (renumber && nOwn > 0) {
+            int bx, by, bz;
+            if (groupHint) a.mode = 2;
+            else if (const std::vector<int> *gc = memo_get(N, F, l, u)) {
+                autoHint.resize(nOwn);
+                for (int g = 0; g + 1 < (int)gc->size(); g++) for (int c = (*gc)[g]; c < (*gc)[g + 1] && c < nOwn; c++) autoHint[c] = g;
+                groupHint = autoHint.data(); a.mode = 2;
+            } else if (N == nOwn && detect_box(N, F, l, u, bx, by, bz)) {
+                const int T = tile_edge();
+                autoHint.resize(nOwn);
+                for (int c = 0; c < nOwn; c++) autoHint[c] = ((c / bx) % by) / T + 32768 * ((c / (bx * by)) / T);
+                groupHint = autoHint.data(); a.mode = 2;
+            }
+        }
+    }
     for (int f = 0; f < F; f++) {
         if (l[f] < 0 || u[f] >= N || l[f] >= u[f]) {
             ffm_set_error("LDU addressing: face %d has l=%d u=%d (need 0<=l<u<nCells=%d)", f, l[f], u[f], N);
@@ -118,6 +208,12 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
                 for (int k = estart[x]; k < estart[x + 1]; k++) { const int y = edges[k].second; if (--indeg[y] == 0) { heap.push_back(y); std::push_heap(heap.begin(), heap.end(), cmp); } }
             }
             if (done == nl) { hinted = true; G = nl; for (int c = 0; c < nOwn; c++) grpOfOld[c] = rank[gid[c]]; }
+        }
+        if (!hinted && autoMode) {           // unusable hint: level-scheduled sweeps
+            LduAnalysis b;
+            FFM_TRY(analyse(N, nOwn, F, l, u, renumber, sortByNewNeighbour, b, nullptr, 0));
+            a = std::move(b);
+            return FFM_OK;
         }
         if (!hinted) {
             // at most 512 groups and at least 8192 cells per group
@@ -257,6 +353,12 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         }
         a.bEntPos.push_back(nOwn);
     }
+    if (a.mode == 2 && !(a.bwdIsReverse && ffm_tile_feasible(nOwn, F, a.l.data(), a.u.data()))) {
+        // the tiled sweeps cannot take this mesh / grouping: level-scheduled sweeps instead
+        LduAnalysis b;
+        FFM_TRY(analyse(N, nOwn, F, l, u, renumber, sortByNewNeighbour, b, nullptr, 0));
+        a = std::move(b);
+    }
     return FFM_OK;
 }
 
@@ -272,6 +374,7 @@ extern "C" int ffm_renumber_hint(int nOwned, int nGhost, int nFaces, const int *
     FFM_TRY(analyse(nOwned + nGhost, nOwned, nFaces, l, u, true, true, a, groupHint));
     if (newToOldCell) std::copy(a.newToOldCell.begin(), a.newToOldCell.end(), newToOldCell);
     if (newToOldFace) std::copy(a.newToOldFace.begin(), a.newToOldFace.end(), newToOldFace);
+    if (a.mode == 2) memo_put(nOwned + nGhost, nFaces, a.l.data(), a.u.data(), a.grpCell);
     return FFM_OK;
 }
 
@@ -283,6 +386,7 @@ extern "C" int ffm_renumber_levels(int nCells, int nFaces, const int *l, const i
     FFM_TRY(analyse(nCells, nCells, nFaces, l, u, true, true, a));
     if (newToOldCell) std::copy(a.newToOldCell.begin(), a.newToOldCell.end(), newToOldCell);
     if (newToOldFace) std::copy(a.newToOldFace.begin(), a.newToOldFace.end(), newToOldFace);
+    if (a.mode == 2) memo_put(nCells, nFaces, a.l.data(), a.u.data(), a.grpCell);
     return FFM_OK;
 }
 
@@ -399,7 +503,7 @@ extern "C" int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwn, int nGhost, int F, co
             hipMemsetAsync(A->pipeTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
         }
         if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
-        if (A->sweepMode == 2) { A->h_loEnt = loEnt; A->h_upNbr = upNbr; rc = ffm_tile_build(A, a.l, a.u, a.levNew, a.blNew, a.grpCell); A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit(); if (rc) break; }
+        if (A->sweepMode == 2) { A->h_loEnt = loEnt; A->h_upNbr = upNbr; rc = ffm_tile_build(A, a.levNew, a.blNew, a.grpCell); A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit(); if (rc) break; }
         {
             // XCD-aware schedule (see ffm_internal.hpp): chunks of 256 rows, binned by the eighth of their dependency level
             const int nChunks = (nOwn + 255) / 256;

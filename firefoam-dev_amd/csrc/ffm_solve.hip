@@ -382,7 +382,7 @@ static int calc_rD(ffm_ldu *A)
 {
     hipStream_t s = A->ctx->stream;
     if (A->sweepMode >= 1) {
-        FFM_TRY(ffm_pipe_calc_rD(A));
+        if (A->sweepMode == 2 && ffm_tile_usable(A)) FFM_TRY(ffm_tile_calc_rD(A)); else FFM_TRY(ffm_pipe_calc_rD(A));
         hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nOwned)), dim3(256), 0, s, (long)A->nOwned, A->rD, A->rD);
         FFM_HIP(hipGetLastError());
         return FFM_OK;

@@ -309,6 +309,11 @@ int ffm_comm_set_host_exchange2(ffm_ctx *ctx, ffm_host_exchange2_fn fn);
 int ffm_comm_rank(const ffm_ctx *ctx);
 int ffm_comm_size(const ffm_ctx *ctx);
 
+/* Diagnostics of the tiled sweeps (ffm_tile.hip): the first call switches tracing on and returns the number of groups; later
+ * calls copy out, for the last tiled launch, 4 words per group {start, first entry ready, end (100 MHz ticks), mailbox
+ * re-loads}.  Not part of the reference interface. */
+int ffm_debug_tile_trace(ffm_ldu *A, unsigned long long *out, int nWords);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,5 +33,23 @@ for _ in range(reps):
 ctx.sync()
 ms = (time.perf_counter() - t0) / reps * 1e3
 N = blk.nCells
+if os.environ.get("FFM_TRACE"):
+    G = L.ffm_debug_tile_trace(A.h, None, 0)          # switch tracing on
+    if G > 0:
+        for which in ("bwd",):                        # the trace holds the last launch of an apply = the backward sweep
+            apply(); ctx.sync()
+            buf = np.zeros(4 * G, np.uint64)
+            L.ffm_debug_tile_trace(A.h, buf.ctypes.data_as(C.c_void_p), 4 * G)
+            tr = buf.reshape(G, 4).astype(np.float64)
+            t0_ = tr[:, 0].min()
+            st, fe, en, sp = (tr[:, 0] - t0_) / 100.0, (tr[:, 1] - t0_) / 100.0, (tr[:, 2] - t0_) / 100.0, tr[:, 3]
+            print("  trace %s: G=%d  kernel span %.1f us; group start min/median/max %.1f/%.1f/%.1f us; first-entry wait median %.1f max %.1f us;"
+                  " run time (end-first entry) min/median/max %.1f/%.1f/%.1f us; re-loads total %d (max per group %d)"
+                  % (which, G, en.max(), st.min(), np.median(st), st.max(), np.median(fe - st), (fe - st).max(),
+                     (en - fe).min(), np.median(en - fe), (en - fe).max(), int(sp.sum()), int(sp.max())))
+            order = np.argsort(st)
+            for q in (0, G // 4, G // 2, 3 * G // 4, G - 1):
+                g = order[q]
+                print("    group %4d: start %.1f first %.1f end %.1f reloads %d" % (g, st[g], fe[g], en[g], sp[g]))
 print("box %dx%dx%d N=%d levels=%d sweep=%s tile=%d: %.4f ms per apply (2 sweeps) = %.3f us/level/sweep, %.1f GB/s of 2x60 B/cell"
       % (nx, ny, nz, N, A.nLevels, os.environ.get("FFM_SWEEP", "levels"), T, ms, ms * 1e3 / 2 / max(A.nLevels, 1), 120.0 * N / ms / 1e6))
