@@ -518,7 +518,9 @@ extern "C" int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwn, int nGhost, int F, co
                     seq[std::min(std::max(eighth, 0), 7)].push_back(ch);
                 }
             } else {
-                for (int ch = 0; ch < nChunks; ch++) seq[ch & 7].push_back(ch);
+                // group-major numbering (tiles): each XCD streams through one contiguous eighth of the rows, so that the rows a
+                // row gathers from (same or neighbouring tile) were fetched into the same L2
+                for (int ch = 0; ch < nChunks; ch++) seq[std::min(7, (int)(8L * ch / std::max(nChunks, 1)))].push_back(ch);
             }
             size_t mx = 0;
             for (auto &q : seq) mx = std::max(mx, q.size());

@@ -185,6 +185,7 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
     T->G = (int)grpCell.size() - 1;
     if (T->G <= 0) return FFM_OK;
     const int nOwn = A->nOwned;
+    if ((long)A->nCells * 24 >= (1L << 32)) return FFM_OK;         // the kernel addresses its streams with 32-bit byte offsets
     std::vector<int> grpOfCell(nOwn);
     for (int g = 0; g < T->G; g++) for (int c = grpCell[g]; c < grpCell[g + 1]; c++) grpOfCell[c] = g;
     bool ok = true;
@@ -217,6 +218,8 @@ __device__ __forceinline__ void t_barrier() { asm volatile("s_waitcnt lgkmcnt(0)
 __device__ __forceinline__ bool t_pending(double v) { return (unsigned long long)__double_as_longlong(v) == T_SENT; }
 
 enum { TM_FWD = 0, TM_BWD = 1, TM_RD = 2 };
+struct __attribute__((aligned(8))) T3 { double a, b, c; };       // the three coefficients of a cell
+static_assert(T_W == 3, "T3");
 
 // slow path of a mailbox read: re-load until the producer's value has replaced the sentinel; bounded, watches the abort word
 template <bool TRACE>
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
 {
     constexpr bool ASC = MODE != TM_BWD;
     constexpr int W = T_W;
-    __shared__ double ring[T_RING];
-    __shared__ double halo[2 * T_XMAX];
+    __shared__ double ring[T_RING + 2 * T_XMAX];      // ring of this group's values, then the two halo buffers
+    double *const halo = ring + T_RING;
     __shared__ int4 shRec[4];           // entry records handed from the mail wave to the compute waves
     __shared__ int shG;
     __shared__ int shAbort;
@@ -324,11 +327,12 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
         const unsigned cnt_ = ((e) < e1) ? ((unsigned)R_.y & 0xFFFFu) : 0u;                              \
         const bool ok_ = tid < cnt_;                                                                     \
         const unsigned cc_ = ok_ ? (ASC ? (unsigned)R_.x + tid : (unsigned)R_.x + cnt_ - 1u - tid) : gs; \
-        pq[k] = t.code[cc_];                                                                             \
-        _Pragma("unroll") for (int s = 0; s < W; s++) pa[k][s] = ca[(size_t)cc_ * W + s];                \
-        if (MODE == TM_RD) { _Pragma("unroll") for (int s = 0; s < W; s++) pb[k][s] = cb[(size_t)cc_ * W + s]; } \
-        pd[k] = dg[cc_];                                                                                 \
-        pv[k] = MODE == TM_FWD ? r[cc_] : (MODE == TM_BWD ? w[cc_] : 0.0);                               \
+        const unsigned o8_ = cc_ * 8u, o24_ = cc_ * 24u;        /* 32-bit byte offsets: arrays < 4 GiB (host check) */  \
+        pq[k] = *(const uint2 *)((const char *)t.code + o8_);                                            \
+        { const T3 v_ = *(const T3 *)((const char *)ca + o24_); pa[k][0] = v_.a; pa[k][1] = v_.b; pa[k][2] = v_.c; }     \
+        if (MODE == TM_RD) { const T3 v_ = *(const T3 *)((const char *)cb + o24_); pb[k][0] = v_.a; pb[k][MODE == TM_RD ? 1 : 0] = v_.b; pb[k][MODE == TM_RD ? 2 : 0] = v_.c; } \
+        pd[k] = *(const double *)((const char *)dg + o8_);                                               \
+        pv[k] = MODE == TM_FWD ? *(const double *)((const char *)r + o8_) : (MODE == TM_BWD ? *(const double *)((const char *)w + o8_) : 0.0); \
         pc[k] = cc_; pok[k] = ok_; ppb[k] = (unsigned)R_.z;                                              \
     }
 #pragma unroll
@@ -343,14 +347,15 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
             // ---- entry ee from slot k (idle lanes work on the dummy cell gs; nothing of theirs is stored)
             {
                 const unsigned c = pc[k];
-                const unsigned hb = (unsigned)(ee & 1) * (unsigned)T_XMAX;
+                const unsigned hb = (unsigned)T_RING + (unsigned)(ee & 1) * (unsigned)T_XMAX;
                 const unsigned cd[4] = {pq[k].x & 0xFFFFu, pq[k].x >> 16, pq[k].y & 0xFFFFu, pq[k].y >> 16};
                 double x[W];
 #pragma unroll
                 for (int s = 0; s < W; s++) {
                     const unsigned ri = ((ASC ? c - cd[s] : c + cd[s]) - gs) & (unsigned)(T_RING - 1);
-                    const double xr = ring[ri], xh = halo[hb + (cd[s] & (unsigned)(T_XMAX - 1))];
-                    x[s] = (cd[s] & T_EXT) ? xh : xr;
+                    const unsigned hi = hb + (cd[s] & (unsigned)(T_XMAX - 1));
+                    const unsigned m = (unsigned)((int)(cd[s] << 16) >> 31);          // all ones for an external (or absent) neighbour
+                    x[s] = ring[ri ^ ((ri ^ hi) & m)];
                 }
                 const double d = pd[k];
                 double val;
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
 #pragma unroll
                     for (int s = 0; s < W; s++) { const double nv = val - pa[k][s] * pb[k][MODE == TM_RD ? s : 0] / x[s]; val = (cd[s] != T_NONE) ? nv : val; }
                 }
-                if (pok[k]) { w[c] = val; ring[(c - gs) & (unsigned)(T_RING - 1)] = val; }
+                if (pok[k]) { *(double *)((char *)w + c * 8u) = val; ring[(c - gs) & (unsigned)(T_RING - 1)] = val; }
                 if (pok[k] && cd[3] != T_NONE) t_st(&t.mail[ppb[k] + cd[3]], val);
             }
             // ---- refill slot k with entry ee + T_PF
