@@ -31,7 +31,7 @@ constexpr int T_RING = 4096;        // doubles (power of two)
 constexpr int T_ENT = 256;          // max cells per entry = workgroup size
 constexpr int T_THREADS = 256;
 constexpr int T_W = 3;              // neighbour slots per cell and direction (hexahedra: 3)
-constexpr int T_PF = 6;             // entries fetched ahead of the one being computed
+constexpr int T_PF = 8;             // entries fetched ahead of the one being computed
 constexpr int T_PM = 3;             // mailbox values are loaded this many entries ahead (2 <= T_PM < T_PF)
 constexpr int T_XMAX = 64;          // max external references per entry (one lane of the mail wave each; power of two)
 constexpr int T_RINGD = T_RING - 2 * T_ENT;     // largest cell distance served by the ring
