@@ -195,6 +195,8 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
 int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<int> &bl, const std::vector<int> &grpCell);
 bool ffm_tile_feasible(int nOwn, int F, const int *l, const int *u);
 int ffm_tile_calc_rD(ffm_ldu *A);
+bool ffm_tile_amul_usable(const ffm_ldu *A);
+int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot);     // returns 1 if the dot product is left to the caller
 void ffm_tile_free(ffm_ldu *A);
 bool ffm_tile_usable(const ffm_ldu *A);
 int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);

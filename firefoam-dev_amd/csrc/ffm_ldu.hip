@@ -763,14 +763,18 @@ __global__ __launch_bounds__(1024) void k_sum_partials(int n, const double *__re
 // grid of the row kernels: a multiple of 8 so that schedule entry i always meets blockIdx % 8 == i % 8
 static inline int rows_grid(const ffm_ldu *A)
 {
-    static const int cap = getenv("FFM_ROWS_GRID") ? std::min(atoi(getenv("FFM_ROWS_GRID")), RED_BLOCKS) : RED_BLOCKS;
-    int g = std::min(A->nSched, cap); g = (g + 7) & ~7; return std::max(g, 8);
+    // Fewer workgroups in flight on very large meshes: the rows in flight per XCD (grid/8 chunks of 256 rows, ~110 B each)
+    // should not exceed the 4 MB L2 by much, or the neighbour gathers miss it (measured at 64 M rows: 1.16 ms with 1024
+    // workgroups, 1.37 ms with 2048; below 10 M rows 2048 is marginally better)
+    static const int cap = getenv("FFM_ROWS_GRID") ? std::min(atoi(getenv("FFM_ROWS_GRID")), RED_BLOCKS) : 0;
+    int g = std::min(A->nSched, cap ? cap : (A->nOwned >= (32 << 20) ? 1024 : RED_BLOCKS)); g = (g + 7) & ~7; return std::max(g, 8);
 }
 
 int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
 {
     if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));   // refresh ghost columns
     const double *up = transpose ? A->lower : A->upper, *lo = transpose ? A->upper : A->lower;
+    if (ffm_tile_amul_usable(A) && !getenv("FFM_NO_TILE_AMUL")) { FFM_TRY(ffm_tile_amul(A, x, y, -1)); return FFM_OK; }
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
                                                A->diag, up, lo, x, (const double *)nullptr, y, (double *)nullptr));
     FFM_HIP(hipGetLastError());
@@ -784,6 +788,11 @@ int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
     if (!A->ifaces.empty()) {  // the halo term changes y after the row kernel: separate dot
         FFM_TRY(ffm_k_spmv(A, x, y, false));
         return ffm_k_dot(A->ctx, y, x, A->nOwned, slot);
+    }
+    if (ffm_tile_amul_usable(A) && !getenv("FFM_NO_TILE_AMUL")) {
+        const int rc = ffm_tile_amul(A, x, y, slot);
+        if (rc == 1) return ffm_k_dot(A->ctx, y, x, A->nOwned, slot);      // ghost faces were added after the tiled kernel
+        return rc;
     }
     const int g = rows_grid(A);
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, true, W>), dim3(g), dim3(256), 0, A->ctx->stream, ffm_view(A), A->diag,

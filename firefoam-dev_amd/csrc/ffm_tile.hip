@@ -60,6 +60,16 @@ struct ffm_tile_plan {
     double *mailAll = nullptr;
     long nMail = 0;
     unsigned long long *trace = nullptr;    // diagnostics (ffm_debug_tile_trace): per group {start, first entry done, end, re-loads} of the last launch
+    // ---- tiled Amul (symmetric matrices): same groups and entries as the forward sweep
+    bool amulUsable = false;
+    std::vector<int> grpEntHost;    // forward entries of each group (host copy)
+    int4 *arec = nullptr;           // [nEnt + pad] {first cell, cells | externals << 16, first index into aext, 0}
+    uint4 *acode = nullptr;         // [nOwn] 8 x 16 bit: 3 lower codes, 3 upper codes (A_* encoding below), 2 spare
+    int2 *aext = nullptr;           // per external reference {cell whose x is needed, native index of the coefficient or -1}
+    int nSeg = 0;                   // workgroups of the tiled Amul: a segment = a run of entries of one group
+    int4 *aseg = nullptr;           // [nSeg] {group, first entry, end entry, end entry of the group}
+    int nTail = 0;                  // cells that own faces towards ghost cells (processed after the tiled kernel, in face order)
+    int *tailCell = nullptr, *tailStart = nullptr, *tailFace = nullptr, *tailNbr = nullptr;
 };
 
 static void free_dir(TileDir &d)
@@ -72,6 +82,8 @@ void ffm_tile_free(ffm_ldu *A)
     if (!A->tile) return;
     free_dir(A->tile->f); free_dir(A->tile->b);
     hipFree(A->tile->mailAll); hipFree(A->tile->trace);
+    hipFree(A->tile->arec); hipFree(A->tile->acode); hipFree(A->tile->aext); hipFree(A->tile->aseg);
+    hipFree(A->tile->tailCell); hipFree(A->tile->tailStart); hipFree(A->tile->tailFace); hipFree(A->tile->tailNbr);
     delete A->tile; A->tile = nullptr;
 }
 bool ffm_tile_usable(const ffm_ldu *A) { return A->tile && A->tile->usable; }
@@ -99,7 +111,8 @@ bool ffm_tile_feasible(int nOwn, int F, const int *l, const int *u)
 // ghost cells are dropped (block-Jacobi sweeps ignore them); the remaining ones keep their order, which is the order of
 // the reference's face loop.
 static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const std::vector<int> &grpCell,
-                     const std::vector<int> &grpOfCell, TileDir &D, bool &ok)
+                     const std::vector<int> &grpOfCell, TileDir &D, bool &ok, std::vector<int4> *recOut = nullptr,
+                     std::vector<int> *grpEntOut = nullptr)
 {
     const int G = (int)grpCell.size() - 1, nOwn = A->nOwned, W = T_W;
     const std::vector<int> &off = fwd ? A->h_loOff : A->h_upOff;
@@ -172,9 +185,106 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
         if (t != (R.y >> 16)) { ffm_set_error("internal: tile plan external count mismatch"); return FFM_ERR_ADDR; }
     }
     D.nEnt = (int)rec.size(); D.nPub = nPub;
+    if (recOut) *recOut = rec;
+    if (grpEntOut) *grpEntOut = grpEnt;
     for (int k = 0; k < 2 * T_PF + 2; k++) rec.push_back(make_int4(0, 0, 0, 0));      // read-ahead padding
     for (int k = 0; k < T_THREADS; k++) extSrc.push_back(0);
     FFM_TRY(upv(&D.grpEnt, grpEnt)); FFM_TRY(upv(&D.rec, rec)); FFM_TRY(upv(&D.extSrc, extSrc)); FFM_TRY(upv(&D.code, code)); FFM_TRY(upv(&D.src, src));
+    return FFM_OK;
+}
+
+
+// ------------------------------------------------------------------ tiled Amul: plan ---
+// y = A x for a symmetric matrix on the tile numbering.  One workgroup streams through one group entry by entry (the
+// forward sweep's entries); x and the upper coefficients of the entries [e-3, e+3] live in LDS rings, so a row finds its
+// neighbours' x and, for its lower faces, the owner's coefficient there: every coefficient, x, diag is read from memory
+// once (56 B per cell + 16 B of codes).  Neighbours outside the window or in another group ("externals", tile faces) are
+// fetched by the mail wave from x / the native coefficient array.  Faces towards ghost cells come last in a row's face
+// order and are added afterwards by k_amul_tail, so the sum of every row runs in the reference's face order.
+constexpr int A_RING = 1024;            // cells in the x / coefficient rings (power of two; >= 8 entries of 256)
+constexpr int A_WIN = 1;                // entries on either side served by the rings
+constexpr int A_AHEAD = A_WIN + 1;      // the rings are filled this many entries ahead of the entry being computed
+constexpr int A_XMAX = 128;             // externals per entry (two per lane of the mail wave)
+constexpr int A_PF = 6;                 // read-ahead (entries), > A_AHEAD
+constexpr unsigned A_NONE = 0xFFFFu, A_EXT = 0x8000u;      // in-ring code: bits 0-10 cell distance, bits 12-13 owner's slot
+static_assert((A_WIN + A_AHEAD + 1) * T_ENT <= A_RING && A_PF > A_AHEAD, "ring window");
+
+static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::vector<int4> &recF)
+{
+    ffm_tile_plan *T = A->tile;
+    const int nOwn = A->nOwned, nEnt = (int)recF.size();
+    std::vector<int> entOf(nOwn, -1);
+    for (int e = 0; e < nEnt; e++) for (int c = recF[e].x; c < recF[e].x + (recF[e].y & 0xFFFF); c++) entOf[c] = e;
+    std::vector<unsigned short> code((size_t)8 * nOwn, (unsigned short)A_NONE);
+    std::vector<int4> arec(nEnt);
+    std::vector<int2> aext;
+    std::vector<int> tailCell, tailStart(1, 0), tailFace, tailNbr;
+    auto inRing = [&](int c, int nb) { return grpOfCell[nb] == grpOfCell[c] && std::abs(entOf[nb] - entOf[c]) <= A_WIN; };
+    for (int e = 0; e < nEnt; e++) {
+        const int c0 = recF[e].x, cnt = recF[e].y & 0xFFFF;
+        const int extOff = (int)aext.size();
+        int t = 0;
+        for (int c = c0; c < c0 + cnt; c++) {
+            const int sl = c >> 6, lane = c & 63;
+            // lower entries in face order
+            const int lw = (A->h_loOff[sl + 1] - A->h_loOff[sl]) / 64;
+            int k = 0;
+            for (int s = 0; s < lw; s++) {
+                const int q = A->h_loEnt[A->h_loOff[sl] + s * 64 + lane];
+                if (q < 0) continue;
+                const int o = q >> 4, os = q & 15;
+                if (k >= 3) return FFM_OK;                                   // not usable
+                if (inRing(c, o) && os < 3 && c - o < 2048) code[(size_t)8 * c + k] = (unsigned short)((c - o) | (os << 12));
+                else {
+                    if (t >= A_XMAX) return FFM_OK;
+                    code[(size_t)8 * c + k] = (unsigned short)(A_EXT | t);
+                    aext.push_back(make_int2(o, A->h_upOff[o >> 6] + os * 64 + (o & 63))); t++;
+                }
+                k++;
+            }
+            // upper slots in slot order: owned neighbours first, ghost neighbours must follow them
+            const int uw = (A->h_upOff[sl + 1] - A->h_upOff[sl]) / 64;
+            k = 0;
+            bool ghostSeen = false;
+            for (int s = 0; s < uw; s++) {
+                const int idx = A->h_upOff[sl] + s * 64 + lane, nb = A->h_upNbr[idx];
+                if (nb < 0) continue;
+                if (nb >= nOwn) {
+                    if (!ghostSeen) { tailCell.push_back(c); ghostSeen = true; }
+                    tailFace.push_back(idx); tailNbr.push_back(nb);
+                    continue;
+                }
+                if (ghostSeen || k >= 3) return FFM_OK;                      // owned after ghost, or too many: not usable
+                if (inRing(c, nb) && nb - c < 2048) code[(size_t)8 * c + 3 + k] = (unsigned short)(nb - c);
+                else {
+                    if (t >= A_XMAX) return FFM_OK;
+                    code[(size_t)8 * c + 3 + k] = (unsigned short)(A_EXT | t);
+                    aext.push_back(make_int2(nb, -1)); t++;
+                }
+                k++;
+            }
+            if (ghostSeen) tailStart.push_back((int)tailFace.size());
+        }
+        arec[e] = make_int4(c0, cnt | (t << 16), extOff, 0);
+    }
+    for (int k = 0; k < 2 * A_PF + 2; k++) arec.push_back(make_int4(0, 0, 0, 0));
+    for (int k = 0; k < 2 * A_XMAX; k++) aext.push_back(make_int2(0, -1));
+    FFM_TRY(upv(&T->arec, arec)); FFM_TRY(upv(&T->aext, aext));
+    FFM_HIP(hipMalloc((void **)&T->acode, sizeof(unsigned short) * 8 * std::max<size_t>(nOwn, 1)));
+    FFM_HIP(hipMemcpy(T->acode, code.data(), sizeof(unsigned short) * code.size(), hipMemcpyHostToDevice));
+    T->nTail = (int)tailCell.size();
+    FFM_TRY(upv(&T->tailCell, tailCell)); FFM_TRY(upv(&T->tailStart, tailStart)); FFM_TRY(upv(&T->tailFace, tailFace)); FFM_TRY(upv(&T->tailNbr, tailNbr));
+    // segments: enough workgroups to fill the chip, each long enough to amortise the A_WIN entries read twice at either end
+    {
+        const std::vector<int> &grpEntH = T->grpEntHost;
+        int L = std::min(64, std::max(16, nEnt / 2048));
+        if (const char *e = getenv("FFM_AMUL_SEG")) L = std::max(1, atoi(e));
+        std::vector<int4> seg;
+        for (int g = 0; g < T->G; g++) for (int a = grpEntH[g]; a < grpEntH[g + 1]; a += L) seg.push_back(make_int4(g, a, std::min(a + L, grpEntH[g + 1]), grpEntH[g + 1]));
+        T->nSeg = (int)seg.size();
+        FFM_TRY(upv(&T->aseg, seg));
+    }
+    T->amulUsable = true;
     return FFM_OK;
 }
 
@@ -189,13 +299,15 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
     std::vector<int> grpOfCell(nOwn);
     for (int g = 0; g < T->G; g++) for (int c = grpCell[g]; c < grpCell[g + 1]; c++) grpOfCell[c] = g;
     bool ok = true;
-    FFM_TRY(build_dir(A, true, lev, grpCell, grpOfCell, T->f, ok));
+    std::vector<int4> recF;
+    FFM_TRY(build_dir(A, true, lev, grpCell, grpOfCell, T->f, ok, &recF, &T->grpEntHost));
     if (ok) FFM_TRY(build_dir(A, false, bl, grpCell, grpOfCell, T->b, ok));
     T->usable = ok;
     if (ok) {
         T->nMail = (long)T->f.nPub + T->b.nPub + 2;
         FFM_HIP(hipMalloc((void **)&T->mailAll, sizeof(double) * T->nMail));
         T->f.mail = T->mailAll; T->b.mail = T->mailAll + T->f.nPub + 1;
+        FFM_TRY(build_amul(A, grpOfCell, recF));
     }
     return FFM_OK;
 }
@@ -460,6 +572,191 @@ int ffm_tile_calc_rD(ffm_ldu *A)
                        (const double *)nullptr, A->rD);
     FFM_HIP(hipGetLastError());
     return FFM_OK;
+}
+
+
+// ------------------------------------------------------------------ tiled Amul: kernels ---
+struct AmulView {
+    int G;
+    const int *grpCell, *grpEnt;
+    const int4 *rec, *seg;
+    const uint4 *code;
+    const int2 *ext;
+};
+
+// y[c] = diag[c]*x[c] + sum_lower coef*x[l] + sum_upper(owned) coef*x[u]   (lduMatrix::Amul row order); DOT: partial of x.y
+template <bool DOT>
+__global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const double *__restrict__ bc, const double *__restrict__ upper,
+                                                              const double *__restrict__ diag, const double *__restrict__ x,
+                                                              double *__restrict__ y, double *__restrict__ partials)
+{
+    __shared__ double xring[A_RING + 2 * A_XMAX];           // x of the window, then the two external-x buffers
+    __shared__ double cring[3 * A_RING + 2 * A_XMAX];       // upper coefficients of the window, then the external coefficients
+    __shared__ int4 shRec[4];
+    __shared__ double sm[8];
+    const unsigned tid = threadIdx.x;
+    // segment [sa, sb) of group g: rows of these entries are computed; the rings also need the A_WIN entries on either side
+    const int4 S = t.seg[blockIdx.x];
+    const int g = S.x, sa = S.y, sb = S.z;
+    const unsigned gs = (unsigned)t.grpCell[g];
+    const int e0 = max(t.grpEnt[g], sa - A_WIN), e1 = min(S.w, sb + A_WIN);     // entries loaded
+    double dot = 0.0;
+    if (sa < sb) {
+        if (tid >= (unsigned)T_THREADS) {
+            // ---------------------------------------------------------------- mail wave: externals of the next entry
+            const unsigned lane = tid - (unsigned)T_THREADS;
+            int4 qrec[A_PF];
+            unsigned qne[A_PF];
+            int2 qi0[A_PF], qi1[A_PF];
+            double qx0[A_PF], qx1[A_PF], qc0[A_PF], qc1[A_PF];
+#define Q_REC(k, e) { qrec[k] = t.rec[min((e), e1)]; }
+#define Q_IDX(k, e) { const int4 R_ = qrec[k]; qne[k] = ((e) < e1) ? ((unsigned)R_.y >> 16) : 0u;                       \
+                      qi0[k] = t.ext[(unsigned)R_.z + (lane < qne[k] ? lane : 0u)];                                     \
+                      qi1[k] = t.ext[(unsigned)R_.z + (lane + 64u < qne[k] ? lane + 64u : 0u)]; }
+#define Q_VAL(k) { qx0[k] = x[qi0[k].x]; qx1[k] = x[qi1[k].x]; qc0[k] = upper[max(qi0[k].y, 0)]; qc1[k] = upper[max(qi1[k].y, 0)]; }
+#define Q_PUT(k, e) { const unsigned hb_ = (unsigned)((e) & 1) * (unsigned)A_XMAX;                                      \
+                      if (lane < qne[k]) { xring[A_RING + hb_ + lane] = qx0[k]; cring[3 * A_RING + hb_ + lane] = qc0[k]; } \
+                      if (lane + 64u < qne[k]) { xring[A_RING + hb_ + lane + 64u] = qx1[k]; cring[3 * A_RING + hb_ + lane + 64u] = qc1[k]; } }
+#pragma unroll
+            for (int k = 0; k < A_PF; k++) Q_REC(k, e0 + k);
+#pragma unroll
+            for (int k = 0; k < A_PF; k++) { Q_IDX(k, e0 + k); Q_REC(k, e0 + A_PF + k); }
+#pragma unroll
+            for (int k = 0; k < T_PM; k++) Q_VAL(k);
+            Q_PUT(0, e0);
+            if (lane == 0) shRec[(e0 + A_PF) & 3] = qrec[0];
+            t_barrier();
+            for (int e = e0; e < sb; e += A_PF) {
+#pragma unroll
+                for (int k = 0; k < A_PF; k++) {
+                    const int ee = e + k;
+                    Q_PUT((k + 1) % A_PF, ee + 1);
+                    if (lane == 0) shRec[(ee + 1 + A_PF) & 3] = qrec[(k + 1) % A_PF];
+                    Q_IDX(k, ee + A_PF);
+                    Q_REC(k, ee + 2 * A_PF);
+                    Q_VAL((k + T_PM) % A_PF);
+                    t_barrier();
+                }
+            }
+#undef Q_REC
+#undef Q_IDX
+#undef Q_VAL
+#undef Q_PUT
+        } else {
+            // ---------------------------------------------------------------- compute waves
+            unsigned pc[A_PF];
+            bool pok[A_PF], pst[A_PF];
+            uint4 pq[A_PF];
+            double pb[A_PF][3], pd[A_PF], px[A_PF];
+#define A_FETCH(k, e, R_) {                                                                              \
+        const unsigned cnt_ = ((e) < e1) ? ((unsigned)(R_).y & 0xFFFFu) : 0u;                            \
+        const bool ok_ = tid < cnt_;                                                                     \
+        const unsigned cc_ = ok_ ? (unsigned)(R_).x + tid : gs;                                          \
+        const unsigned o8_ = cc_ * 8u;                                                                   \
+        pq[k] = *(const uint4 *)((const char *)t.code + cc_ * 16u);                                      \
+        { const T3 v_ = *(const T3 *)((const char *)bc + cc_ * 24u); pb[k][0] = v_.a; pb[k][1] = v_.b; pb[k][2] = v_.c; } \
+        pd[k] = *(const double *)((const char *)diag + o8_);                                             \
+        px[k] = *(const double *)((const char *)x + o8_);                                                \
+        pc[k] = cc_; pok[k] = ok_; pst[k] = ok_ && (e) >= sa && (e) < sb;                                \
+    }
+#define A_FILL(k) { if (pok[k]) { const unsigned i_ = (pc[k] - gs) & (unsigned)(A_RING - 1); xring[i_] = px[k];    \
+                                   cring[3u * i_] = pb[k][0]; cring[3u * i_ + 1u] = pb[k][1]; cring[3u * i_ + 2u] = pb[k][2]; } }
+#pragma unroll
+            for (int k = 0; k < A_PF; k++) { const int4 R0 = t.rec[min(e0 + k, e1)]; A_FETCH(k, e0 + k, R0); }
+#pragma unroll
+            for (int k = 0; k < A_AHEAD; k++) A_FILL(k);
+            t_barrier();
+            for (int e = e0; e < sb; e += A_PF) {
+#pragma unroll
+                for (int k = 0; k < A_PF; k++) {
+                    const int ee = e + k;
+                    const int4 Rn = shRec[(ee + A_PF) & 3];
+                    {
+                        const unsigned c = pc[k];
+                        const unsigned hb = (unsigned)(ee & 1) * (unsigned)A_XMAX;
+                        const unsigned cd[6] = {pq[k].x & 0xFFFFu, pq[k].x >> 16, pq[k].y & 0xFFFFu, pq[k].y >> 16, pq[k].z & 0xFFFFu, pq[k].z >> 16};
+                        const double xc = px[k];
+                        double acc = pd[k] * xc;
+#pragma unroll
+                        for (int s = 0; s < 3; s++) {       // lower faces: x and the coefficient from the owner's ring slot
+                            const unsigned m = (unsigned)((int)(cd[s] << 16) >> 31);
+                            const unsigned ri = (c - (cd[s] & 0x7FFu) - gs) & (unsigned)(A_RING - 1);
+                            const unsigned hi = hb + (cd[s] & (unsigned)(A_XMAX - 1));
+                            const unsigned xi = ri ^ ((ri ^ ((unsigned)A_RING + hi)) & m);
+                            const unsigned ci = (3u * ri + ((cd[s] >> 12) & 3u)) ^ (((3u * ri + ((cd[s] >> 12) & 3u)) ^ (3u * (unsigned)A_RING + hi)) & m);
+                            const double nv = acc + cring[ci] * xring[xi];
+                            acc = (cd[s] != A_NONE) ? nv : acc;
+                        }
+#pragma unroll
+                        for (int s = 0; s < 3; s++) {       // upper faces: own coefficient
+                            const unsigned u = cd[3 + s];
+                            const unsigned m = (unsigned)((int)(u << 16) >> 31);
+                            const unsigned ri = (c + (u & 0x7FFu) - gs) & (unsigned)(A_RING - 1);
+                            const unsigned xi = ri ^ ((ri ^ ((unsigned)A_RING + hb + (u & (unsigned)(A_XMAX - 1)))) & m);
+                            const double nv = acc + pb[k][s] * xring[xi];
+                            acc = (u != A_NONE) ? nv : acc;
+                        }
+                        if (pst[k]) __builtin_nontemporal_store(acc, (double *)((char *)y + c * 8u));
+                        if (DOT) dot += pst[k] ? acc * xc : 0.0;
+                    }
+                    A_FILL((k + A_AHEAD) % A_PF);           // rings: entry ee + A_AHEAD
+                    A_FETCH(k, ee + A_PF, Rn);
+                    t_barrier();
+                }
+            }
+#undef A_FETCH
+#undef A_FILL
+        }
+    }
+    if (DOT) {
+        const double rsum = block_sum(dot, sm);
+        if (tid == 0) partials[blockIdx.x] = rsum;
+    }
+}
+
+// faces towards ghost cells, in slot order, added to the finished owned part of the row
+__global__ void k_amul_tail(int n, const int *__restrict__ cell, const int *__restrict__ start, const int *__restrict__ face,
+                            const int *__restrict__ nbr, const double *__restrict__ upper, const double *__restrict__ x, double *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell[i];
+    double acc = y[c];
+    for (int q = start[i]; q < start[i + 1]; q++) acc += upper[face[q]] * x[nbr[q]];
+    y[c] = acc;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_sum_partials(int n, const double *__restrict__ partials, double *__restrict__ scal, int slot)
+{
+    __shared__ double sm[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) scal[slot] = r;
+}
+
+bool ffm_tile_amul_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable && A->symmetric && A->ifaces.empty(); }
+
+// y = A x (symmetric A); dotSlot >= 0: also scal[dotSlot] = x.y over the owned rows (local part)
+int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot)
+{
+    ffm_tile_plan *T = A->tile;
+    hipStream_t s = A->ctx->stream;
+    const double *bcoef;
+    FFM_TRY(tile_coef(A, T->b, true, &bcoef));
+    AmulView v; v.G = T->G; v.grpCell = A->grpCell; v.grpEnt = T->f.grpEnt; v.rec = T->arec; v.seg = T->aseg; v.code = T->acode; v.ext = T->aext;
+    const bool fusedDot = dotSlot >= 0 && T->nTail == 0 && T->nSeg <= 4 * RED_BLOCKS;
+    if (fusedDot) {
+        hipLaunchKernelGGL((k_tile_amul<true>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, A->ctx->partials_d);
+        hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->nSeg, (const double *)A->ctx->partials_d, A->ctx->scal_d, dotSlot);
+    } else {
+        hipLaunchKernelGGL((k_tile_amul<false>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, (double *)nullptr);
+        if (T->nTail > 0)
+            hipLaunchKernelGGL(k_amul_tail, dim3((T->nTail + 255) / 256), dim3(256), 0, s, T->nTail, (const int *)T->tailCell, (const int *)T->tailStart,
+                               (const int *)T->tailFace, (const int *)T->tailNbr, (const double *)A->upper, x, y);
+    }
+    FFM_HIP(hipGetLastError());
+    return fusedDot || dotSlot < 0 ? FFM_OK : 1;       // 1: the caller still has to take the dot product
 }
 
 // Diagnostics: the first call switches tracing on; later calls copy out, for the LAST tiled launch, 4 words per group:

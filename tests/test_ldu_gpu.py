@@ -166,7 +166,8 @@ def test_fixed_iteration_history_matches(O, ctx, case):
         pg = A.solve(psi, ctx.to_device(b), tolerance=0.0, minIter=k, maxIter=k)
         assert pg["nIterations"] == pr["nIterations"] == k
         assert rel_l2(psi.cpu().numpy(), ref) < 1e-12
-        assert abs(pg["finalResidual"] - pr["finalResidual"]) <= 1e-10 * pr["finalResidual"]
+        # (absolute slack: on the chain the residual after one exact-Cholesky iteration is pure rounding noise)
+        assert abs(pg["finalResidual"] - pr["finalResidual"]) <= 1e-10 * pr["finalResidual"] + 1e-13
 
 
 def test_solver_edge_cases(O, ctx, ffm):
