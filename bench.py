@@ -10,8 +10,9 @@ solver/fireFoam.C:97-119): rhoEqn, UEqn (3 PBiCGStab+DILU solves), YEEqn (4 spec
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus `roofline` (the pEqn PCG SpMV
-kernel against the 8 TB/s HBM peak, algorithmic bytes 24 N + 16 F) and `cpu_baseline` (the oracle
-port on one host core, bounded sample, scaled by cell count).
+kernel against the 8 TB/s HBM peak, algorithmic bytes 24 N + 16 F; `traffic` = the PMC figure of
+profiles/spmv_traffic.json, quoted for the configuration it was measured on) and `cpu_baseline` (the
+oracle port on one host core, bounded sample, scaled by cell count).
 """
 import argparse
 import json
@@ -118,7 +119,8 @@ def main():
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_rows<0,*> (lduMatrix::Amul, symmetric p_rgh matrix)", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "k_tile_amul (lduMatrix::Amul, symmetric p_rgh matrix, tile numbering%s)" % ("" if world == 1 else "; + ghost refresh and ghost-face tail"),
+                "achieved": round(achieved, 1),
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(ms.value, 5)}
 
