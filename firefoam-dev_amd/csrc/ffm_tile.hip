@@ -36,9 +36,10 @@ constexpr int T_PM = 3;             // mailbox values are loaded this many entri
 constexpr int T_XMAX = 64;          // max external references per entry (one lane of the mail wave each; power of two)
 constexpr int T_RINGD = T_RING - 2 * T_ENT;     // largest cell distance served by the ring
 constexpr unsigned T_SPIN_LIMIT = 1u << 22;
-constexpr unsigned T_NONE = 0xFFFFu, T_EXT = 0x8000u;
+constexpr unsigned T_NONE = 0xFFFFu;               // absent neighbour / cell that publishes nothing
+constexpr int T_LDS = T_RING + 2 * T_XMAX + 1;      // ring, two external buffers (entry parity), one dummy slot read by absent neighbours
 constexpr unsigned long long T_SENT = 0x7FF4DEADBEEFCAFEull;    // signalling NaN: no arithmetic result has these bits
-static_assert(T_RINGD < (int)T_EXT && T_ENT <= 256, "neighbour codes: 15-bit ring distance or 8-bit mailbox slot");
+static_assert(T_LDS < (int)T_NONE && T_ENT <= 256, "neighbour codes are LDS slots");
 static_assert(T_PM >= 2 && T_PM < T_PF, "read-ahead distances");
 
 struct TileDir {            // one sweep direction (device arrays)
@@ -46,7 +47,8 @@ struct TileDir {            // one sweep direction (device arrays)
     int *grpEnt = nullptr;      // [G+1] entries of each group
     int4 *rec = nullptr;        // [nEnt + pad] {first cell, cells | externals << 16, first mailbox slot, first extSrc index}
     int *extSrc = nullptr;      // mailbox slot of every external reference, entry by entry
-    unsigned short *code = nullptr;   // [4*nOwn] per cell: 3 neighbour codes (ring distance | T_EXT + index | T_NONE), publish slot | T_NONE
+    unsigned short *code = nullptr;   // [4*nOwn] per cell: 3 neighbour codes = the LDS slot holding the neighbour's value when the cell is computed
+                                      // (ring slot (nb - group start) mod T_RING, or T_RING + parity(entry)*T_XMAX + external index; T_NONE: no neighbour), publish slot | T_NONE
     int *src = nullptr;         // [3*nOwn] native coefficient index of each neighbour slot (-1: none)
     double *coefU = nullptr, *coefL = nullptr;        // [3*nOwn] gathered upper / lower coefficients (lazily allocated)
     unsigned long epochU = ~0ul, epochL = ~0ul;
@@ -170,8 +172,10 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
     }
     // neighbour codes and the external lists (mailbox slots are known for every group now)
     std::vector<int> extSrc;
-    for (auto &R : rec) {
+    for (size_t ei = 0; ei < rec.size(); ei++) {
+        int4 &R = rec[ei];
         const int c0 = R.x, cnt = R.y & 0xFFFF;
+        const int gs = cnt ? grpCell[grpOfCell[c0]] : 0;
         R.w = (int)extSrc.size();
         int t = 0;
         for (int c = c0; c < c0 + cnt; c++) for (int k = 0; k < W; k++) {
@@ -179,8 +183,8 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
             if (nb < 0) continue;
             if (isExt(c, nb)) {
                 if (mailIdx[nb] < 0) { ffm_set_error("internal: tile plan references an unpublished cell"); return FFM_ERR_ADDR; }
-                code[(size_t)4 * c + k] = (unsigned short)(T_EXT | t); extSrc.push_back(mailIdx[nb]); t++;
-            } else code[(size_t)4 * c + k] = (unsigned short)std::abs(c - nb);
+                code[(size_t)4 * c + k] = (unsigned short)(T_RING + (int)(ei & 1) * T_XMAX + t); extSrc.push_back(mailIdx[nb]); t++;
+            } else code[(size_t)4 * c + k] = (unsigned short)((nb - gs) & (T_RING - 1));
         }
         if (t != (R.y >> 16)) { ffm_set_error("internal: tile plan external count mismatch"); return FFM_ERR_ADDR; }
     }
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
 {
     constexpr bool ASC = MODE != TM_BWD;
     constexpr int W = T_W;
-    __shared__ double ring[T_RING + 2 * T_XMAX];      // ring of this group's values, then the two halo buffers
+    __shared__ double ring[T_LDS];                    // ring of this group's values, the two halo buffers, the dummy slot
     double *const halo = ring + T_RING;
     __shared__ int4 shRec[4];           // entry records handed from the mail wave to the compute waves
     __shared__ int shG;
@@ -459,16 +463,10 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
             // ---- entry ee from slot k (idle lanes work on the dummy cell gs; nothing of theirs is stored)
             {
                 const unsigned c = pc[k];
-                const unsigned hb = (unsigned)T_RING + (unsigned)(ee & 1) * (unsigned)T_XMAX;
                 const unsigned cd[4] = {pq[k].x & 0xFFFFu, pq[k].x >> 16, pq[k].y & 0xFFFFu, pq[k].y >> 16};
                 double x[W];
 #pragma unroll
-                for (int s = 0; s < W; s++) {
-                    const unsigned ri = ((ASC ? c - cd[s] : c + cd[s]) - gs) & (unsigned)(T_RING - 1);
-                    const unsigned hi = hb + (cd[s] & (unsigned)(T_XMAX - 1));
-                    const unsigned m = (unsigned)((int)(cd[s] << 16) >> 31);          // all ones for an external (or absent) neighbour
-                    x[s] = ring[ri ^ ((ri ^ hi) & m)];
-                }
+                for (int s = 0; s < W; s++) x[s] = ring[min(cd[s], (unsigned)(T_LDS - 1))];     // the plan stores the LDS slot itself
                 const double d = pd[k];
                 double val;
                 if (MODE == TM_FWD) {
