@@ -124,6 +124,9 @@ def lib():
         "ffm_reduce_summag": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_mesh_create": ([vp, hp, hp, hp, hp, hp, hp, C.c_int, ip, C.POINTER(ip), C.POINTER(hp), C.POINTER(hp), C.POINTER(vp)], C.c_int),
         "ffm_mesh_destroy": ([vp], C.c_int),
+        "ffm_mesh_set_face_centres": ([vp, hp], C.c_int),
+        "ffm_fv_lust_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvm_relax": ([vp, C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_mesh_nboundary": ([vp], C.c_int),
         "ffm_mesh_nnative": ([vp], C.c_int),
         "ffm_faces_to_native": ([vp, hp, dp], C.c_int),
@@ -519,6 +522,11 @@ class fvMesh:
         if getattr(self, "h", None):
             lib().ffm_mesh_destroy(self.h)
             self.h = None
+
+    def set_face_centres(self, Cf):
+        """Cf[3][F] in LDU face order (mesh.Cf(), needed by the LUST correction)."""
+        a = np.ascontiguousarray(Cf, np.float64)
+        _check(lib().ffm_mesh_set_face_centres(self.h, _hp(a)), "ffm_mesh_set_face_centres")
 
     def to_native(self, faceField):
         out = self.ctx.zeros(max(self.nNative, 1))

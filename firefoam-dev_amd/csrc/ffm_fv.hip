@@ -30,6 +30,7 @@ struct ffm_mesh {
     // device geometry
     double *V = nullptr, *C[3] = {nullptr, nullptr, nullptr};
     double *Sf[3] = {nullptr, nullptr, nullptr}, *magSf = nullptr, *delta = nullptr, *w = nullptr;  // [nNat]
+    double *Cf[3] = {nullptr, nullptr, nullptr};     // [nNat] face centres (optional: ffm_mesh_set_face_centres, needed by LUST)
     double *invT = nullptr;          // [6][N] inverse of surfaceSum(Sf (x) Sf / magSf), symmetric
     int *bCells = nullptr;           // [B] face cell of each boundary face
     double *bSf[3] = {nullptr, nullptr, nullptr}, *bMagSf = nullptr, *bDelta = nullptr;           // [B]
@@ -167,7 +168,7 @@ extern "C" int ffm_mesh_destroy(ffm_mesh *m)
     hipStreamSynchronize(m->ctx->stream);
     hipFree(m->V); hipFree(m->magSf); hipFree(m->delta); hipFree(m->w); hipFree(m->invT); hipFree(m->bCells);
     hipFree(m->bMagSf); hipFree(m->bDelta); hipFree(m->cellB); hipFree(m->bcStart); hipFree(m->bcItem);
-    for (int d = 0; d < 3; d++) { hipFree(m->C[d]); hipFree(m->Sf[d]); hipFree(m->bSf[d]); }
+    for (int d = 0; d < 3; d++) { hipFree(m->C[d]); hipFree(m->Sf[d]); hipFree(m->bSf[d]); hipFree(m->Cf[d]); }
     delete m;
     return FFM_OK;
 }
@@ -250,6 +251,7 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
             double wgt;
             if (scheme == 0) wgt = p0;
             else if (scheme == 1) wgt = q.w[e];
+            else if (scheme == 4) wgt = 0.75 * q.w[e] + 0.25 * p0;          // LUST<Type>::weights
             else {
                 const double Nn = vf[nb];
                 const double dx = Cx[nb] - Cx[c], dy = Cy[nb] - Cy[c], dz = Cz[nb] - Cz[c];
@@ -269,6 +271,59 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
             }
             out[e] = wgt;
         }
+    }
+}
+
+// LUST<Type>::correction = 0.25 * linearUpwind<Type>::correction: (Cf - C_c) & grad(vf)_c, c = owner if the flux is > 0, else
+// the neighbour (one scalar component; zero on non-coupled patches, which is what the boundary part of the caller holds)
+__global__ void k_lust_correction(MeshView q, const double *__restrict__ phi, const double *__restrict__ gx, const double *__restrict__ gy,
+                                  const double *__restrict__ gz, const double *__restrict__ Cx, const double *__restrict__ Cy,
+                                  const double *__restrict__ Cz, const double *__restrict__ Cfx, const double *__restrict__ Cfy,
+                                  const double *__restrict__ Cfz, double *__restrict__ out)
+{
+    GRID_STRIDE(ci, q.v.N) {
+        const int c = (int)ci;
+        FOR_OWN_FACES(q, c, e, nb) {
+            const int up = phi[e] > 0 ? c : nb;
+            const double dx = Cfx[e] - Cx[up], dy = Cfy[e] - Cy[up], dz = Cfz[e] - Cz[up];
+            out[e] = 0.25 * ((dx * gx[up] + dy * gy[up]) + dz * gz[up]);
+        }
+    }
+}
+
+// fvMatrix<Type>::relax(alpha), non-coupled patches (coupled faces of a decomposed block are ordinary faces towards ghost
+// cells here and enter sumMagOffDiag like internal faces).  One thread per row, sums in face order.
+template <int W>
+__global__ void k_relax(MeshView q, double alpha, int nc, const double *__restrict__ upper, const double *__restrict__ lower,
+                        const double *__restrict__ ic0, const double *__restrict__ ic1, const double *__restrict__ ic2,
+                        double *__restrict__ diag, const double *__restrict__ p0, const double *__restrict__ p1,
+                        const double *__restrict__ p2, double *__restrict__ s0, double *__restrict__ s1, double *__restrict__ s2)
+{
+    GRID_STRIDE(ci, q.v.N) {
+        const int c = (int)ci;
+        RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
+        double sumOff = 0.0;
+#pragma unroll
+        for (int s = 0; s < W; s++) if (L.on[s]) sumOff += fabs(lower[L.f[s]]);
+#pragma unroll
+        for (int s = 0; s < W; s++) if (U.on[s]) sumOff += fabs(upper[U.f[s]]);
+        const double D0 = diag[c];
+        double D = D0;
+        const int j = q.cellB[c];
+        if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) {
+            const int k = q.bcItem[t];
+            D += (nc == 3) ? fmax(fmax(fabs(ic0[k]), fabs(ic1[k])), fabs(ic2[k])) : fabs(ic0[k]);
+        }
+        D = fmax(fabs(D), sumOff);
+        D = D / alpha;
+        if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) {
+            const int k = q.bcItem[t];
+            D -= (nc == 3) ? fmin(fmin(ic0[k], ic1[k]), ic2[k]) : ic0[k];
+        }
+        diag[c] = D;
+        const double dd = D - D0;
+        s0[c] += dd * p0[c];
+        if (nc == 3) { s1[c] += dd * p1[c]; s2[c] += dd * p2[c]; }
     }
 }
 
@@ -536,8 +591,39 @@ extern "C" int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double 
                                       const double *vf, const double *gx, const double *gy, const double *gz, double *out_w)
 {
     CHECK_M(m);
-    if (scheme < 0 || scheme > 3 || !phi_f || !out_w || (scheme >= 2 && (!vf || !gx || !gy || !gz))) return FFM_ERR_ARG;
+    if (scheme < 0 || scheme > 4 || !phi_f || !out_w || ((scheme == 2 || scheme == 3) && (!vf || !gx || !gy || !gz))) return FFM_ERR_ARG;
     LAUNCH(k_limited_weights, m->N, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], out_w);
+    DONE();
+}
+extern "C" int ffm_mesh_set_face_centres(ffm_mesh *m, const double *Cf)
+{
+    CHECK_M(m);
+    if (!Cf) return FFM_ERR_ARG;
+    for (int d = 0; d < 3; d++) {
+        std::vector<double> v(std::max(m->nNat, 1), 0.0);
+        for (int f = 0; f < m->F; f++) v[m->A->h_callerToNative[f]] = Cf[(size_t)d * m->F + f];
+        hipFree(m->Cf[d]); m->Cf[d] = nullptr;
+        FFM_TRY(up(m->ctx, &m->Cf[d], v));
+    }
+    return FFM_OK;
+}
+extern "C" int ffm_fv_lust_correction(ffm_mesh *m, const double *phi_f, const double *gx, const double *gy, const double *gz, double *out_f)
+{
+    CHECK_M(m);
+    if (!phi_f || !gx || !gy || !gz || !out_f) return FFM_ERR_ARG;
+    if (!m->Cf[0]) { ffm_set_error("ffm_fv_lust_correction: face centres not set (ffm_mesh_set_face_centres)"); return FFM_ERR_ARG; }
+    LAUNCH(k_lust_correction, m->N, mview(m), phi_f, gx, gy, gz, m->C[0], m->C[1], m->C[2], m->Cf[0], m->Cf[1], m->Cf[2], out_f);
+    DONE();
+}
+extern "C" int ffm_fvm_relax(ffm_mesh *m, double alpha, int nc, const double *upper, const double *lower, const double *ic0,
+                             const double *ic1, const double *ic2, double *diag, const double *psi0, const double *psi1,
+                             const double *psi2, double *src0, double *src1, double *src2)
+{
+    CHECK_M(m);
+    if ((nc != 1 && nc != 3) || !upper || !lower || !diag || !psi0 || !src0 || (m->B && !ic0)) return FFM_ERR_ARG;
+    if (nc == 3 && (!psi1 || !psi2 || !src1 || !src2 || (m->B && (!ic1 || !ic2)))) return FFM_ERR_ARG;
+    if (alpha <= 0) return FFM_OK;                              // fvMatrix::relax: no-op
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_relax<W>, m->N, mview(m), alpha, nc, upper, lower, ic0, ic1, ic2, diag, psi0, psi1, psi2, src0, src1, src2));
     DONE();
 }
 extern "C" int ffm_fvm_transport(ffm_mesh *m, double rDeltaT, const double *rho, const double *phi_f, const double *w_f,

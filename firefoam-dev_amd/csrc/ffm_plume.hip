@@ -20,6 +20,8 @@ extern "C" {
 int ffm_mesh_create(ffm_ldu *, const double *, const double *, const double *, const double *, const double *, const double *, int,
                     const int *, const int *const *, const double *const *, const double *const *, ffm_mesh **);
 int ffm_mesh_destroy(ffm_mesh *);
+int ffm_mesh_set_face_centres(ffm_mesh *, const double *);
+int ffm_fv_lust_correction(ffm_mesh *, const double *, const double *, const double *, const double *, double *);
 int ffm_fvc_interpolate(ffm_mesh *, const double *, const double *, double *);
 int ffm_fvc_snGrad(ffm_mesh *, const double *, double *);
 int ffm_fvc_snGrad_b(ffm_mesh *, const double *, const double *, double *);
@@ -367,15 +369,10 @@ extern "C" int ffm_plume_step(ffm_plume *P)
     FFM_TRY(update_bcs(P));
     double *Ub[3] = {P->wB[1], P->wB[2], P->wB[3]};
     FFM_TRY(U_boundary(P, Ub));
-    double *mag2 = P->wN[0], *mag2b = P->wB[0], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *wU = P->wF[3];
-    {
-        const double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2], *b0 = Ub[0], *b1 = Ub[1], *b2 = Ub[2];
-        forN(P, N, [=] __device__(long i) { mag2[i] = (U0[i] * U0[i] + U1[i] * U1[i]) + U2[i] * U2[i]; });
-        forN(P, B, [=] __device__(long k) { mag2b[k] = (b0[k] * b0[k] + b1[k] * b1[k]) + b2[k] * b2[k]; });
-    }
-    FFM_TRY(ffm_fvc_grad(m, mag2, mag2b, gx, gy, gz));
-    FFM_TRY(HX(P, gx)); FFM_TRY(HX(P, gy)); FFM_TRY(HX(P, gz));
-    FFM_TRY(ffm_fv_limited_weights(m, 2, 1.0, 0.0, 1.0, P->phi, mag2, gx, gy, gz, wU));
+    // div(phi,U) Gauss LUST grad(U) (cases/steckler/system/fvSchemes:32): LUST weights for the implicit part; the explicit
+    // correction is added to the source below
+    double *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *wU = P->wF[3];
+    FFM_TRY(ffm_fv_limited_weights(m, 4, 1.0, 0.0, 1.0, P->phi, nullptr, nullptr, nullptr, nullptr, wU));
     double *muf = P->wF[0], *mub = P->wB[4];
     forN(P, nNat, [=] __device__(long e) { muf[e] = MU; });
     forN(P, B, [=] __device__(long k) { mub[k] = MU; });
@@ -398,8 +395,15 @@ extern "C" int ffm_plume_step(ffm_plume *P)
     double *rec[3] = {rx, ry, rz};
     for (int c = 0; c < 3; c++) {
         FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, mub, -1, P->fU[c], P->refU[c], P->zeroB, P->Uic[c], P->Ubc[c]));
+        // gaussConvectionScheme::fvmDiv with a corrected() scheme: fvm += fvc::surfaceIntegrate(phi*LUST::correction(U_c))
+        double *corr = P->wF[4], *divc = P->wN[4];
+        FFM_TRY(ffm_fvc_grad(m, P->U[c], Ub[c], gx, gy, gz));
+        FFM_TRY(HX(P, gx)); FFM_TRY(HX(P, gy)); FFM_TRY(HX(P, gz));
+        FFM_TRY(ffm_fv_lust_correction(m, P->phi, gx, gy, gz, corr));
+        { const double *phi = P->phi; forN(P, nNat, [=] __device__(long e) { corr[e] = phi[e] * corr[e]; }); }
+        FFM_TRY(ffm_fvc_surface_integrate(m, corr, P->zeroB, divc));
         double *s = P->Usrc[c]; const double *rho0 = P->rho0, *u0 = P->U0[c];
-        forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * u0[i] * V[i]; });
+        forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * u0[i] * V[i] - V[i] * divc[i]; });
     }
     for (int c = 0; c < 3; c++) {
         FFM_TRY(ffm_fvm_add_boundary(m, P->Uic[c], P->Ubc[c], P->Udiag, P->Usrc[c], rec[c], P->dWork, P->sWork));
@@ -591,6 +595,12 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     }
     P->B = Btot;
     FFM_TRY(ffm_mesh_create(P->A, V.data(), C.data(), Sf.data(), magSf.data(), wgt.data(), del.data(), 4, sizes, fcs, pSf, pDel, &P->mesh));
+    {
+        // face centres (LUST correction): owner's centre + half a cell towards the neighbour
+        std::vector<double> Cf(3 * (size_t)F);
+        for (int f = 0; f < F; f++) for (int d = 0; d < 3; d++) Cf[(size_t)d * F + f] = C[(size_t)d * N + l2[f]] + (fd2[f] == d ? sg2[f] * 0.5 * h : 0.0);
+        FFM_TRY(ffm_mesh_set_face_centres(P->mesh, Cf.data()));
+    }
     const int ny_glob = gy;
     const int B = Btot; const long nNat = P->nNat;
     // ---- fields

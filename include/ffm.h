@@ -201,6 +201,8 @@ int ffm_mesh_create(ffm_ldu *ldu, const double *V, const double *C,
                     const double *deltaCoeffs, int nPatches, const int *patchSizes,
                     const int *const *faceCells, const double *const *patchSf,
                     const double *const *patchDeltaCoeffs, ffm_mesh **out);
+/* mesh.Cf() of the internal faces, host array Cf[3][F] in LDU face order (needed by the LUST correction only) */
+int ffm_mesh_set_face_centres(ffm_mesh *mesh, const double *Cf);
 int ffm_mesh_destroy(ffm_mesh *mesh);
 int ffm_mesh_nboundary(const ffm_mesh *mesh);
 int ffm_mesh_nnative(const ffm_mesh *mesh);
@@ -219,11 +221,17 @@ int ffm_fvc_surface_sum(ffm_mesh *m, const double *ssf_f, const double *ssf_b, d
 int ffm_fvc_grad(ffm_mesh *m, const double *vf, const double *vb, double *gx, double *gy, double *gz);
 int ffm_fvc_reconstruct(ffm_mesh *m, const double *ssf_f, const double *ssf_b, double *ox, double *oy, double *oz);
 /* limitedSurfaceInterpolationScheme weights: scheme 0 upwind, 1 linear,
- * 2 limitedLinear k, 3 limitedLinear01 k with bounds [lo,hi]
- * (cases/steckler/system/fvSchemes:28-54)                                    */
+ * 2 limitedLinear k, 3 limitedLinear01 k with bounds [lo,hi], 4 LUST (0.75 linear +
+ * 0.25 upwind; vf and gradients unused)  (cases/steckler/system/fvSchemes:28-54) */
 int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double hi,
                            const double *phi_f, const double *vf, const double *gx,
                            const double *gy, const double *gz, double *out_w_f);
+
+/* LUST<Type>::correction(vf) for one scalar component, internal faces: 0.25*(Cf - C_c) & grad(vf)_c with c the upwind cell
+ * (`div(phi,U) Gauss LUST grad(U)`, cases/steckler/system/fvSchemes:32; solver/UEqn.H:5).  gaussConvectionScheme::fvmDiv
+ * then adds fvc::surfaceIntegrate(phi*correction) to the matrix: source -= V * ffm_fvc_surface_integrate(phi_f*corr_f, 0). */
+int ffm_fv_lust_correction(ffm_mesh *m, const double *phi_f, const double *gx, const double *gy,
+                           const double *gz, double *out_f);
 
 /* ------------------------------------------------------- fvm:: (implicit)    */
 /* [fvm::ddt(rho,.)] + [fvm::div(phi,.)] (+/-) [fvm::laplacian(gamma,.)] in one
@@ -243,6 +251,13 @@ int ffm_bc_values(ffm_mesh *m, const double *f, const double *ref, const double 
 int ffm_fvm_add_boundary(ffm_mesh *m, const double *internalCoeffs, const double *boundaryCoeffs,
                          const double *diag, const double *source, const double *su,
                          double *diagOut, double *sourceOut);
+/* fvMatrix<Type>::relax(alpha) (solver/UEqn.H:13, solver/YEEqn.H:56,107; equation factors e.g.
+ * cases/wallFireSpread2D/system/fvSolution:194-200): diagonal dominance + under-relaxation in place,
+ * source_c += (D - D0)*psiPrev_c for nCmpt = 1 or 3 components sharing the coefficients.            */
+int ffm_fvm_relax(ffm_mesh *m, double alpha, int nCmpt, const double *upper, const double *lower,
+                  const double *ic0, const double *ic1, const double *ic2, double *diag,
+                  const double *psiPrev0, const double *psiPrev1, const double *psiPrev2,
+                  double *source0, double *source1, double *source2);
 /* fvMatrix::A(), H() (one component), flux()  (solver/pEqn.H:3,5,43)          */
 int ffm_fvm_A(ffm_mesh *m, int nCmpt, const double *diag, const double *ic0, const double *ic1,
               const double *ic2, double *out);

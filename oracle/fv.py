@@ -263,6 +263,21 @@ def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
     return lim * w + (1.0 - lim) * pos0(phi)
 
 
+def lust_weights(mesh, phi):
+    """LUST<Type>::weights (OpenFOAM-dev src/finiteVolume/interpolation/surfaceInterpolation/schemes/LUST/LUST.H):
+    0.75*linear weights + 0.25*upwind weights; reference selection cases/steckler/system/fvSchemes:32."""
+    return 0.75 * mesh.weights + 0.25 * pos0(phi)
+
+
+def lust_correction(mesh, phi, gradvf):
+    """LUST<Type>::correction = 0.25*linearUpwind<Type>::correction: per internal face (Cf - C_c) & grad(vf)_c with
+    c = owner if phi > 0 else neighbour (linearUpwind.C); zero on non-coupled patches.  One scalar component."""
+    cell = np.where(phi > 0, mesh.l, mesh.u)
+    d = mesh.Cf - mesh.C[cell]
+    g = gradvf[cell]
+    return 0.25 * ((d[:, 0] * g[:, 0] + d[:, 1] * g[:, 1]) + d[:, 2] * g[:, 2])
+
+
 class Matrix:
     """fvMatrix<Type> with nc components sharing diag/upper/lower (Type = scalar: nc=1, vector: nc=3)."""
 
@@ -294,6 +309,34 @@ class Matrix:
     def add_su(self, su):
         """`M == su` / `M - su` for a volField su: source += V*su."""
         self.source += self.mesh.V * np.atleast_2d(su)
+        return self
+
+    def add_vol(self, su):
+        """`M += su` for a volField su (fvMatrix::operator+=(volField)): source -= V*su.  Used by gaussConvectionScheme::fvmDiv
+        for corrected() interpolation schemes: fvm += fvc::surfaceIntegrate(faceFlux*correction(vf))."""
+        self.source -= self.mesh.V * np.atleast_2d(su)
+        return self
+
+    def relax(self, alpha, psi_prev):
+        """fvMatrix<Type>::relax(alpha) (OpenFOAM-dev src/finiteVolume/fvMatrices/fvMatrix/fvMatrix.C; reference call sites
+        solver/UEqn.H:13, solver/YEEqn.H:56,107; equation factors cases/wallFireSpread2D/system/fvSolution:194-200), all patches
+        non-coupled: D += cmptMax|internalCoeffs|; D = max(|D|, sumMagOffDiag); D /= alpha; D -= cmptMin(internalCoeffs);
+        source += (D - D0)*psi.prevIter()."""
+        if alpha <= 0:
+            return self
+        m = self.mesh
+        D0 = self.diag.copy()
+        sumOff = np.zeros(m.nCells)
+        np.add.at(sumOff, m.u, np.abs(self.lower))          # rows in face order: faces of which the cell is the neighbour first
+        np.add.at(sumOff, m.l, np.abs(self.upper))
+        D = self.diag
+        for p, ic in zip(m.patches, self.internalCoeffs):
+            np.add.at(D, p.faceCells, np.abs(ic).max(axis=0))
+        D[:] = np.maximum(np.abs(D), sumOff)
+        D /= alpha
+        for p, ic in zip(m.patches, self.internalCoeffs):
+            np.subtract.at(D, p.faceCells, ic.min(axis=0))
+        self.source += (D - D0) * np.atleast_2d(psi_prev)
         return self
 
     def solve_system(self, cmpt=0):

@@ -200,12 +200,16 @@ class Plume:
         # ---- UEqn.H
         bcU = self.bc_U()
         muf = np.full(m.nFaces, MU); mub = [np.full(p.size, MU) for p in m.patches]
-        magSqrU = (self.U ** 2).sum(axis=0)
         Ub = [b.values(m, self.U[c]) for c, b in enumerate(bcU)]
-        magSqrUb = [sum(Ub[c][q] ** 2 for c in range(3)) for q in range(len(m.patches))]
-        wU = fv.limited_weights(m, "limitedLinear", self.phi, magSqrU, fv.grad(m, magSqrU, magSqrUb), 1.0)
+        # div(phi,U) Gauss LUST grad(U) (cases/steckler/system/fvSchemes:32): implicit part with the LUST weights, explicit
+        # correction fvc::surfaceIntegrate(phi*correction(U)) added to the matrix (gaussConvectionScheme::fvmDiv)
+        wU = fv.lust_weights(m, self.phi)
         UEqn = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.U0)
-        UEqn += fv.fvm_div(m, self.phi, self.phib, wU, bcU)
+        divU = fv.fvm_div(m, self.phi, self.phib, wU, bcU)
+        zb = [np.zeros(p.size) for p in m.patches]
+        divU.add_vol(np.stack([fv.surface_integrate(m, self.phi * fv.lust_correction(m, self.phi, fv.grad(m, self.U[c], Ub[c])), zb)
+                               for c in range(3)]))
+        UEqn += divU
         UEqn -= fv.fvm_laplacian(m, muf, mub, bcU)
         rhob = self.zg(self.rho)
         sgr, _ = fv.snGrad(m, self.rho, rhob)

@@ -159,3 +159,48 @@ def test_fvm_assembly_and_matrix_ops(setup, O, ctx):
     mesh.call("fvm_flux", up, lo, ic, bcc, cellf(s, ctx, psi), ff, fb)
     fi, fbr = M.flux(psi)
     assert np.array_equal(back_face(s, ff), fi) and rel_l2(fb.cpu().numpy(), np.concatenate(fbr)) < 1e-15
+
+
+def test_lust_weights_and_correction(setup, O, ctx):
+    """`div(phi,U) Gauss LUST grad(U)` (cases/steckler/system/fvSchemes:32): weights 0.75 linear + 0.25 upwind, explicit
+    correction 0.25*(Cf - C_upwind) & grad(vf)_upwind; both bitwise against oracle/fv.py (same expression order)."""
+    s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
+    vf, phi, vb = fields(s, O)
+    phi = phi.copy(); phi[::7] = 0.0                      # the flux == 0 branch differs between weights (>= 0) and correction (> 0)
+    mesh.set_face_centres(m.Cf[s["fOrd"]].T.copy())
+    w = ctx.zeros(mesh.nNative)
+    mesh.call("fv_limited_weights", 4, 1.0, 0.0, 1.0, facef(s, phi), None, None, None, None, w)
+    assert np.array_equal(back_face(s, w), fv.lust_weights(m, phi))
+    gref = fv.grad(m, vf, vb)
+    g = [cellf(s, ctx, gref[:, d]) for d in range(3)]
+    corr = ctx.zeros(mesh.nNative)
+    mesh.call("fv_lust_correction", facef(s, phi), *g, corr)
+    assert np.array_equal(back_face(s, corr), fv.lust_correction(m, phi, gref))
+
+
+@pytest.mark.parametrize("nc", [1, 3])
+def test_fvm_relax(setup, O, ctx, nc):
+    """fvMatrix::relax(alpha) on a convection-diffusion matrix that is NOT diagonally dominant everywhere (so that the
+    max(|D|, sumMagOffDiag) branch is exercised), scalar and vector (cmptMax / cmptMin of the boundary coefficients)."""
+    s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
+    N = s["N"]
+    vf, phi, vb = fields(s, O)
+    bcs = [fv.MixedBC(m, f=[O.hash_u(90 + 7 * c + q, np.arange(p.size)) for q, p in enumerate(m.patches)],
+                      ref=[np.full(p.size, 0.3 + c) for p in m.patches]) for c in range(nc)]
+    phib = [0.2 * (O.hash_u(60 + q, np.arange(p.size)) - 0.5) for q, p in enumerate(m.patches)]
+    M = fv.fvm_div(m, 5.0 * phi, phib, fv.limited_weights(m, "linear", phi, None, None), bcs)       # central differencing: not dominant
+    M -= fv.fvm_laplacian(m, np.full(s["F"], 1e-3), [np.full(p.size, 1e-3) for p in m.patches], bcs)
+    M += fv.fvm_ddt(m, 0.1, np.ones(N), np.ones(N), np.stack([vf + c for c in range(nc)]))
+    psi = np.stack([vf * (1 + 0.1 * c) for c in range(nc)])
+    up, lo, dg = facef(s, M.upper), facef(s, M.lower), cellf(s, ctx, M.diag)
+    ic = [bndf(ctx, [M.internalCoeffs[q][c] for q in range(len(m.patches))]) for c in range(nc)]
+    src = [cellf(s, ctx, M.source[c]) for c in range(nc)]
+    ps = [cellf(s, ctx, psi[c]) for c in range(nc)]
+    pad = lambda lst: lst + [None] * (3 - len(lst))
+    mesh.call("fvm_relax", 0.7, nc, up, lo, *pad(ic), dg, *pad(ps), *pad(src))
+    D0 = M.diag.copy()
+    M.relax(0.7, psi)
+    assert (np.abs(D0) < np.abs(M.diag) * 0.7 - 1e-15).any()          # dominance was enforced somewhere
+    assert np.array_equal(back_cell(s, dg), M.diag)
+    for c in range(nc):
+        assert np.array_equal(back_cell(s, src[c]), M.source[c])
