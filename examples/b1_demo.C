@@ -1,0 +1,128 @@
+/*---------------------------------------------------------------------------*\
+  b1_demo.C -- solver statements in the style of the reference's solver/rhoEqn.H, YEEqn.H (one specie), UEqn.H and the
+  head of pEqn.H, written against include/ffmFoam.H (B1 of SURVEY 8b) and running on the device through the C ABI.
+  It is NOT the reference's text: the physics handles of the reference (turbulence, combustion, parcels, fvOptions,
+  MRF, thermo) are replaced by plain fields handed in by the caller (dEff, mu, the specie source R).
+
+  Built as libffm_b1demo.so (firefoam-dev_amd/csrc/Makefile, host compiler only) and driven by
+  tests/test_foam_layer_gpu.py, which evaluates the same equations with oracle/fv.py and compares the fields.
+\*---------------------------------------------------------------------------*/
+#include "ffmFoam.H"
+
+using namespace Foam;
+
+namespace
+{
+std::shared_ptr<mixedBC> makeBC(const fvMesh& mesh, const double* f, const double* ref, const double* grad)
+{ return std::make_shared<mixedBC>(mesh.ctx, mesh.nBoundary, f, ref, grad); }
+
+surfaceScalarField surfaceFromHost(const fvMesh& mesh, const double* lduOrder, const double* boundary)
+{
+    surfaceScalarField s(mesh);
+    FFM_FOAM_CHK(ffm_faces_to_native(mesh.msh, lduOrder, s.v.data()));
+    s.b.assignHost(boundary);
+    return s;
+}
+}
+
+// All arrays are host arrays: cell fields [N] in the library's cell order, face fields [F] in LDU face order, boundary fields
+// [B] with the patches concatenated.  bcY = {f, ref, refGrad}, bcU = 3 x {f, ref, refGrad}.  Returns the number of solves.
+extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT, double alphaY,
+                       const double* rhoOld, const double* rhoNow, const double* phiF, const double* phiB,
+                       const double* Yi0, const double* const* bcY, const double* dEffC, const double* RYi,
+                       const double* U0, const double* const* bcU, double muValue,
+                       const double* ghfF, const double* ghfB, const double* p_rgh0, const double* p_rghB,
+                       double* rhoOut, double* YiOut, double* UOut, double* KOut, double* rAUOut, double* HbyAOut, int* nIterOut)
+{
+    fvMesh mesh(ctx, ldu, msh, deltaT);
+    // fvSolution / fvSchemes of the demo (cf. cases/steckler/system/fvSolution:19-83, fvSchemes:28-61)
+    mesh.solvers["rho"] = {FFM_DIAGONAL, FFM_NONE, 1e-6, 0, 0, 1000, 1};
+    mesh.solvers["Yi"] = {FFM_PBICGSTAB, FFM_DILU, 1e-10, 0, 0, 1000, 1};
+    mesh.solvers["U"] = {FFM_PBICGSTAB, FFM_DILU, 1e-10, 0, 0, 1000, 1};
+    mesh.divSchemes["div(phi,U)"] = {4, 1, 0, 1};               // Gauss LUST grad(U)
+    mesh.divSchemes["div(phi,Yi_h)"] = {3, 1, 0, 1};            // Gauss limitedLinear01 1 (multivariateSelection entry)
+    mesh.equationRelaxation["Yi"] = alphaY;
+
+    const label N = mesh.nCells;
+    volScalarField rho("rho", mesh); rho.v.assignHost(rhoOld); rho.b.assignHost(std::vector<double>(mesh.nBoundary, 0.0).data());
+    rho.storeOldTime();
+    rho.v.assignHost(rhoNow);
+    const surfaceScalarField phi(surfaceFromHost(mesh, phiF, phiB));
+    const surfaceScalarField ghf(surfaceFromHost(mesh, ghfF, ghfB));
+
+    // ---- rhoEqn.H
+    {
+        fvScalarMatrix rhoEqn(fvm::ddt(rho) + fvc::div(phi));
+        rhoEqn.solve();
+    }
+    rho.v.toHost(rhoOut);
+
+    // ---- YEEqn.H, one specie
+    volScalarField Yi("Yi", mesh); Yi.v.assignHost(Yi0); Yi.bc = makeBC(mesh, bcY[0], bcY[1], bcY[2]);
+    Yi.correctBoundaryConditions(); Yi.storeOldTime();
+    volScalarField dEff("dEff", mesh); dEff.v.assignHost(dEffC); dEff.b.assignHost(std::vector<double>(mesh.nBoundary, 0.0).data());
+    {   // zeroGradient boundary values of dEff
+        std::vector<double> one(mesh.nBoundary, 0.0), zero(mesh.nBoundary, 0.0);
+        dEff.bc = makeBC(mesh, zero.data(), zero.data(), zero.data()); dEff.correctBoundaryConditions();
+    }
+    volScalarField R("R", mesh); R.v.assignHost(RYi);
+    std::shared_ptr<fv::convectionScheme<scalar>> mvConvection(new fv::convectionScheme<scalar>(mesh, phi, mesh.divSchemeOf("div(phi,Yi_h)")));
+    {
+        fvScalarMatrix YiEqn
+        (
+            fvm::ddt(rho, Yi)
+          + mvConvection->fvmDiv(phi, Yi)
+          - fvm::laplacian(dEff, Yi)
+         ==
+            R
+        );
+        YiEqn.relax();
+        YiEqn.solve(mesh.solver("Yi"));
+        Yi.max(0.0);
+    }
+    Yi.v.toHost(YiOut);
+
+    // ---- UEqn.H
+    volVectorField U("U", mesh);
+    for (int d = 0; d < 3; d++) { U.v[d].assignHost(U0 + (size_t)d*N); U.bc[d] = makeBC(mesh, bcU[3*d], bcU[3*d + 1], bcU[3*d + 2]); }
+    U.correctBoundaryConditions(); U.storeOldTime();
+    volScalarField p_rgh("p_rgh", mesh); p_rgh.v.assignHost(p_rgh0); p_rgh.b.assignHost(p_rghB);
+    volScalarField mu("mu", mesh, muValue);
+    volScalarField rhoB("rho", rho);            // rho with zeroGradient boundary values for snGrad(rho)
+    {
+        std::vector<double> zero(mesh.nBoundary, 0.0);
+        rhoB.bc = makeBC(mesh, zero.data(), zero.data(), zero.data()); rhoB.correctBoundaryConditions();
+    }
+    fvVectorMatrix UEqn
+    (
+        fvm::ddt(rho, U) + fvm::div(phi, U)
+      - fvm::laplacian(mu, U)
+    );
+    UEqn.relax();
+    solve
+    (
+        UEqn
+     ==
+        fvc::reconstruct
+        (
+            (
+              - ghf*fvc::snGrad(rhoB)
+              - fvc::snGrad(p_rgh)
+            )*mesh.magSf()
+        )
+    );
+    volScalarField K("K", 0.5*magSqr(U));
+    for (int d = 0; d < 3; d++) U.v[d].toHost(UOut + (size_t)d*N);
+    K.v.toHost(KOut);
+
+    // ---- head of pEqn.H
+    volScalarField rAU("rAU", 1.0/UEqn.A());
+    volVectorField HbyA(rAU*UEqn.H());
+    rAU.v.toHost(rAUOut);
+    for (int d = 0; d < 3; d++) HbyA.v[d].toHost(HbyAOut + (size_t)d*N);
+
+    FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    int n = 0;
+    for (const solverPerformance& sp : mesh.log) nIterOut[n++] = sp.nIterations;
+    return n;
+}

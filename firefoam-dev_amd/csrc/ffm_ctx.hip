@@ -162,3 +162,58 @@ extern "C" int ffm_reduce_min(ffm_ctx *c, const double *x, long n, double *o) { 
 extern "C" int ffm_reduce_max(ffm_ctx *c, const double *x, long n, double *o) { return reduce_public<R_MAX>(c, x, nullptr, n, o); }
 extern "C" int ffm_reduce_dot(ffm_ctx *c, const double *x, const double *y, long n, double *o) { return reduce_public<R_DOT>(c, x, y, n, o); }
 extern "C" int ffm_reduce_summag(ffm_ctx *c, const double *x, long n, double *o) { return reduce_public<R_SUMMAG>(c, x, nullptr, n, o); }
+
+// ------------------------------------------------------------------ element-wise field algebra ---
+template <class F> __global__ void k_field(long n, F f, double *__restrict__ out)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f(i);
+}
+template <class F> static int field_launch(ffm_ctx *c, long n, F f, double *out)
+{
+    if (!c || n < 0 || (n && !out)) return FFM_ERR_ARG;
+    if (n == 0) return FFM_OK;
+    FFM_HIP(hipSetDevice(c->device));
+    const int g = (int)std::max(1L, std::min((n + 255) / 256, (long)RED_BLOCKS));
+    hipLaunchKernelGGL(k_field<F>, dim3(g), dim3(256), 0, c->stream, n, f, out);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+extern "C" int ffm_field_binary(ffm_ctx *c, int op, long n, const double *a, const double *b, double *out)
+{
+    if (n && (!a || !b)) return FFM_ERR_ARG;
+    switch (op) {
+    case FFM_OP_ADD: return field_launch(c, n, [=] __device__(long i) { return a[i] + b[i]; }, out);
+    case FFM_OP_SUB: return field_launch(c, n, [=] __device__(long i) { return a[i] - b[i]; }, out);
+    case FFM_OP_MUL: return field_launch(c, n, [=] __device__(long i) { return a[i] * b[i]; }, out);
+    case FFM_OP_DIV: return field_launch(c, n, [=] __device__(long i) { return a[i] / b[i]; }, out);
+    case FFM_OP_MAX: return field_launch(c, n, [=] __device__(long i) { return fmax(a[i], b[i]); }, out);
+    case FFM_OP_MIN: return field_launch(c, n, [=] __device__(long i) { return fmin(a[i], b[i]); }, out);
+    }
+    return FFM_ERR_ARG;
+}
+extern "C" int ffm_field_scalar(ffm_ctx *c, int op, long n, const double *a, double s, int sf, double *out)
+{
+    if (n && !a) return FFM_ERR_ARG;
+    switch (op) {
+    case FFM_OP_ADD: return field_launch(c, n, [=] __device__(long i) { return sf ? s + a[i] : a[i] + s; }, out);
+    case FFM_OP_SUB: return field_launch(c, n, [=] __device__(long i) { return sf ? s - a[i] : a[i] - s; }, out);
+    case FFM_OP_MUL: return field_launch(c, n, [=] __device__(long i) { return sf ? s * a[i] : a[i] * s; }, out);
+    case FFM_OP_DIV: return field_launch(c, n, [=] __device__(long i) { return sf ? s / a[i] : a[i] / s; }, out);
+    case FFM_OP_MAX: return field_launch(c, n, [=] __device__(long i) { return fmax(a[i], s); }, out);
+    case FFM_OP_MIN: return field_launch(c, n, [=] __device__(long i) { return fmin(a[i], s); }, out);
+    }
+    return FFM_ERR_ARG;
+}
+extern "C" int ffm_field_unary(ffm_ctx *c, int op, long n, const double *a, double *out)
+{
+    if (n && !a) return FFM_ERR_ARG;
+    switch (op) {
+    case FFM_UN_NEG: return field_launch(c, n, [=] __device__(long i) { return -a[i]; }, out);
+    case FFM_UN_SQR: return field_launch(c, n, [=] __device__(long i) { return a[i] * a[i]; }, out);
+    case FFM_UN_MAG: return field_launch(c, n, [=] __device__(long i) { return fabs(a[i]); }, out);
+    case FFM_UN_SQRT: return field_launch(c, n, [=] __device__(long i) { return sqrt(a[i]); }, out);
+    }
+    return FFM_ERR_ARG;
+}
+extern "C" int ffm_field_fill(ffm_ctx *c, long n, double s, double *out)
+{ return field_launch(c, n, [=] __device__(long) { return s; }, out); }

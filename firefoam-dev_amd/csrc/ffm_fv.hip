@@ -661,6 +661,13 @@ extern "C" int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lowe
     DONE();
 }
 
+extern "C" const double *ffm_mesh_geometry_d(const ffm_mesh *m, int which)
+{
+    if (!m) return nullptr;
+    switch (which) { case 0: return m->V; case 1: return m->magSf; case 2: return m->delta; case 3: return m->w; case 4: return m->bMagSf; case 5: return m->bDelta; }
+    return nullptr;
+}
+
 // internal accessors for the case driver
 const int *ffm_mesh_bcells(const ffm_mesh *m) { return m->bCells; }
 const double *ffm_mesh_geom(const ffm_mesh *m, int which)

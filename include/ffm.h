@@ -78,6 +78,16 @@ int ffm_memcpy_d2h(ffm_ctx *ctx, void *dst, const void *src_d, size_t bytes);
 int ffm_memcpy_d2d(ffm_ctx *ctx, void *dst_d, const void *src_d, size_t bytes);
 int ffm_memset(ffm_ctx *ctx, void *dst_d, int value, size_t bytes);
 
+/* element-wise field algebra (Field<scalar> operators of the Foam layer): one pass per operator, like
+ * OpenFOAM's own tmp-field evaluation, so an expression rounds the way the reference's does                        */
+enum { FFM_OP_ADD = 0, FFM_OP_SUB = 1, FFM_OP_MUL = 2, FFM_OP_DIV = 3, FFM_OP_MAX = 4, FFM_OP_MIN = 5 };
+enum { FFM_UN_NEG = 0, FFM_UN_SQR = 1, FFM_UN_MAG = 2, FFM_UN_SQRT = 3 };
+int ffm_field_binary(ffm_ctx *ctx, int op, long n, const double *a_d, const double *b_d, double *out_d);
+/* out = a op s, or s op a when scalarFirst != 0 */
+int ffm_field_scalar(ffm_ctx *ctx, int op, long n, const double *a_d, double s, int scalarFirst, double *out_d);
+int ffm_field_unary(ffm_ctx *ctx, int op, long n, const double *a_d, double *out_d);
+int ffm_field_fill(ffm_ctx *ctx, long n, double s, double *out_d);
+
 /* ----------------------------------------------------------- lduAddressing */
 /* Replaces lduAddressing + lduMatrix construction
  * [upstream src/OpenFOAM/matrices/lduMatrix/lduAddressing/lduAddressing.H].
@@ -205,6 +215,9 @@ int ffm_mesh_create(ffm_ldu *ldu, const double *V, const double *C,
 int ffm_mesh_set_face_centres(ffm_mesh *mesh, const double *Cf);
 int ffm_mesh_destroy(ffm_mesh *mesh);
 int ffm_mesh_nboundary(const ffm_mesh *mesh);
+/* device geometry fields for the Foam layer: 0 V[N], 1 magSf[nNative], 2 deltaCoeffs[nNative], 3 weights[nNative],
+ * 4 boundary magSf[B], 5 boundary deltaCoeffs[B]                                                           */
+const double *ffm_mesh_geometry_d(const ffm_mesh *mesh, int which);
 int ffm_mesh_nnative(const ffm_mesh *mesh);
 int ffm_faces_to_native(const ffm_mesh *mesh, const double *lduOrder, double *native_d);
 int ffm_faces_from_native(const ffm_mesh *mesh, const double *native_d, double *lduOrder);

@@ -88,3 +88,15 @@ def test_synthetic_matrix_decomposition_is_consistent(ffm):
             np.add.at(rs, itf["faceCells"], -bou)
         assert np.allclose(rs, rowsum[b.gcell], rtol=0, atol=1e-18)
         assert np.array_equal(sb["source"], s["source"][b.gcell])
+
+
+def test_foam_layer_demo_builds_and_loads():
+    """include/ffmFoam.H (B1 subset) compiles with the host compiler alone and the demo library exports its entry point."""
+    import ctypes, os
+    from ffm_import import ffm
+    so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so")
+    assert os.path.exists(so), "run firefoam-dev_amd/csrc/Makefile (or __graft_entry__.build())"
+    import torch  # noqa: F401  (same load order as everywhere else: torch's ROCm runtime first)
+    ffm.lib()
+    lib = ctypes.CDLL(so)
+    assert hasattr(lib, "b1_demo")

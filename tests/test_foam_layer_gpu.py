@@ -1,0 +1,111 @@
+"""B1 subset: solver statements in the reference's style (rhoEqn, one YiEqn with relax, UEqn with LUST and the
+reconstructed buoyancy/pressure source, rAU and HbyA of pEqn) written against include/ffmFoam.H -- examples/b1_demo.C,
+built as libffm_b1demo.so with the host compiler -- run on the device and are compared with the same equations evaluated by
+oracle/fv.py + the C solvers.  Bars: fields after a linear solve (tolerance 1e-10) within 1e-8 rel-L2 with identical
+iteration counts; quantities without a solve (rho from the diagonal solver, rAU) to rounding."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from common import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_b1_demo_matches_oracle(O, ffm, ctx):
+    from oracle import fv, plume
+    m = plume.make_mesh((9, 8, 7), h=0.1)
+    N, F = m.nCells, m.nFaces
+    B = sum(p.size for p in m.patches)
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    mesh.set_face_centres(m.Cf[fOrd].T.copy())
+    hu = lambda seed, n: O.hash_u(seed, np.arange(n))
+    pl = lambda seed, scale=1.0, shift=0.0: [shift + scale * hu(seed + q, p.size) for q, p in enumerate(m.patches)]
+    dt, alphaY, mu = 2e-3, 0.8, 1.8e-5
+    rho_old = 1.0 + 0.2 * hu(1, N); rho_now = rho_old * (1 + 0.01 * (hu(2, N) - 0.5))
+    phi = 0.02 * (hu(3, F) - 0.5); phib = pl(10, 0.02, -0.01)
+    Yi0 = 0.1 + 0.8 * hu(4, N); dEff = 2e-5 * (1 + hu(5, N)); R = 0.5 * (hu(6, N) - 0.5)
+    U0 = np.stack([hu(20 + d, N) - 0.5 for d in range(3)])
+    p_rgh = 10.0 * (hu(7, N) - 0.5); ghf = -9.81 * m.Cf[:, 1]; ghfb = [-9.81 * p.Cf[:, 1] for p in m.patches]
+    bcY = fv.MixedBC(m, f=pl(30), ref=pl(40, 0.5), refGrad=pl(50, 0.1, -0.05))
+    bcU = [fv.MixedBC(m, f=pl(60 + 10 * d), ref=pl(90 + 10 * d, 1.0, -0.5)) for d in range(3)]
+    p_b = pl(120, 10.0, -5.0)
+    rdt = 1.0 / dt
+    zb = [np.zeros(p.size) for p in m.patches]
+    ctl = dict(tolerance=1e-10, relTol=0.0)
+
+    # ------------------------------------------------------------------ the oracle's evaluation of the same statements
+    M = fv.fvm_ddt(m, rdt, np.ones(N), np.ones(N), rho_old); M.add_vol(fv.surface_integrate(m, phi, phib))
+    d, s = M.solve_system(0)
+    rho_new = s / d
+    Yb = bcY.values(m, Yi0)
+    w = fv.limited_weights(m, "limitedLinear01", phi, Yi0, fv.grad(m, Yi0, Yb), 1.0)
+    dEf, dEb = fv.interpolate(m, dEff, [dEff[p.faceCells] for p in m.patches])
+    M = fv.fvm_ddt(m, rdt, rho_new, rho_old, Yi0); M += fv.fvm_div(m, phi, phib, w, [bcY]); M -= fv.fvm_laplacian(m, dEf, dEb, [bcY])
+    M.add_su(R)
+    M.relax(alphaY, Yi0[None])
+    d, s = M.solve_system(0)
+    Yi_ref, pfY = O.Ldu(N, m.l, m.u).set_coeffs(d, M.upper, M.lower).solve(O.PBICGSTAB, O.DILU, Yi0, s, **ctl)
+    Yi_ref = np.maximum(Yi_ref, 0.0)
+    Ub = [bcU[c].values(m, U0[c]) for c in range(3)]
+    UEqn = fv.fvm_ddt(m, rdt, rho_new, rho_old, U0)
+    divU = fv.fvm_div(m, phi, phib, fv.lust_weights(m, phi), bcU)
+    divU.add_vol(np.stack([fv.surface_integrate(m, phi * fv.lust_correction(m, phi, fv.grad(m, U0[c], Ub[c])), zb) for c in range(3)]))
+    UEqn += divU
+    UEqn -= fv.fvm_laplacian(m, np.full(F, mu), [np.full(p.size, mu) for p in m.patches], bcU)
+    sgr, _ = fv.snGrad(m, rho_new, [rho_new[p.faceCells] for p in m.patches])
+    sgp, sgpb = fv.snGrad(m, p_rgh, p_b)
+    rec = fv.reconstruct(m, (-ghf * sgr - sgp) * m.magSf, [-sb * p.magSf for sb, p in zip(sgpb, m.patches)])
+    import copy
+    Msolve = copy.deepcopy(UEqn); Msolve.add_su(rec.T)
+    U_ref, itU = np.empty((3, N)), []
+    for c in range(3):
+        d, s = Msolve.solve_system(c)
+        U_ref[c], pf = O.Ldu(N, m.l, m.u).set_coeffs(d, UEqn.upper, UEqn.lower).solve(O.PBICGSTAB, O.DILU, U0[c], s, **ctl)
+        itU.append(pf["nIterations"])
+    K_ref = 0.5 * ((U_ref[0] ** 2 + U_ref[1] ** 2) + U_ref[2] ** 2)
+    rAU_ref = 1.0 / UEqn.A()
+    HbyA_ref = rAU_ref * UEqn.H(U_ref)
+
+    # ------------------------------------------------------------------ the C++ layer on the device
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    dp = C.POINTER(C.c_double)
+    h = lambda a: np.ascontiguousarray(a, np.float64)
+    cell = lambda a: h(np.asarray(a)[..., cOrd])
+    face = lambda a: h(np.asarray(a)[fOrd])
+    bnd = lambda lst: h(np.concatenate(lst))
+    keep = []
+    def P(a):
+        keep.append(a)
+        return a.ctypes.data_as(dp)
+    def PP(arrs):
+        arrs = [h(a) for a in arrs]; keep.append(arrs)
+        arr = (dp * len(arrs))(*[a.ctypes.data_as(dp) for a in arrs]); keep.append(arr)
+        return arr
+    out = dict(rho=np.empty(N), Yi=np.empty(N), U=np.empty((3, N)), K=np.empty(N), rAU=np.empty(N), HbyA=np.empty((3, N)))
+    nit = (C.c_int * 16)()
+    lib.b1_demo.restype = C.c_int
+    lib.b1_demo.argtypes = [C.c_void_p] * 3 + [C.c_double] * 2 + [dp] * 5 + [C.POINTER(dp)] + [dp] * 3 + [C.POINTER(dp)] + [C.c_double] + [dp] * 4 + [dp] * 6 + [C.POINTER(C.c_int)]
+    bcYp = PP([bnd(bcY.f), bnd(bcY.ref), bnd(bcY.refGrad)])
+    bcUp = PP([x for d in range(3) for x in (bnd(bcU[d].f), bnd(bcU[d].ref), bnd(bcU[d].refGrad))])
+    ctx._ready()
+    ns = lib.b1_demo(ctx.h, A.h, mesh.h, dt, alphaY, P(cell(rho_old)), P(cell(rho_now)), P(face(phi)), P(bnd(phib)),
+                     P(cell(Yi0)), bcYp, P(cell(dEff)), P(cell(R)), P(cell(U0)), bcUp, mu, P(face(ghf)), P(bnd(ghfb)),
+                     P(cell(p_rgh)), P(bnd(p_b)), P(out["rho"]), P(out["Yi"]), P(out["U"]), P(out["K"]), P(out["rAU"]), P(out["HbyA"]), nit)
+    assert ns == 5                                   # rho, Yi, Ux, Uy, Uz
+    back = lambda a: (lambda o: (o.__setitem__((Ellipsis, cOrd), a), o)[1])(np.empty_like(a))
+    assert np.array_equal(back(out["rho"]), rho_new)
+    assert list(nit[:5]) == [0, pfY["nIterations"]] + itU
+    assert rel_l2(back(out["Yi"]), Yi_ref) < 1e-8
+    for c in range(3):
+        assert rel_l2(back(out["U"])[c], U_ref[c]) < 1e-8
+        assert rel_l2(back(out["HbyA"])[c], HbyA_ref[c]) < 1e-7
+    assert rel_l2(back(out["K"]), K_ref) < 1e-8
+    assert rel_l2(back(out["rAU"]), rAU_ref) < 1e-14
+    mesh.close(); A.close()
