@@ -57,6 +57,18 @@ static MeshView mview(const ffm_mesh *m)
 static inline int sgrid(long n) { long g = (n + 255) / 256; return (int)std::max(1L, std::min(g, (long)RED_BLOCKS)); }
 #define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 #define LAUNCH(kern, n, ...) hipLaunchKernelGGL(kern, dim3(sgrid(n)), dim3(256), 0, m->ctx->stream, __VA_ARGS__)
+// Cell-row kernels walk the matrix' XCD-aware row schedule (chunks of 256 rows; entry i is served by a workgroup with
+// blockIdx % 8 == i % 8, see ffm_internal.hpp): the rows a row gathers from are then fetched into the same XCD's L2.
+#define CELL_SCHED(ci, q)                                                                              \
+    for (long it_ = blockIdx.x, ci = 0; it_ < (q).v.nSched; it_ += gridDim.x)                           \
+        if ((q).v.sched[it_] >= 0 && (ci = (long)(q).v.sched[it_] * 256 + threadIdx.x) < (q).v.N)
+static inline int cgrid(const ffm_mesh *m)
+{
+    int g = std::min(m->A->nSched, m->A->nOwned >= (32 << 20) ? 1024 : RED_BLOCKS);
+    g = (g + 7) & ~7;
+    return std::max(g, 8);
+}
+#define LAUNCH_CELLS(kern, ...) hipLaunchKernelGGL(kern, dim3(cgrid(m)), dim3(256), 0, m->ctx->stream, __VA_ARGS__)
 
 template <class T> static int up(ffm_ctx *c, T **d, const std::vector<T> &v)
 {
@@ -205,7 +217,7 @@ extern "C" int ffm_faces_from_native(const ffm_mesh *m, const double *native_d, 
 // fvc::interpolate with given weights (NULL: the mesh's linear weights)
 __global__ void k_interpolate(MeshView q, const double *__restrict__ wf, const double *__restrict__ vf, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci; const double P = vf[c];
         FOR_OWN_FACES(q, c, e, nb) { const double w = wf ? wf[e] : q.w[e]; out[e] = w * P + (1.0 - w) * vf[nb]; }
     }
@@ -213,7 +225,7 @@ __global__ void k_interpolate(MeshView q, const double *__restrict__ wf, const d
 // fvc::snGrad (uncorrected)
 __global__ void k_snGrad(MeshView q, const double *__restrict__ vf, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci; const double P = vf[c];
         FOR_OWN_FACES(q, c, e, nb) out[e] = q.delta[e] * (vf[nb] - P);
     }
@@ -222,7 +234,7 @@ __global__ void k_snGrad(MeshView q, const double *__restrict__ vf, double *__re
 __global__ void k_flux(MeshView q, const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
                        double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci; const double Px = vx[c], Py = vy[c], Pz = vz[c];
         FOR_OWN_FACES(q, c, e, nb) {
             const double w = q.w[e];
@@ -242,7 +254,7 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
                                   const double *__restrict__ gz, const double *__restrict__ Cx, const double *__restrict__ Cy,
                                   const double *__restrict__ Cz, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         const double P = vf ? vf[c] : 0.0;
         FOR_OWN_FACES(q, c, e, nb) {
@@ -281,7 +293,7 @@ __global__ void k_lust_correction(MeshView q, const double *__restrict__ phi, co
                                   const double *__restrict__ Cz, const double *__restrict__ Cfx, const double *__restrict__ Cfy,
                                   const double *__restrict__ Cfz, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         FOR_OWN_FACES(q, c, e, nb) {
             const int up = phi[e] > 0 ? c : nb;
@@ -299,7 +311,7 @@ __global__ void k_relax(MeshView q, double alpha, int nc, const double *__restri
                         double *__restrict__ diag, const double *__restrict__ p0, const double *__restrict__ p1,
                         const double *__restrict__ p2, double *__restrict__ s0, double *__restrict__ s1, double *__restrict__ s2)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         double sumOff = 0.0;
@@ -333,7 +345,7 @@ __global__ void k_relax(MeshView q, double alpha, int nc, const double *__restri
 template <int MODE, int W>
 __global__ void k_face_sum(MeshView q, const double *__restrict__ ssf, const double *__restrict__ ssb, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         double a[W], b[W];
@@ -358,7 +370,7 @@ template <int W>
 __global__ void k_grad(MeshView q, const double *__restrict__ vf, const double *__restrict__ vb, double *__restrict__ gx,
                        double *__restrict__ gy, double *__restrict__ gz)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         const double P = vf[c];
@@ -396,7 +408,7 @@ __global__ void k_reconstruct(MeshView q, long invStride, const double *__restri
                               const double *__restrict__ ssf, const double *__restrict__ ssb, double *__restrict__ ox,
                               double *__restrict__ oy, double *__restrict__ oz)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci; const long N = invStride;      // invT is [6][nCells] (owned + ghost)
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         double vx = 0, vy = 0, vz = 0;
@@ -430,7 +442,7 @@ __global__ void k_fvm_transport(MeshView q, double rDeltaT, const double *__rest
                                 const double *__restrict__ wf, const double *__restrict__ gamma, double lapSign,
                                 double *__restrict__ diag, double *__restrict__ upper, double *__restrict__ lower)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         double dDiv = 0.0, dLap = 0.0;
@@ -496,7 +508,7 @@ __global__ void k_add_boundary(MeshView q, const double *__restrict__ ic, const 
                                const double *__restrict__ diag, const double *__restrict__ src, const double *__restrict__ su,
                                double *__restrict__ diagOut, double *__restrict__ srcOut)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         double d = diag ? diag[c] : 0.0, s = src ? src[c] : 0.0;
         const int j = q.cellB[c];
@@ -511,7 +523,7 @@ __global__ void k_add_boundary(MeshView q, const double *__restrict__ ic, const 
 __global__ void k_matrix_A(MeshView q, int nc, const double *__restrict__ diag, const double *__restrict__ ic0,
                            const double *__restrict__ ic1, const double *__restrict__ ic2, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         double d = diag[c];
         const int j = q.cellB[c];
@@ -530,7 +542,7 @@ __global__ void k_matrix_H(MeshView q, int nc, const double *__restrict__ upper,
                            const double *__restrict__ ic1, const double *__restrict__ ic2, const double *__restrict__ bcC,
                            const double *__restrict__ psi, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci;
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         double al[W], au[W], xl[W], xu[W];
@@ -558,7 +570,7 @@ __global__ void k_matrix_H(MeshView q, int nc, const double *__restrict__ upper,
 __global__ void k_matrix_flux(MeshView q, const double *__restrict__ upper, const double *__restrict__ lower,
                               const double *__restrict__ psi, double *__restrict__ out)
 {
-    GRID_STRIDE(ci, q.v.N) {
+    CELL_SCHED(ci, q) {
         const int c = (int)ci; const double P = psi[c];
         FOR_OWN_FACES(q, c, e, nb) out[e] = upper[e] * psi[nb] - lower[e] * P;
     }
@@ -572,27 +584,27 @@ __global__ void k_matrix_flux_b(int B, const int *__restrict__ fc, const double 
 #define DONE() FFM_HIP(hipGetLastError()); return FFM_OK
 
 extern "C" int ffm_fvc_interpolate(ffm_mesh *m, const double *w_f, const double *vf, double *out_f)
-{ CHECK_M(m); LAUNCH(k_interpolate, m->N, mview(m), w_f, vf, out_f); DONE(); }
+{ CHECK_M(m); LAUNCH_CELLS(k_interpolate, mview(m), w_f, vf, out_f); DONE(); }
 extern "C" int ffm_fvc_snGrad(ffm_mesh *m, const double *vf, double *out_f)
-{ CHECK_M(m); LAUNCH(k_snGrad, m->N, mview(m), vf, out_f); DONE(); }
+{ CHECK_M(m); LAUNCH_CELLS(k_snGrad, mview(m), vf, out_f); DONE(); }
 extern "C" int ffm_fvc_snGrad_b(ffm_mesh *m, const double *vf, const double *vb, double *out_b)
 { CHECK_M(m); if (m->B) LAUNCH(k_snGrad_b, m->B, m->B, m->bCells, m->bDelta, vf, vb, out_b); DONE(); }
 extern "C" int ffm_fvc_flux(ffm_mesh *m, const double *vx, const double *vy, const double *vz, double *out_f)
-{ CHECK_M(m); LAUNCH(k_flux, m->N, mview(m), vx, vy, vz, out_f); DONE(); }
+{ CHECK_M(m); LAUNCH_CELLS(k_flux, mview(m), vx, vy, vz, out_f); DONE(); }
 extern "C" int ffm_fvc_surface_integrate(ffm_mesh *m, const double *ssf, const double *ssb, double *out)
-{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH((k_face_sum<0, W>), m->N, mview(m), ssf, ssb, out)); DONE(); }
+{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_face_sum<0, W>), mview(m), ssf, ssb, out)); DONE(); }
 extern "C" int ffm_fvc_surface_sum(ffm_mesh *m, const double *ssf, const double *ssb, double *out)
-{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH((k_face_sum<1, W>), m->N, mview(m), ssf, ssb, out)); DONE(); }
+{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_face_sum<1, W>), mview(m), ssf, ssb, out)); DONE(); }
 extern "C" int ffm_fvc_grad(ffm_mesh *m, const double *vf, const double *vb, double *gx, double *gy, double *gz)
-{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_grad<W>, m->N, mview(m), vf, vb, gx, gy, gz)); DONE(); }
+{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_grad<W>, mview(m), vf, vb, gx, gy, gz)); DONE(); }
 extern "C" int ffm_fvc_reconstruct(ffm_mesh *m, const double *ssf, const double *ssb, double *ox, double *oy, double *oz)
-{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_reconstruct<W>, m->N, mview(m), (long)m->N, m->invT, m->bMagSf, ssf, ssb, ox, oy, oz)); DONE(); }
+{ CHECK_M(m); FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_reconstruct<W>, mview(m), (long)m->N, m->invT, m->bMagSf, ssf, ssb, ox, oy, oz)); DONE(); }
 extern "C" int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double hi, const double *phi_f,
                                       const double *vf, const double *gx, const double *gy, const double *gz, double *out_w)
 {
     CHECK_M(m);
     if (scheme < 0 || scheme > 4 || !phi_f || !out_w || ((scheme == 2 || scheme == 3) && (!vf || !gx || !gy || !gz))) return FFM_ERR_ARG;
-    LAUNCH(k_limited_weights, m->N, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], out_w);
+    LAUNCH_CELLS(k_limited_weights, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], out_w);
     DONE();
 }
 extern "C" int ffm_mesh_set_face_centres(ffm_mesh *m, const double *Cf)
@@ -612,7 +624,7 @@ extern "C" int ffm_fv_lust_correction(ffm_mesh *m, const double *phi_f, const do
     CHECK_M(m);
     if (!phi_f || !gx || !gy || !gz || !out_f) return FFM_ERR_ARG;
     if (!m->Cf[0]) { ffm_set_error("ffm_fv_lust_correction: face centres not set (ffm_mesh_set_face_centres)"); return FFM_ERR_ARG; }
-    LAUNCH(k_lust_correction, m->N, mview(m), phi_f, gx, gy, gz, m->C[0], m->C[1], m->C[2], m->Cf[0], m->Cf[1], m->Cf[2], out_f);
+    LAUNCH_CELLS(k_lust_correction, mview(m), phi_f, gx, gy, gz, m->C[0], m->C[1], m->C[2], m->Cf[0], m->Cf[1], m->Cf[2], out_f);
     DONE();
 }
 extern "C" int ffm_fvm_relax(ffm_mesh *m, double alpha, int nc, const double *upper, const double *lower, const double *ic0,
@@ -623,7 +635,7 @@ extern "C" int ffm_fvm_relax(ffm_mesh *m, double alpha, int nc, const double *up
     if ((nc != 1 && nc != 3) || !upper || !lower || !diag || !psi0 || !src0 || (m->B && !ic0)) return FFM_ERR_ARG;
     if (nc == 3 && (!psi1 || !psi2 || !src1 || !src2 || (m->B && (!ic1 || !ic2)))) return FFM_ERR_ARG;
     if (alpha <= 0) return FFM_OK;                              // fvMatrix::relax: no-op
-    FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_relax<W>, m->N, mview(m), alpha, nc, upper, lower, ic0, ic1, ic2, diag, psi0, psi1, psi2, src0, src1, src2));
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_relax<W>, mview(m), alpha, nc, upper, lower, ic0, ic1, ic2, diag, psi0, psi1, psi2, src0, src1, src2));
     DONE();
 }
 extern "C" int ffm_fvm_transport(ffm_mesh *m, double rDeltaT, const double *rho, const double *phi_f, const double *w_f,
@@ -631,7 +643,7 @@ extern "C" int ffm_fvm_transport(ffm_mesh *m, double rDeltaT, const double *rho,
 {
     CHECK_M(m);
     if (!diag || !upper || !lower || (phi_f && !w_f)) return FFM_ERR_ARG;
-    FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_fvm_transport<W>, m->N, mview(m), rDeltaT, rho, phi_f, w_f, gamma_f, (double)laplacianSign, diag, upper, lower));
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_fvm_transport<W>, mview(m), rDeltaT, rho, phi_f, w_f, gamma_f, (double)laplacianSign, diag, upper, lower));
     DONE();
 }
 extern "C" int ffm_fvm_boundary_coeffs(ffm_mesh *m, const double *phib, const double *gammab, int laplacianSign, const double *f,
@@ -641,22 +653,22 @@ extern "C" int ffm_bc_values(ffm_mesh *m, const double *f, const double *ref, co
 { CHECK_M(m); if (m->B) LAUNCH(k_bc_values, m->B, m->B, m->bCells, m->bDelta, f, ref, refGrad, vf, out_b); DONE(); }
 extern "C" int ffm_fvm_add_boundary(ffm_mesh *m, const double *ic, const double *bc, const double *diag, const double *src,
                                     const double *su, double *diagOut, double *srcOut)
-{ CHECK_M(m); LAUNCH(k_add_boundary, m->N, mview(m), ic, bc, diag, src, su, diagOut, srcOut); DONE(); }
+{ CHECK_M(m); LAUNCH_CELLS(k_add_boundary, mview(m), ic, bc, diag, src, su, diagOut, srcOut); DONE(); }
 extern "C" int ffm_fvm_A(ffm_mesh *m, int nc, const double *diag, const double *ic0, const double *ic1, const double *ic2, double *out)
-{ CHECK_M(m); if (nc != 1 && nc != 3) return FFM_ERR_ARG; LAUNCH(k_matrix_A, m->N, mview(m), nc, diag, ic0, ic1, ic2, out); DONE(); }
+{ CHECK_M(m); if (nc != 1 && nc != 3) return FFM_ERR_ARG; LAUNCH_CELLS(k_matrix_A, mview(m), nc, diag, ic0, ic1, ic2, out); DONE(); }
 extern "C" int ffm_fvm_H(ffm_mesh *m, int nc, int cmpt, const double *upper, const double *lower, const double *src,
                          const double *ic0, const double *ic1, const double *ic2, const double *bcC, const double *psi, double *out)
 {
     CHECK_M(m); if ((nc != 1 && nc != 3) || cmpt < 0 || cmpt >= nc) return FFM_ERR_ARG;
     const double *icC = cmpt == 0 ? ic0 : cmpt == 1 ? ic1 : ic2;
-    FFM_DISPATCH_W(m->A->maxW, LAUNCH(k_matrix_H<W>, m->N, mview(m), nc, upper, lower, src, icC, ic0, ic1, ic2, bcC, psi, out));
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_matrix_H<W>, mview(m), nc, upper, lower, src, icC, ic0, ic1, ic2, bcC, psi, out));
     DONE();
 }
 extern "C" int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lower, const double *ic, const double *bc,
                             const double *psi, double *out_f, double *out_b)
 {
     CHECK_M(m);
-    LAUNCH(k_matrix_flux, m->N, mview(m), upper, lower, psi, out_f);
+    LAUNCH_CELLS(k_matrix_flux, mview(m), upper, lower, psi, out_f);
     if (m->B && out_b) LAUNCH(k_matrix_flux_b, m->B, m->B, m->bCells, ic, bc, psi, out_b);
     DONE();
 }
