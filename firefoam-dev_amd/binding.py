@@ -102,6 +102,7 @@ def lib():
         "ffm_ldu_n_native_faces": ([vp], C.c_int),
         "ffm_ldu_get_face_map": ([vp, ip], C.c_int),
         "ffm_ldu_set_coeffs_native_d": ([vp, dp, dp, dp], C.c_int),
+        "ffm_ldu_bind_coeffs_native_d": ([vp, dp, dp, dp, C.c_int], C.c_int),
         "ffm_ldu_set_interfaces": ([vp, C.c_int, ip, C.POINTER(ip), C.POINTER(hp), C.POINTER(hp), ip], C.c_int),
         "ffm_ldu_set_global_cells": ([vp, C.c_long], C.c_int),
         "ffm_spmv": ([vp, dp, dp], C.c_int),

@@ -133,6 +133,9 @@ struct ffm_ldu {
     double *rD = nullptr;          // reciprocal diagonal (DIC/DILU/diagonal)
     int rDKind = -1;               // which preconditioner rD currently holds
     unsigned long coeffEpoch = 0, rDEpoch = ~0ul;
+    unsigned long offDiagEpoch = 0;       // bumped when upper / lower change (coeffEpoch: any coefficient, diag included)
+    double *diagBuf = nullptr, *upperBuf = nullptr;     // the library's own coefficient storage; diag/upper/lower may instead
+                                                        // point at caller arrays (ffm_ldu_bind_coeffs_native_d)
 
     // work vectors (internal numbering), allocated on demand
     std::vector<double *> work;    // [nWork] each N doubles

@@ -142,7 +142,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
     const bool autoMode = a.mode == SWEEP_AUTO;
     if (a.mode == SWEEP_AUTO) {
         a.mode = 0;
-        if (renumber && nOwn > 0) {
+        if (renumber && nOwn > 0 && (long)N * 24 < (1L << 32)) {      // (the tiled kernels use 32-bit byte offsets into their streams)
             int bx, by, bz;
             if (groupHint) a.mode = 2;
             else if (const std::vector<int> *gc = memo_get(N, F, l, u)) {
@@ -532,7 +532,7 @@ extern "C" int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwn, int nGhost, int F, co
         size_t nb = sizeof(double) * (size_t)std::max(N, 1), fb = sizeof(double) * (size_t)std::max(A->upTotal, 1);
         if (hipMalloc((void **)&A->diag, nb) != hipSuccess || hipMalloc((void **)&A->upper, fb) != hipSuccess ||
             hipMalloc((void **)&A->rD, nb) != hipSuccess) { ffm_set_error("ffm_ldu_create: hipMalloc failed"); rc = FFM_ERR_HIP; break; }
-        A->lower = A->upper;
+        A->lower = A->upper; A->diagBuf = A->diag; A->upperBuf = A->upper;
         hipMemsetAsync(A->diag, 0, nb, ctx->stream); hipMemsetAsync(A->upper, 0, fb, ctx->stream);
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ffm_set_error("ffm_ldu_create: upload failed"); rc = FFM_ERR_HIP; break; }
     } while (0);
@@ -556,7 +556,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     hipFree(A->pipeProgress); hipFree(A->pipeTicket); hipFree(A->rowSched);
     ffm_tile_free(A);
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); if (A->ghSendBuf_h) hipHostFree(A->ghSendBuf_h); if (A->ghRecvBuf_h) hipHostFree(A->ghRecvBuf_h);
-    hipFree(A->diag); hipFree(A->upper); hipFree(A->lowerBuf); hipFree(A->rD);
+    hipFree(A->diagBuf); hipFree(A->upperBuf); hipFree(A->lowerBuf); hipFree(A->rD);
     hipFree(A->ifFaceCells); hipFree(A->ifBou); hipFree(A->ifInt); hipFree(A->haloSend); hipFree(A->haloRecv);
     hipFree(A->ifCell); hipFree(A->ifCellStart); hipFree(A->ifItem);
     delete A;
@@ -639,6 +639,7 @@ extern "C" int ffm_ldu_set_coeffs_d(ffm_ldu *A, const double *diag_d, const doub
     if (!A || !diag_d || (A->nFaces && !upper_d)) return FFM_ERR_ARG;
     hipStream_t s = A->ctx->stream;
     const size_t nb = sizeof(double) * A->nCells, fb = sizeof(double) * std::max(A->upTotal, 1);
+    A->diag = A->diagBuf; A->upper = A->upperBuf;
     if (lower_d && lower_d != upper_d) {
         if (!A->lowerBuf) FFM_HIP(hipMalloc((void **)&A->lowerBuf, fb));
         A->lower = A->lowerBuf; A->symmetric = false;
@@ -651,7 +652,7 @@ extern "C" int ffm_ldu_set_coeffs_d(ffm_ldu *A, const double *diag_d, const doub
             hipLaunchKernelGGL(k_gather_faces, dim3(stream_grid(A->upTotal)), dim3(256), 0, s, (long)A->upTotal, A->faceSrc, lower_d, A->lower);
     }
     FFM_HIP(hipGetLastError());
-    A->coeffEpoch++;
+    A->coeffEpoch++; A->offDiagEpoch++;
     return FFM_OK;
 }
 
@@ -679,6 +680,7 @@ extern "C" int ffm_ldu_set_coeffs_native_d(ffm_ldu *A, const double *diag_d, con
     if (!A->identity) { ffm_set_error("native coefficient layout needs the library's cell order (ffm_renumber_levels)"); return FFM_ERR_UNSUPPORTED; }
     hipStream_t s = A->ctx->stream;
     const size_t nb = sizeof(double) * A->nCells, fb = sizeof(double) * A->upTotal;
+    A->diag = A->diagBuf; A->upper = A->upperBuf;
     if (lower_d && lower_d != upper_d) {
         if (!A->lowerBuf) FFM_HIP(hipMalloc((void **)&A->lowerBuf, std::max(fb, sizeof(double))));
         A->lower = A->lowerBuf; A->symmetric = false;
@@ -686,7 +688,24 @@ extern "C" int ffm_ldu_set_coeffs_native_d(ffm_ldu *A, const double *diag_d, con
     } else { A->lower = A->upper; A->symmetric = true; }
     if (nb) FFM_HIP(hipMemcpyAsync(A->diag, diag_d, nb, hipMemcpyDeviceToDevice, s));
     if (fb) FFM_HIP(hipMemcpyAsync(A->upper, upper_d, fb, hipMemcpyDeviceToDevice, s));
+    A->coeffEpoch++; A->offDiagEpoch++;
+    return FFM_OK;
+}
+
+// Zero-copy form: the matrix uses the caller's device arrays (native layout) until the next set / bind call; the caller keeps
+// them alive and unchanged meanwhile.  offDiagUnchanged != 0: upper / lower hold the same values as at the previous call
+// (e.g. the components of a vector equation, which differ in the boundary diagonal only), so layouts derived from them are kept.
+extern "C" int ffm_ldu_bind_coeffs_native_d(ffm_ldu *A, const double *diag_d, const double *upper_d, const double *lower_d,
+                                            int offDiagUnchanged)
+{
+    if (!A || !diag_d || (A->upTotal && !upper_d)) return FFM_ERR_ARG;
+    if (!A->identity) { ffm_set_error("native coefficient layout needs the library's cell order (ffm_renumber_levels)"); return FFM_ERR_UNSUPPORTED; }
+    A->diag = const_cast<double *>(diag_d);
+    A->upper = const_cast<double *>(upper_d ? upper_d : A->upperBuf);
+    if (lower_d && lower_d != upper_d) { A->lower = const_cast<double *>(lower_d); A->symmetric = false; }
+    else { A->lower = A->upper; A->symmetric = true; }
     A->coeffEpoch++;
+    if (!offDiagUnchanged) A->offDiagEpoch++;
     return FFM_OK;
 }
 

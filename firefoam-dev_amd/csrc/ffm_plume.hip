@@ -17,6 +17,7 @@
 
 struct ffm_mesh;
 extern "C" {
+int ffm_ldu_bind_coeffs_native_d(ffm_ldu *, const double *, const double *, const double *, int);
 int ffm_mesh_create(ffm_ldu *, const double *, const double *, const double *, const double *, const double *, const double *, int,
                     const int *, const int *const *, const double *const *, const double *const *, ffm_mesh **);
 int ffm_mesh_destroy(ffm_mesh *);
@@ -134,9 +135,10 @@ static void bc_update_f(ffm_plume *P, double *f, const double *fStatic)
 { const double *pb = P->phib; forN(P, P->B, [=] __device__(long k) { f[k] = fStatic[k] < 0 ? 1.0 - (pb[k] >= 0 ? 1.0 : 0.0) : fStatic[k]; }); }
 
 static int solve_named(ffm_plume *P, const char *name, int solver, int pre, double tol, double relTol, const double *d,
-                       const double *up, const double *lo, double *psi, const double *src)
+                       const double *up, const double *lo, double *psi, const double *src, bool sameOffDiag = false)
 {
-    FFM_TRY(ffm_ldu_set_coeffs_native_d(P->A, d, up, lo));
+    // zero-copy: the driver's coefficient arrays stay untouched until the solve has returned
+    FFM_TRY(ffm_ldu_bind_coeffs_native_d(P->A, d, up, lo, sameOffDiag ? 1 : 0));
     SolveLog L; memset(&L, 0, sizeof(L)); strncpy(L.name, name, sizeof(L.name) - 1);
     if (P->tight) { tol = 1e-13; relTol = 0.0; }
     FFM_TRY(ffm_solve_d(P->A, solver, pre, tol, relTol, 0, 1000, 1, psi, src, &L.perf));
@@ -408,7 +410,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
     for (int c = 0; c < 3; c++) {
         FFM_TRY(ffm_fvm_add_boundary(m, P->Uic[c], P->Ubc[c], P->Udiag, P->Usrc[c], rec[c], P->dWork, P->sWork));
         const char *nm[3] = {"Ux", "Uy", "Uz"};
-        FFM_TRY(solve_named(P, nm[c], FFM_PBICGSTAB, FFM_DILU, 1e-6, 0.0, P->dWork, P->Uupper, P->Ulower, P->U[c], P->sWork));
+        FFM_TRY(solve_named(P, nm[c], FFM_PBICGSTAB, FFM_DILU, 1e-6, 0.0, P->dWork, P->Uupper, P->Ulower, P->U[c], P->sWork, c > 0));
         FFM_TRY(HX(P, P->U[c]));
     }
     {

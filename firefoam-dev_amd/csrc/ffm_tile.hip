@@ -521,10 +521,10 @@ static int tile_coef(ffm_ldu *A, TileDir &d, bool upper, const double **out)
     double *&buf = upper ? d.coefU : d.coefL;
     unsigned long &ep = upper ? d.epochU : d.epochL;
     if (!buf) { FFM_HIP(hipMalloc((void **)&buf, sizeof(double) * std::max<long>(n, 1))); ep = ~0ul; }
-    if (ep != A->coeffEpoch) {
+    if (ep != A->offDiagEpoch) {
         const int g = std::max(1, std::min(ffm_grid(n, 256), 8 * RED_BLOCKS));
         hipLaunchKernelGGL(k_tile_gather, dim3(g), dim3(256), 0, A->ctx->stream, n, d.src, upper ? A->upper : A->lower, buf);
-        ep = A->coeffEpoch;
+        ep = A->offDiagEpoch;
     }
     *out = buf;
     return FFM_OK;

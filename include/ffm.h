@@ -152,6 +152,11 @@ int ffm_ldu_n_native_faces(const ffm_ldu *ldu);
 int ffm_ldu_get_face_map(const ffm_ldu *ldu, int *callerToNative);
 int ffm_ldu_set_coeffs_native_d(ffm_ldu *ldu, const double *diag_d,
                                 const double *upper_d, const double *lower_d);
+/* zero-copy form of the same: the matrix reads the caller's device arrays until the next set/bind call (the caller keeps them
+ * alive and unchanged); offDiagUnchanged != 0 tells the library that upper/lower hold the same values as at the previous call
+ * (the components of a vector equation differ in the boundary diagonal only: fvMatrix::solveSegregated)               */
+int ffm_ldu_bind_coeffs_native_d(ffm_ldu *ldu, const double *diag_d, const double *upper_d,
+                                 const double *lower_d, int offDiagUnchanged);
 
 /* processor patches (lduInterface / interfaceBouCoeffs / interfaceIntCoeffs):
  * face i of patch p couples cell faceCells[p][i] (caller numbering) with face i
