@@ -2,6 +2,7 @@
 import ctypes
 
 import numpy as np
+import pytest
 
 
 def test_library_loads_and_exports_every_declared_symbol(ffm):
@@ -100,3 +101,44 @@ def test_foam_layer_demo_builds_and_loads():
     ffm.lib()
     lib = ctypes.CDLL(so)
     assert hasattr(lib, "b1_demo")
+
+
+def _levels(N, l, u):
+    lev = np.zeros(N, np.int64)
+    for a, b in zip(l, u):
+        lev[b] = max(lev[b], lev[a] + 1)
+    return lev
+
+
+@pytest.mark.parametrize("mode", ["auto", "levels"])
+def test_renumbering_is_a_topological_order_of_the_same_dag(mode):
+    """ffm_renumber_levels is pure host code: on a blockMesh box the default picks the tile-major order (2-D tiles of cell
+    columns, level-major inside a tile), FFM_SWEEP=levels the level-major order.  Both must be permutations that keep
+    owner < neighbour and upper-triangular face order, i.e. DIC / DILU / Gauss-Seidel stay the same operators."""
+    import os
+    from ffm_import import ffm
+    H = ffm.hexmesh
+    nx, ny, nz = 9, 37, 21
+    N, l, u = H.hex_ldu(nx, ny, nz)
+    os.environ["FFM_SWEEP"] = mode
+    try:
+        cOrd, fOrd = ffm.renumber_levels(N, l, u)
+    finally:
+        os.environ.pop("FFM_SWEEP", None)
+    assert sorted(cOrd) == list(range(N)) and sorted(fOrd) == list(range(len(l)))
+    l2, u2, oldToNew = H.apply_renumbering(N, l, u, cOrd, fOrd)
+    assert (l2 < u2).all()
+    assert (np.diff(l2) >= 0).all()                                   # faces sorted by owner ...
+    same = np.diff(l2) == 0
+    assert (np.diff(u2)[same] > 0).all()                              # ... then by neighbour
+    lev = _levels(N, l2, u2)
+    if mode == "levels":
+        assert (np.diff(lev) >= 0).all()                              # level-major
+    else:
+        c = np.asarray(cOrd)
+        tile = ((c // nx) % ny) // 16 + 1000 * ((c // (nx * ny)) // 16)
+        change = np.nonzero(np.diff(tile))[0]
+        assert len(change) + 1 == len(set(tile)) == 3 * 2             # every tile is one contiguous range of the new order
+        starts = np.concatenate(([0], change + 1, [N]))
+        for a, b in zip(starts[:-1], starts[1:]):
+            assert (np.diff(lev[a:b]) >= 0).all()                     # level-major inside a tile
