@@ -139,6 +139,7 @@ struct ffm_ldu {
 
     // work vectors (internal numbering), allocated on demand
     std::vector<double *> work;    // [nWork] each N doubles
+    double *gsProd = nullptr;      // [3N] scratch of the tiled Gauss-Seidel sweep
     double *permIn[3] = {nullptr, nullptr, nullptr};  // staging for caller-order vectors
 
     // interfaces (processor patches), packed patch after patch
@@ -198,6 +199,8 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
 int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<int> &bl, const std::vector<int> &grpCell);
 bool ffm_tile_feasible(int nOwn, int F, const int *l, const int *u);
 int ffm_tile_calc_rD(ffm_ldu *A);
+bool ffm_tile_gs_usable(const ffm_ldu *A);
+int ffm_tile_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSave, double *prod3);
 bool ffm_tile_amul_usable(const ffm_ldu *A);
 int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot);     // returns 1 if the dot product is left to the caller
 void ffm_tile_free(ffm_ldu *A);

@@ -548,6 +548,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     hipStreamSynchronize(A->ctx->stream);
     for (auto &kv : A->graphs) hipGraphExecDestroy(kv.second);
     for (double *w : A->work) hipFree(w);
+    hipFree(A->gsProd);
     for (int i = 0; i < 3; i++) hipFree(A->permIn[i]);
     hipFree(A->upOff); hipFree(A->loOff); hipFree(A->upNbr); hipFree(A->loEnt); hipFree(A->faceSrc);
     hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative);

@@ -466,6 +466,11 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             FFM_TRY(ffm_halo_update(A, psi, bP, A->ifBou, +1.0));
             bUse = bP;
         }
+        if (A->sweepMode == 2 && ffm_tile_gs_usable(A)) {
+            if (!A->gsProd) FFM_HIP(hipMalloc((void **)&A->gsProd, sizeof(double) * 3 * (size_t)std::max(A->nCells, 1)));
+            FFM_TRY(ffm_tile_gs(A, sym, psi, bUse, bSave, A->gsProd));
+            continue;
+        }
         if (A->sweepMode >= 1) { FFM_TRY(ffm_pipe_gs(A, sym, psi, bUse, bSave)); continue; }
         SweepGraphKey key{sym ? SW_SYMGS : SW_GS, psi, bUse, A->lower};
         FFM_TRY(run_graphed(A, key, [&]() -> int {

@@ -50,6 +50,7 @@ struct TileDir {            // one sweep direction (device arrays)
     unsigned short *code = nullptr;   // [4*nOwn] per cell: 3 neighbour codes = the LDS slot holding the neighbour's value when the cell is computed
                                       // (ring slot (nb - group start) mod T_RING, or T_RING + parity(entry)*T_XMAX + external index; T_NONE: no neighbour), publish slot | T_NONE
     int *src = nullptr;         // [3*nOwn] native coefficient index of each neighbour slot (-1: none)
+    int *nbrCell = nullptr;     // [3*nOwn] the neighbour cell of each slot (-1: none)
     double *coefU = nullptr, *coefL = nullptr;        // [3*nOwn] gathered upper / lower coefficients (lazily allocated)
     unsigned long epochU = ~0ul, epochL = ~0ul;
     double *mail = nullptr;     // [nPub + 1] (inside ffm_tile_plan::mailAll)
@@ -76,7 +77,7 @@ struct ffm_tile_plan {
 
 static void free_dir(TileDir &d)
 {
-    hipFree(d.grpEnt); hipFree(d.rec); hipFree(d.extSrc); hipFree(d.code); hipFree(d.src); hipFree(d.coefU); hipFree(d.coefL);
+    hipFree(d.grpEnt); hipFree(d.rec); hipFree(d.extSrc); hipFree(d.code); hipFree(d.src); hipFree(d.nbrCell); hipFree(d.coefU); hipFree(d.coefL);
     d = TileDir();
 }
 void ffm_tile_free(ffm_ldu *A)
@@ -194,6 +195,7 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
     for (int k = 0; k < 2 * T_PF + 2; k++) rec.push_back(make_int4(0, 0, 0, 0));      // read-ahead padding
     for (int k = 0; k < T_THREADS; k++) extSrc.push_back(0);
     FFM_TRY(upv(&D.grpEnt, grpEnt)); FFM_TRY(upv(&D.rec, rec)); FFM_TRY(upv(&D.extSrc, extSrc)); FFM_TRY(upv(&D.code, code)); FFM_TRY(upv(&D.src, src));
+    if (!fwd) FFM_TRY(upv(&D.nbrCell, nbr));
     return FFM_OK;
 }
 
@@ -333,7 +335,7 @@ __device__ __forceinline__ void t_st(double *p, double v) { __hip_atomic_store(p
 __device__ __forceinline__ void t_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ bool t_pending(double v) { return (unsigned long long)__double_as_longlong(v) == T_SENT; }
 
-enum { TM_FWD = 0, TM_BWD = 1, TM_RD = 2 };
+enum { TM_FWD = 0, TM_BWD = 1, TM_RD = 2, TM_GSF = 3, TM_GSB = 4 };
 struct __attribute__((aligned(8))) T3 { double a, b, c; };       // the three coefficients of a cell
 static_assert(T_W == 3, "T3");
 
@@ -359,6 +361,10 @@ __device__ __noinline__ double t_wait_value(const double *addr, unsigned int *ti
 // TM_FWD: w[c] = rD[c]*r[c] - sum_k rD[c]*a[c][k]*w[l_k]           (k ascending: the reference's face order)
 // TM_BWD: w[c] -= sum_k rD[c]*a[c][k]*w[u_k]                       (k descending)
 // TM_RD : D[c] = diag[c] - sum_k a[c][k]*b[c][k]/D[l_k]            (k ascending; the caller inverts D afterwards)
+// TM_GSF: Gauss-Seidel forward row sweep: v = bPrime[c] - sum_k lower[c][k]*psi[l_k] (new values); aux[c] = v (kept for the
+//         reverse sweep of symGaussSeidel); v -= b[c][k] for k = 0..2 (b = upper*psi_old of the upper neighbours, computed
+//         by k_tile_gs_products; +0.0 where there is none); psi[c] = v/diag[c]
+// TM_GSB: reverse row sweep: v = aux[c] - sum_k upper[c][k]*psi[u_k] (new values, k ascending); psi[c] = v/diag[c]
 // The per-level path is issue-bound (one wave per SIMD runs the whole entry), so
 //   * waves 0-3 ("compute") are kept free of divergent branches: idle lanes work on a dummy cell, only stores are predicated;
 //   * wave 4 ("mail") does nothing but bring the external values of the next entry into LDS: entry record -> mailbox slot
@@ -367,10 +373,12 @@ __device__ __noinline__ double t_wait_value(const double *addr, unsigned int *ti
 // Every wave executes the same number of workgroup barriers: one after the prologue, one per entry of the padded loop.
 template <int MODE, bool TRACE>
 __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const double *__restrict__ ca, const double *__restrict__ cb,
-                                                         const double *__restrict__ dg, const double *__restrict__ r, double *w)
+                                                         const double *__restrict__ dg, const double *__restrict__ r, double *w, double *aux)
 {
-    constexpr bool ASC = MODE != TM_BWD;
+    constexpr bool ASC = MODE != TM_BWD && MODE != TM_GSB;
+    constexpr bool TWO = MODE == TM_RD || MODE == TM_GSF;       // a second triple of per-cell doubles (cb)
     constexpr int W = T_W;
+    constexpr int T_PF = TWO ? 6 : ::T_PF;                      // (register budget) read-ahead of this mode
     __shared__ double ring[T_LDS];                    // ring of this group's values, the two halo buffers, the dummy slot
     double *const halo = ring + T_RING;
     __shared__ int4 shRec[4];           // entry records handed from the mail wave to the compute waves
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
     unsigned pc[T_PF], ppb[T_PF];
     bool pok[T_PF];
     uint2 pq[T_PF];
-    double pa[T_PF][W], pb[T_PF][MODE == TM_RD ? W : 1], pd[T_PF], pv[T_PF];
+    double pa[T_PF][W], pb[T_PF][TWO ? W : 1], pd[T_PF], pv[T_PF];
 #define T_FETCH(k, e, R_) {                                                                             \
         const unsigned cnt_ = ((e) < e1) ? ((unsigned)R_.y & 0xFFFFu) : 0u;                              \
         const bool ok_ = tid < cnt_;                                                                     \
@@ -446,9 +454,9 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
         const unsigned o8_ = cc_ * 8u, o24_ = cc_ * 24u;        /* 32-bit byte offsets: arrays < 4 GiB (host check) */  \
         pq[k] = *(const uint2 *)((const char *)t.code + o8_);                                            \
         { const T3 v_ = *(const T3 *)((const char *)ca + o24_); pa[k][0] = v_.a; pa[k][1] = v_.b; pa[k][2] = v_.c; }     \
-        if (MODE == TM_RD) { const T3 v_ = *(const T3 *)((const char *)cb + o24_); pb[k][0] = v_.a; pb[k][MODE == TM_RD ? 1 : 0] = v_.b; pb[k][MODE == TM_RD ? 2 : 0] = v_.c; } \
+        if (TWO) { const T3 v_ = *(const T3 *)((const char *)cb + o24_); pb[k][0] = v_.a; pb[k][TWO ? 1 : 0] = v_.b; pb[k][TWO ? 2 : 0] = v_.c; } \
         pd[k] = *(const double *)((const char *)dg + o8_);                                               \
-        pv[k] = MODE == TM_FWD ? *(const double *)((const char *)r + o8_) : (MODE == TM_BWD ? *(const double *)((const char *)w + o8_) : 0.0); \
+        pv[k] = (MODE == TM_FWD || MODE == TM_GSF || MODE == TM_GSB) ? *(const double *)((const char *)r + o8_) : (MODE == TM_BWD ? *(const double *)((const char *)w + o8_) : 0.0); \
         pc[k] = cc_; pok[k] = ok_; ppb[k] = (unsigned)R_.z;                                              \
     }
 #pragma unroll
@@ -477,10 +485,23 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
                     val = pv[k];
 #pragma unroll
                     for (int s = W - 1; s >= 0; s--) { const double nv = val - d * pa[k][s] * x[s]; val = (cd[s] != T_NONE) ? nv : val; }
-                } else {
+                } else if (MODE == TM_RD) {
                     val = d;
 #pragma unroll
-                    for (int s = 0; s < W; s++) { const double nv = val - pa[k][s] * pb[k][MODE == TM_RD ? s : 0] / x[s]; val = (cd[s] != T_NONE) ? nv : val; }
+                    for (int s = 0; s < W; s++) { const double nv = val - pa[k][s] * pb[k][TWO ? s : 0] / x[s]; val = (cd[s] != T_NONE) ? nv : val; }
+                } else if (MODE == TM_GSF) {
+                    val = pv[k];
+#pragma unroll
+                    for (int s = 0; s < W; s++) { const double nv = val - pa[k][s] * x[s]; val = (cd[s] != T_NONE) ? nv : val; }
+                    if (pok[k]) *(double *)((char *)aux + c * 8u) = val;
+#pragma unroll
+                    for (int s = 0; s < W; s++) val -= pb[k][TWO ? s : 0];
+                    val = val / d;
+                } else {
+                    val = pv[k];
+#pragma unroll
+                    for (int s = 0; s < W; s++) { const double nv = val - pa[k][s] * x[s]; val = (cd[s] != T_NONE) ? nv : val; }
+                    val = val / d;
                 }
                 if (pok[k]) { *(double *)((char *)w + c * 8u) = val; ring[(c - gs) & (unsigned)(T_RING - 1)] = val; }
                 if (pok[k] && cd[3] != T_NONE) t_st(&t.mail[ppb[k] + cd[3]], val);
@@ -548,12 +569,46 @@ int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, d
     FFM_TRY(tile_coef(A, T->b, bwdUpper, &cb));
     tile_fill(A, T->mailAll, T->nMail);
     if (T->trace) {
-        hipLaunchKernelGGL((k_tile<TM_FWD, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr, (const double *)A->rD, r, w);
-        hipLaunchKernelGGL((k_tile<TM_BWD, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr, (const double *)A->rD, r, w);
+        hipLaunchKernelGGL((k_tile<TM_FWD, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr, (const double *)A->rD, r, w, (double *)nullptr);
+        hipLaunchKernelGGL((k_tile<TM_BWD, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr, (const double *)A->rD, r, w, (double *)nullptr);
     } else {
-        hipLaunchKernelGGL((k_tile<TM_FWD, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr, (const double *)A->rD, r, w);
-        hipLaunchKernelGGL((k_tile<TM_BWD, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr, (const double *)A->rD, r, w);
+        hipLaunchKernelGGL((k_tile<TM_FWD, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr, (const double *)A->rD, r, w, (double *)nullptr);
+        hipLaunchKernelGGL((k_tile<TM_BWD, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr, (const double *)A->rD, r, w, (double *)nullptr);
     }
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+
+// upper*psi_old of the (owned) upper neighbours of every cell, slot by slot; +0.0 where a cell has fewer than three
+__global__ void k_tile_gs_products(long n3, const int *__restrict__ nbrCell, const double *__restrict__ coef, const double *__restrict__ psi,
+                                   double *__restrict__ out)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n3; i += (long)gridDim.x * blockDim.x) {
+        const int nb = nbrCell[i];
+        out[i] = (nb >= 0) ? coef[i] * psi[nb] : 0.0;
+    }
+}
+
+bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->nCells == A->nOwned; }
+
+// One GaussSeidelSmoother / symGaussSeidelSmoother sweep (forward rows, then reverse rows when sym): psi in place, bP = bPrime
+// (source with the lagged interface terms), bSave = scratch [nCells].  prod = scratch [3*nCells].
+int ffm_tile_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSave, double *prod)
+{
+    ffm_tile_plan *T = A->tile;
+    hipStream_t s = A->ctx->stream;
+    const double *cl, *cu;
+    FFM_TRY(tile_coef(A, T->f, A->lower == A->upper, &cl));        // lower coefficients, lower-neighbour layout
+    FFM_TRY(tile_coef(A, T->b, true, &cu));                         // upper coefficients, upper-neighbour layout
+    const long n3 = (long)T_W * A->nOwned;
+    hipLaunchKernelGGL(k_tile_gs_products, dim3(std::max(1, std::min(ffm_grid(n3, 256), 8 * RED_BLOCKS))), dim3(256), 0, s, n3,
+                       (const int *)T->b.nbrCell, cu, (const double *)psi, prod);
+    tile_fill(A, T->mailAll, T->nMail);
+    hipLaunchKernelGGL((k_tile<TM_GSF, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cl, (const double *)prod, (const double *)A->diag, bP, psi, bSave);
+    if (sym)
+        hipLaunchKernelGGL((k_tile<TM_GSB, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cu, (const double *)nullptr, (const double *)A->diag,
+                           (const double *)bSave, psi, (double *)nullptr);
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
@@ -567,7 +622,7 @@ int ffm_tile_calc_rD(ffm_ldu *A)
     if (A->lower == A->upper) cl = cu; else FFM_TRY(tile_coef(A, T->f, false, &cl));
     tile_fill(A, T->f.mail, (long)T->f.nPub + 1);
     hipLaunchKernelGGL((k_tile<TM_RD, false>), dim3(T->G), dim3(T_THREADS + 64), 0, A->ctx->stream, tview(A, T->f), cu, cl, (const double *)A->diag,
-                       (const double *)nullptr, A->rD);
+                       (const double *)nullptr, A->rD, (double *)nullptr);
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
