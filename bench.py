@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--edge", dest="n", type=int, default=400, help="cells per box edge (400 -> 64 M cells, BASELINE.json config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=96)
+    ap.add_argument("--solvers", choices=["krylov", "steckler"], default="krylov",
+                    help="transport equations: PBiCGStab+DILU (default) or smoothSolver+symGaussSeidel maxIter 10 (cases/steckler/system/fvSolution:49-62)")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="rccl: one rank per GPU over xGMI (production); host: ranks share GPUs, halo through gloo (rehearsal)")
     args = ap.parse_args()
@@ -72,6 +74,8 @@ def main():
         grid = ffm.hexmesh.grid_for(world)
         lo, hi, nbr = ffm.hexmesh.block_of_rank((n, n, n), grid, rank)
         case = ffm.Plume(ctx, (n, n, n), h=0.05, deltaT=1e-3, lo=lo, hi=hi, nbrRank=nbr)
+    if args.solvers == "steckler":
+        case.set_solvers(steckler=True)
     setup_s = time.time() - t0
     N, F = n ** 3, 3 * n * n * (n - 1)          # global cells / faces
     Nloc, Floc = case.nCells, case.nFaces
@@ -149,7 +153,8 @@ def main():
             "config": {"workload": "synthetic %d^3 hex box (%d cells), buoyant plume + 5-species EDC-shaped source, "
                                    "PIMPLE 1/2/0: rhoEqn + UEqn + YEEqn(4 Yi + h) + 2 pEqn per step" % (n, N),
                        "cells": N, "faces": F, "deltaT": 1e-3, "parallelism": "1 GPU" if world == 1 else "%dx%dx%d block decomposition, one block per GPU, RCCL halo + all-reduce" % grid,
-                       "p_rgh_iterations_last_step": pIters, "setup_s": round(setup_s, 1)},
+                       "p_rgh_iterations_last_step": pIters, "setup_s": round(setup_s, 1),
+                       "transport_solvers": "PBiCGStab+DILU" if args.solvers == "krylov" else "smoothSolver+symGaussSeidel maxIter 10"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

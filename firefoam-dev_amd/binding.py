@@ -152,6 +152,7 @@ def lib():
         "ffm_plume_destroy": ([vp], C.c_int),
         "ffm_plume_step": ([vp], C.c_int),
         "ffm_plume_set_tight": ([vp, C.c_int], C.c_int),
+        "ffm_plume_set_solvers": ([vp, C.c_int], C.c_int),
         "ffm_plume_ncells": ([vp], C.c_int),
         "ffm_plume_nfaces": ([vp], C.c_int),
         "ffm_plume_get_field": ([vp, C.c_char_p, hp], C.c_int),
@@ -470,6 +471,10 @@ class Plume:
         if getattr(self, "h", None):
             lib().ffm_plume_destroy(self.h)
             self.h = None
+
+    def set_solvers(self, steckler=True):
+        """transport equations with smoothSolver + symGaussSeidel (maxIter 10) as cases/steckler/system/fvSolution:49-62"""
+        _check(lib().ffm_plume_set_solvers(self.h, 1 if steckler else 0), "ffm_plume_set_solvers")
 
     def set_tight(self, on=True):
         _check(lib().ffm_plume_set_tight(self.h, 1 if on else 0), "ffm_plume_set_tight")

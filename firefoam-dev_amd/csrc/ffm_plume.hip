@@ -84,6 +84,8 @@ struct ffm_plume {
     double *Udiag, *Uupper, *Ulower, *Usrc[3], *Uic[3], *Ubc[3];
     std::vector<SolveLog> log;
     bool tight = false;                    // tests: every solve to 1e-13 / relTol 0 (removes the stopping-rule noise)
+    bool stecklerSolvers = false;          // transport equations with smoothSolver + symGaussSeidel, maxIter 10
+                                           // (cases/steckler/system/fvSolution:49-62) instead of PBiCGStab + DILU
 };
 
 #define PL_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ffm_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e_)); return FFM_ERR_HIP; } } while (0)
@@ -141,7 +143,9 @@ static int solve_named(ffm_plume *P, const char *name, int solver, int pre, doub
     FFM_TRY(ffm_ldu_bind_coeffs_native_d(P->A, d, up, lo, sameOffDiag ? 1 : 0));
     SolveLog L; memset(&L, 0, sizeof(L)); strncpy(L.name, name, sizeof(L.name) - 1);
     if (P->tight) { tol = 1e-13; relTol = 0.0; }
-    FFM_TRY(ffm_solve_d(P->A, solver, pre, tol, relTol, 0, 1000, 1, psi, src, &L.perf));
+    int maxIter = 1000;
+    if (P->stecklerSolvers && solver == FFM_PBICGSTAB) { solver = FFM_SMOOTH; pre = FFM_SYMGS; maxIter = P->tight ? 1000 : 10; }
+    FFM_TRY(ffm_solve_d(P->A, solver, pre, tol, relTol, 0, maxIter, 1, psi, src, &L.perf));
     P->log.push_back(L);
     return FFM_OK;
 }
@@ -673,6 +677,7 @@ extern "C" int ffm_plume_destroy(ffm_plume *P)
 }
 
 extern "C" int ffm_plume_set_tight(ffm_plume *P, int on) { if (!P) return FFM_ERR_ARG; P->tight = on != 0; return FFM_OK; }
+extern "C" int ffm_plume_set_solvers(ffm_plume *P, int stecklerSelection) { if (!P) return FFM_ERR_ARG; P->stecklerSolvers = stecklerSelection != 0; return FFM_OK; }
 extern "C" int ffm_plume_ncells(const ffm_plume *P) { return P ? P->nOwn : FFM_ERR_ARG; }
 extern "C" int ffm_plume_nfaces(const ffm_plume *P) { return P ? P->F : FFM_ERR_ARG; }
 

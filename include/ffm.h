@@ -299,6 +299,9 @@ int ffm_plume_destroy(ffm_plume *p);
 int ffm_plume_step(ffm_plume *p);
 /* tests: run every linear solve to 1e-13 with relTol 0 instead of the fvSolution controls */
 int ffm_plume_set_tight(ffm_plume *p, int on);
+/* linear solvers of the transport equations (U, Yi, h): 0 = PBiCGStab + DILU (default, the kernels BASELINE names),
+ * 1 = smoothSolver + symGaussSeidel with maxIter 10, the selection of cases/steckler/system/fvSolution:49-62 */
+int ffm_plume_set_solvers(ffm_plume *plume, int stecklerSelection);
 int ffm_plume_ncells(const ffm_plume *p);
 int ffm_plume_nfaces(const ffm_plume *p);
 int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);

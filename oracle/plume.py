@@ -75,9 +75,18 @@ class Solvers:
     def solve(self, kind, name, mesh, diag, upper, lower, source, psi0):
         c = self.CONTROLS[kind]
         A = O.Ldu(mesh.nCells, mesh.l, mesh.u).set_coeffs(diag, upper, None if c["solver"] == "PCG" else lower)
-        psi, perf = A.solve(getattr(O, c["solver"]), getattr(O, c["pre"]), psi0, source, tolerance=c["tolerance"], relTol=c["relTol"])
+        psi, perf = A.solve(getattr(O, c["solver"]), getattr(O, c["pre"]), psi0, source, tolerance=c["tolerance"], relTol=c["relTol"],
+                            maxIter=c.get("maxIter", 1000))
         self.log.append((name, perf))
         return psi
+
+
+class StecklerSolvers(Solvers):
+    """the transport-equation selection of cases/steckler/system/fvSolution:49-62: smoothSolver + symGaussSeidel, maxIter 10"""
+    CONTROLS = dict(Solvers.CONTROLS,
+                    U=dict(solver="SMOOTH", pre="SYMGS", tolerance=1e-6, relTol=0.0, maxIter=10),
+                    Yi=dict(solver="SMOOTH", pre="SYMGS", tolerance=1e-8, relTol=0.0, maxIter=10),
+                    h=dict(solver="SMOOTH", pre="SYMGS", tolerance=1e-8, relTol=0.0, maxIter=10))
 
 
 class Plume:

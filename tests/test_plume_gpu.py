@@ -39,3 +39,26 @@ def test_plume_steps_match_oracle(O, ffm, ctx, n):
         a, b = gpu.field("p_rgh"), f["p_rgh"]
         assert np.linalg.norm(a - b) / max(np.linalg.norm(b - b.mean()), 1e-30) < 1e-5
     gpu.close()
+
+
+def test_plume_with_the_steckler_solver_selection(O, ffm, ctx):
+    """The same time steps with the linear solvers cases/steckler/system/fvSolution:49-62 selects for U, Yi and h:
+    smoothSolver + symGaussSeidel, maxIter 10 (the sweeps run in the tiled Gauss-Seidel kernels)."""
+    from oracle import plume
+    n = (12, 16, 12)
+    ref = plume.Plume(n, solvers=plume.StecklerSolvers())
+    gpu = ffm.Plume(ctx, n)
+    gpu.set_solvers(steckler=True)
+    for step in range(2):
+        ref.step(); gpu.step()
+        it_ref = [(nme, pf["nIterations"]) for nme, pf in ref.sol.log]
+        it_gpu = [(nme, pf["nIterations"]) for nme, pf in gpu.solves()]
+        assert it_ref == it_gpu, (step, it_ref, it_gpu)
+        f = ref.fields()
+        for name in FIELDS:
+            a, b = gpu.field(name), f[name]
+            if np.linalg.norm(b) < 1e-30:
+                assert np.abs(a).max() < 1e-12, name
+            else:
+                assert rel_l2(a, b) < 1e-8, (step, name, rel_l2(a, b))
+    gpu.close()
