@@ -1,6 +1,6 @@
 /*---------------------------------------------------------------------------*\
-  b1_demo.C -- solver statements in the style of the reference's solver/rhoEqn.H, YEEqn.H (one specie), UEqn.H and the
-  head of pEqn.H, written against include/ffmFoam.H (B1 of SURVEY 8b) and running on the device through the C ABI.
+  b1_demo.C -- solver statements in the style of the reference's solver/rhoEqn.H, YEEqn.H (one specie), UEqn.H and one
+  corrector of pEqn.H, written against include/ffmFoam.H (B1 of SURVEY 8b) and running on the device through the C ABI.
   It is NOT the reference's text: the physics handles of the reference (turbulence, combustion, parcels, fvOptions,
   MRF, thermo) are replaced by plain fields handed in by the caller (dEff, mu, the specie source R).
 
@@ -32,13 +32,17 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
                        const double* Yi0, const double* const* bcY, const double* dEffC, const double* RYi,
                        const double* U0, const double* const* bcU, double muValue,
                        const double* ghfF, const double* ghfB, const double* p_rgh0, const double* p_rghB,
-                       double* rhoOut, double* YiOut, double* UOut, double* KOut, double* rAUOut, double* HbyAOut, int* nIterOut)
+                       const double* psiNow, const double* psiOld, const double* ghC, double pRefValue, const double* const* bcP,
+                       const double* fluxMaskB, const double* UfixedB,
+                       double* rhoOut, double* YiOut, double* UOut, double* KOut, double* rAUOut, double* HbyAOut,
+                       double* p_rghOut, double* phiOutF, double* phiOutB, double* UcorrOut, int* nIterOut)
 {
     fvMesh mesh(ctx, ldu, msh, deltaT);
     // fvSolution / fvSchemes of the demo (cf. cases/steckler/system/fvSolution:19-83, fvSchemes:28-61)
     mesh.solvers["rho"] = {FFM_DIAGONAL, FFM_NONE, 1e-6, 0, 0, 1000, 1};
     mesh.solvers["Yi"] = {FFM_PBICGSTAB, FFM_DILU, 1e-10, 0, 0, 1000, 1};
     mesh.solvers["U"] = {FFM_PBICGSTAB, FFM_DILU, 1e-10, 0, 0, 1000, 1};
+    mesh.solvers["p_rgh"] = {FFM_PCG, FFM_DIC, 1e-10, 0, 0, 1000, 1};
     mesh.divSchemes["div(phi,U)"] = {4, 1, 0, 1};               // Gauss LUST grad(U)
     mesh.divSchemes["div(phi,Yi_h)"] = {3, 1, 0, 1};            // Gauss limitedLinear01 1 (multivariateSelection entry)
     mesh.equationRelaxation["Yi"] = alphaY;
@@ -115,11 +119,55 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
     for (int d = 0; d < 3; d++) U.v[d].toHost(UOut + (size_t)d*N);
     K.v.toHost(KOut);
 
-    // ---- head of pEqn.H
-    volScalarField rAU("rAU", 1.0/UEqn.A());
-    volVectorField HbyA(rAU*UEqn.H());
-    rAU.v.toHost(rAUOut);
-    for (int d = 0; d < 3; d++) HbyA.v[d].toHost(HbyAOut + (size_t)d*N);
+    // ---- pEqn.H (one corrector)
+    {
+        U.fixesValue = std::make_shared<dField>(mesh.ctx, mesh.nBoundary); U.fixesValue->assignHost(UfixedB);
+        dField fluxMask(mesh.ctx, mesh.nBoundary); fluxMask.assignHost(fluxMaskB);
+        p_rgh.bc = makeBC(mesh, bcP[0], bcP[1], bcP[2]); p_rgh.storeOldTime();
+        volScalarField psi("psi", mesh); psi.v.assignHost(psiOld); psi.storeOldTime(); psi.v.assignHost(psiNow);
+        volScalarField gh("gh", mesh); gh.v.assignHost(ghC);
+        const scalar pRef = pRefValue;
+        const volScalarField& rho_ = rhoB;          // rho with its (zeroGradient) boundary values; rho.oldTime() via `rho`
+        volScalarField rhoT("rho", rhoB); rhoT.old_ = rho.old_;
+
+        volScalarField rAU("rAU", 1.0/UEqn.A());
+        surfaceScalarField rhorAUf("rhorAUf", fvc::interpolate(rho_*rAU));
+        volVectorField HbyA(constrainHbyA(rAU*UEqn.H(), U, p_rgh));
+        rAU.v.toHost(rAUOut);
+        for (int d = 0; d < 3; d++) HbyA.v[d].toHost(HbyAOut + (size_t)d*N);
+
+        surfaceScalarField phig("phig", -rhorAUf*ghf*fvc::snGrad(rho_)*mesh.magSf());
+        surfaceScalarField phiHbyA
+        (
+            "phiHbyA",
+            (
+                fvc::flux(rho_*HbyA)
+              + rhorAUf*fvc::ddtCorr(rhoT, U, phi)
+            )
+          + phig
+        );
+        // Update the pressure BCs to ensure flux consistency
+        constrainPressure(p_rgh, rho_, U, phiHbyA, rhorAUf, fluxMask);
+
+        fvScalarMatrix p_rghEqn
+        (
+            fvm::ddt(psi, p_rgh)
+          + fvc::ddt(psi, rhoT)*gh
+          + fvc::ddt(psi)*pRef
+          + fvc::div(phiHbyA)
+          - fvm::laplacian(rhorAUf, p_rgh)
+        );
+        p_rghEqn.solve(mesh.solver("p_rgh"));
+
+        surfaceScalarField phiNew("phi", phiHbyA + p_rghEqn.flux());
+        U = HbyA + rAU*fvc::reconstruct((p_rghEqn.flux() + phig)/rhorAUf);
+        U.correctBoundaryConditions();
+
+        p_rgh.v.toHost(p_rghOut);
+        FFM_FOAM_CHK(ffm_faces_from_native(mesh.msh, phiNew.v.data(), phiOutF));
+        phiNew.b.toHost(phiOutB);
+        for (int d = 0; d < 3; d++) U.v[d].toHost(UcorrOut + (size_t)d*N);
+    }
 
     FFM_FOAM_CHK(ffm_ctx_sync(ctx));
     int n = 0;

@@ -676,7 +676,10 @@ extern "C" int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lowe
 extern "C" const double *ffm_mesh_geometry_d(const ffm_mesh *m, int which)
 {
     if (!m) return nullptr;
-    switch (which) { case 0: return m->V; case 1: return m->magSf; case 2: return m->delta; case 3: return m->w; case 4: return m->bMagSf; case 5: return m->bDelta; }
+    switch (which) {
+    case 0: return m->V; case 1: return m->magSf; case 2: return m->delta; case 3: return m->w; case 4: return m->bMagSf; case 5: return m->bDelta;
+    case 6: return m->bSf[0]; case 7: return m->bSf[1]; case 8: return m->bSf[2];
+    }
     return nullptr;
 }
 

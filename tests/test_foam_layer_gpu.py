@@ -36,6 +36,18 @@ def test_b1_demo_matches_oracle(O, ffm, ctx):
     bcY = fv.MixedBC(m, f=pl(30), ref=pl(40, 0.5), refGrad=pl(50, 0.1, -0.05))
     bcU = [fv.MixedBC(m, f=pl(60 + 10 * d), ref=pl(90 + 10 * d, 1.0, -0.5)) for d in range(3)]
     p_b = pl(120, 10.0, -5.0)
+    # pEqn inputs: compressibility now / old, gh, pRef; p_rgh: fixedFluxPressure on inlet, floor and sides (gradient set by
+    # constrainPressure), fixedValue on the top; U fixes its value on inlet and floor
+    psi_now = 1.17e-5 * (0.9 + 0.2 * hu(130, N)); psi_old = psi_now * (1 + 1e-3 * (hu(131, N) - 0.5))
+    gh = -9.81 * m.C[:, 1]; pRef = 101325.0
+    names = [p.name for p in m.patches]
+    fluxMask = [np.full(p.size, 0.0 if p.name == "top" else 1.0) for p in m.patches]
+    UfixMask = [np.full(p.size, 1.0 if p.name in ("inlet", "floor") else 0.0) for p in m.patches]
+    for d in range(3):                                    # consistent with the mask: fixedValue there
+        for q, p in enumerate(m.patches):
+            if p.name in ("inlet", "floor"):
+                bcU[d].f[q] = np.ones(p.size)
+    bcP = fv.MixedBC(m, f=[np.full(p.size, 1.0 if p.name == "top" else 0.0) for p in m.patches], ref=pl(140, 2.0, -1.0))
     rdt = 1.0 / dt
     zb = [np.zeros(p.size) for p in m.patches]
     ctl = dict(tolerance=1e-10, relTol=0.0)
@@ -72,6 +84,35 @@ def test_b1_demo_matches_oracle(O, ffm, ctx):
     K_ref = 0.5 * ((U_ref[0] ** 2 + U_ref[1] ** 2) + U_ref[2] ** 2)
     rAU_ref = 1.0 / UEqn.A()
     HbyA_ref = rAU_ref * UEqn.H(U_ref)
+    # ---- pEqn.H, one corrector (the association of the reference's tmp<fvMatrix> algebra: one source update per term)
+    rhorAU = rho_new * rAU_ref
+    rhorAUf, rhorAUfb = fv.interpolate(m, rhorAU, [rhorAU[p.faceCells] for p in m.patches])
+    Ubn = [bcU[c].values(m, U_ref[c]) for c in range(3)]
+    HbyAb = [[np.where(UfixMask[q] == 1.0, Ubn[c][q], HbyA_ref[c][p.faceCells]) for q, p in enumerate(m.patches)] for c in range(3)]
+    rhob = [rho_new[p.faceCells] for p in m.patches]
+    phig = -rhorAUf * ghf * sgr * m.magSf
+    rhoH = rho_new * HbyA_ref
+    flux = sum(fv.interpolate(m, rhoH[c], [rhob[q] * HbyAb[c][q] for q in range(len(m.patches))])[0] * m.Sf[:, c] for c in range(3))
+    fluxb = [(rhob[q] * HbyAb[0][q] * p.Sf[:, 0] + rhob[q] * HbyAb[1][q] * p.Sf[:, 1]) + rhob[q] * HbyAb[2][q] * p.Sf[:, 2] for q, p in enumerate(m.patches)]
+    rhoU0 = rho_old * U0
+    phiCorr = phi - sum((m.weights * rhoU0[c][m.l] + (1 - m.weights) * rhoU0[c][m.u]) * m.Sf[:, c] for c in range(3))
+    coeff = 1.0 - np.minimum(np.abs(phiCorr) / (np.abs(phi) + 1e-15), 1.0)
+    phiHbyA = flux + rhorAUf * (coeff * rdt * phiCorr) + phig
+    grads = [(fluxb[q] - rhob[q] * ((p.Sf[:, 0] * Ubn[0][q] + p.Sf[:, 1] * Ubn[1][q]) + p.Sf[:, 2] * Ubn[2][q])) / (p.magSf * rhorAUfb[q])
+             for q, p in enumerate(m.patches)]
+    bcp = fv.MixedBC(m, f=bcP.f, ref=bcP.ref, refGrad=[np.where(fluxMask[q] == 1.0, grads[q], bcP.refGrad[q]) for q in range(len(m.patches))])
+    E = fv.fvm_ddt(m, rdt, psi_now, psi_old, p_rgh)
+    E.add_vol(rdt * (psi_now * rho_new - psi_old * rho_old) * gh)
+    E.add_vol(rdt * (psi_now - psi_old) * pRef)
+    E.add_vol(fv.surface_integrate(m, phiHbyA, fluxb))
+    E -= fv.fvm_laplacian(m, rhorAUf, rhorAUfb, [bcp])
+    d, s = E.solve_system(0)
+    p_ref, pfP = O.Ldu(N, m.l, m.u).set_coeffs(d, E.upper, None).solve(O.PCG, O.DIC, p_rgh, s, **ctl)
+    fl, flb = E.flux(p_ref)
+    phi_ref = phiHbyA + fl
+    phib_ref = [a + b for a, b in zip(fluxb, flb)]
+    rec2 = fv.reconstruct(m, (fl + phig) / rhorAUf, [b / r for b, r in zip(flb, rhorAUfb)])
+    Ucorr_ref = HbyA_ref + rAU_ref * rec2.T
 
     # ------------------------------------------------------------------ the C++ layer on the device
     lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
@@ -88,24 +129,37 @@ def test_b1_demo_matches_oracle(O, ffm, ctx):
         arrs = [h(a) for a in arrs]; keep.append(arrs)
         arr = (dp * len(arrs))(*[a.ctypes.data_as(dp) for a in arrs]); keep.append(arr)
         return arr
-    out = dict(rho=np.empty(N), Yi=np.empty(N), U=np.empty((3, N)), K=np.empty(N), rAU=np.empty(N), HbyA=np.empty((3, N)))
+    out = dict(rho=np.empty(N), Yi=np.empty(N), U=np.empty((3, N)), K=np.empty(N), rAU=np.empty(N), HbyA=np.empty((3, N)),
+               p=np.empty(N), phi=np.empty(F), phib=np.empty(B), Uc=np.empty((3, N)))
     nit = (C.c_int * 16)()
     lib.b1_demo.restype = C.c_int
-    lib.b1_demo.argtypes = [C.c_void_p] * 3 + [C.c_double] * 2 + [dp] * 5 + [C.POINTER(dp)] + [dp] * 3 + [C.POINTER(dp)] + [C.c_double] + [dp] * 4 + [dp] * 6 + [C.POINTER(C.c_int)]
+    lib.b1_demo.argtypes = ([C.c_void_p] * 3 + [C.c_double] * 2 + [dp] * 5 + [C.POINTER(dp)] + [dp] * 3 + [C.POINTER(dp)] + [C.c_double] + [dp] * 4
+                            + [dp] * 3 + [C.c_double] + [C.POINTER(dp)] + [dp] * 2 + [dp] * 10 + [C.POINTER(C.c_int)])
+    bcPp = PP([bnd(bcP.f), bnd(bcP.ref), bnd(bcP.refGrad)])
     bcYp = PP([bnd(bcY.f), bnd(bcY.ref), bnd(bcY.refGrad)])
     bcUp = PP([x for d in range(3) for x in (bnd(bcU[d].f), bnd(bcU[d].ref), bnd(bcU[d].refGrad))])
     ctx._ready()
     ns = lib.b1_demo(ctx.h, A.h, mesh.h, dt, alphaY, P(cell(rho_old)), P(cell(rho_now)), P(face(phi)), P(bnd(phib)),
                      P(cell(Yi0)), bcYp, P(cell(dEff)), P(cell(R)), P(cell(U0)), bcUp, mu, P(face(ghf)), P(bnd(ghfb)),
-                     P(cell(p_rgh)), P(bnd(p_b)), P(out["rho"]), P(out["Yi"]), P(out["U"]), P(out["K"]), P(out["rAU"]), P(out["HbyA"]), nit)
-    assert ns == 5                                   # rho, Yi, Ux, Uy, Uz
+                     P(cell(p_rgh)), P(bnd(p_b)), P(cell(psi_now)), P(cell(psi_old)), P(cell(gh)), pRef, bcPp, P(bnd(fluxMask)), P(bnd(UfixMask)),
+                     P(out["rho"]), P(out["Yi"]), P(out["U"]), P(out["K"]), P(out["rAU"]), P(out["HbyA"]),
+                     P(out["p"]), P(out["phi"]), P(out["phib"]), P(out["Uc"]), nit)
+    assert ns == 6                                   # rho, Yi, Ux, Uy, Uz, p_rgh
     back = lambda a: (lambda o: (o.__setitem__((Ellipsis, cOrd), a), o)[1])(np.empty_like(a))
     assert np.array_equal(back(out["rho"]), rho_new)
-    assert list(nit[:5]) == [0, pfY["nIterations"]] + itU
+    assert list(nit[:6]) == [0, pfY["nIterations"]] + itU + [pfP["nIterations"]]
     assert rel_l2(back(out["Yi"]), Yi_ref) < 1e-8
     for c in range(3):
         assert rel_l2(back(out["U"])[c], U_ref[c]) < 1e-8
         assert rel_l2(back(out["HbyA"])[c], HbyA_ref[c]) < 1e-7
     assert rel_l2(back(out["K"]), K_ref) < 1e-8
     assert rel_l2(back(out["rAU"]), rAU_ref) < 1e-14
+    # pEqn: pressure against the scale of its own variation, fluxes and the corrected velocity
+    pg = back(out["p"])
+    assert np.linalg.norm(pg - p_ref) / np.linalg.norm(p_ref - p_ref.mean()) < 1e-7
+    phig_ = np.empty(F); phig_[fOrd] = out["phi"]
+    assert rel_l2(phig_, phi_ref) < 1e-8
+    assert rel_l2(out["phib"], np.concatenate(phib_ref)) < 1e-8
+    for c in range(3):
+        assert rel_l2(back(out["Uc"])[c], Ucorr_ref[c]) < 1e-8
     mesh.close(); A.close()
