@@ -227,7 +227,7 @@ static int hydrostatic_init(ffm_plume *P)
 
 // transport equation of a scalar: ddt(rho,vf) + div(phi,vf) - laplacian(gamma,vf) == su (+ explicit LHS terms in `expl`)
 static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *vf, const double *vf0, const double *fBC, const double *ref,
-                            const double *gamma_f, const double *gamma_b, const double *su, const double *expl, double tol)
+                            const double *gamma_f, const double *gamma_b, const double *su, const double *const *expl, double tol)
 {
     ffm_mesh *m = P->mesh; const int N = P->N;
     double *vb = P->wB[2], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *w = P->wF[3];
@@ -239,7 +239,9 @@ static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *
     FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, gamma_b, -1, fBC, ref, P->zeroB, P->ic[0], P->bc[0]));
     // source = rdt*rho0*vf0*V (- V*expl) ; then + boundaryCoeffs + V*su
     const double *V = ffm_mesh_geom(m, 0), *rho0 = P->rho0; double *s = P->src[0]; const double rdt = P->rdt;
-    if (expl) forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * vf0[i] * V[i] - V[i] * expl[i]; });
+    // explicit volume terms on the left-hand side: one `source -= V*term` each, in the order given (fvMatrix + volField)
+    if (expl) { const double *e0 = expl[0], *e1 = expl[1], *e2 = expl[2];
+                forN(P, N, [=] __device__(long i) { s[i] = ((rdt * rho0[i] * vf0[i] * V[i] - V[i] * e0[i]) - V[i] * e1[i]) - V[i] * e2[i]; }); }
     else forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * vf0[i] * V[i]; });
     double *s2 = P->wN[4];
     if (su) { forN(P, N, [=] __device__(long i) { s2[i] = s[i] + V[i] * su[i]; }); }
@@ -326,8 +328,9 @@ static int p_corrector(ffm_plume *P, bool final)
     {
         double *s = P->src[0]; const double *psi0 = P->psi0, *prgh0 = P->p_rgh0, *rho0 = P->rho0, *gh = P->gh;
         forN(P, N, [=] __device__(long i) {
-            const double expl = (rdt * (psi[i] * rho[i] - psi0[i] * rho0[i]) * gh[i] + rdt * (psi[i] - psi0[i]) * PREF) + div[i];
-            s[i] = rdt * psi0[i] * prgh0[i] * V[i] - V[i] * expl;
+            // fvc::ddt(psi,rho)*gh, fvc::ddt(psi)*pRef, fvc::div(phiHbyA): one source update each (solver/pEqn.H:30-33)
+            s[i] = ((rdt * psi0[i] * prgh0[i] * V[i] - V[i] * (rdt * (psi[i] * rho[i] - psi0[i] * rho0[i]) * gh[i]))
+                    - V[i] * (rdt * (psi[i] - psi0[i]) * PREF)) - V[i] * div[i];
         });
     }
     FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, P->src[0], nullptr, P->dWork, P->sWork));
@@ -458,8 +461,9 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         forN(P, B, [=] __device__(long k) { KfB[k] = phib[k] * Kb[k]; });
         double *divK = P->wN[4];
         FFM_TRY(ffm_fvc_surface_integrate(m, Kf, KfB, divK));
-        double *expl = P->wN[0]; const double *rho = P->rho, *rho0 = P->rho0, *K = P->K, *K0 = P->K0, *dpdt = P->dpdt;
-        forN(P, N, [=] __device__(long c) { expl[c] = (rdt * (rho[c] * K[c] - rho0[c] * K0[c]) + divK[c]) - dpdt[c]; });
+        double *ddtK = P->wN[0], *ndpdt = P->wN[5]; const double *rho = P->rho, *rho0 = P->rho0, *K = P->K, *K0 = P->K0, *dpdt = P->dpdt;
+        forN(P, N, [=] __device__(long c) { ddtK[c] = rdt * (rho[c] * K[c] - rho0[c] * K0[c]); ndpdt[c] = -dpdt[c]; });
+        const double *expl[3] = {ddtK, divK, ndpdt};       // fvc::ddt(rho,K) + fvc::div(phi,K) + (-dpdt), solver/YEEqn.H:89-101
         FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8));
     }
     standin_thermo(P);

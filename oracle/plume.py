@@ -261,9 +261,11 @@ class Plume:
         E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.h0)
         E += fv.fvm_div(m, self.phi, self.phib, wh, [bch])
         E -= fv.fvm_laplacian(m, af, afb, [bch])
-        expl = rdt * (self.rho * self.K - self.rho0 * self.K0) \
-            + fv.surface_integrate(m, self.phi * Kf, [pb * kb for pb, kb in zip(self.phib, Kb)]) - self.dpdt
-        E.source -= m.V * expl                                           # explicit terms on the LHS
+        # explicit terms on the LHS, one fvMatrix::operator+(tmp<fvMatrix>, tmp<volField>) each (source -= V*term), in the
+        # order of solver/YEEqn.H:89-101: fvc::ddt(rho, K), fvc::div(phi, K), -dpdt
+        E.add_vol(rdt * (self.rho * self.K - self.rho0 * self.K0))
+        E.add_vol(fv.surface_integrate(m, self.phi * Kf, [pb * kb for pb, kb in zip(self.phib, Kb)]))
+        E.add_vol(-self.dpdt)
         E.add_su(Qdot)
         d, s = E.solve_system()
         self.h = self.sol.solve("h", "h", m, d, E.upper, E.lower, s, self.h)
@@ -302,9 +304,10 @@ class Plume:
                  for q, p in enumerate(m.patches)]
         bcp = self.bc_p_rgh(grads)
         E = fv.fvm_ddt(m, rdt, self.psi, self.psi0, self.p_rgh0)
-        expl = rdt * (self.psi * self.rho - self.psi0 * self.rho0) * self.gh + rdt * (self.psi - self.psi0) * PREF \
-            + fv.surface_integrate(m, phiHbyA, phiHbyAb)
-        E.source -= m.V * expl
+        # fvc::ddt(psi, rho)*gh, fvc::ddt(psi)*pRef, fvc::div(phiHbyA): one source update each (solver/pEqn.H:30-33)
+        E.add_vol(rdt * (self.psi * self.rho - self.psi0 * self.rho0) * self.gh)
+        E.add_vol(rdt * (self.psi - self.psi0) * PREF)
+        E.add_vol(fv.surface_integrate(m, phiHbyA, phiHbyAb))
         E -= fv.fvm_laplacian(m, rhorAUf, rhorAUfb, [bcp])
         d, s = E.solve_system()
         self.p_rgh = self.sol.solve("p_rghFinal" if final else "p_rgh", "p_rgh", m, d, E.upper, E.lower, s, self.p_rgh)
