@@ -16,16 +16,21 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 2)])
-def test_decomposed_plume_matches_single_rank(ffm, ctx, grid):
-    glob = (12, 16, 12)
+# the third case gives every block 3 x 3 tiles of 16 x 16 cell columns plus ghost layers: the tiled sweeps, the tiled Amul
+# with its ghost-face tail and the mailboxes all run across tile AND rank boundaries
+@pytest.mark.parametrize("glob,grid", [((12, 16, 12), (2, 1, 1)), ((12, 16, 12), (1, 2, 2)), ((20, 36, 34), (2, 1, 1))])
+def test_decomposed_plume_matches_single_rank(ffm, ctx, glob, grid):
     world = grid[0] * grid[1] * grid[2]
     os.environ["FFM_PLUME_TIGHT"] = "1"   # every solve (hydrostatic start-up included) to 1e-13: block-Jacobi vs serial
     try:                                  # DIC then only changes the iteration path, not the converged fields
         ref = ffm.Plume(ctx, glob)
     finally:
         del os.environ["FFM_PLUME_TIGHT"]
-    nSteps = 2
+    # the multi-tile case runs one step and is compared at 1e-10 (after one step the decomposed and the single-rank run differ
+    # by solver-tolerance noise only, ~1e-13; from the second step on that noise flips limiter switches here and there)
+    big = glob[0] * glob[1] * glob[2] > 10000
+    nSteps = 1 if big else 2
+    tol = 1e-10 if big else 1e-8
     for _ in range(nSteps):
         ref.step()
     port = 29500 + (os.getpid() % 500) + 7 * world
@@ -44,9 +49,9 @@ def test_decomposed_plume_matches_single_rank(ffm, ctx, grid):
             full[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]] = pt[name].reshape(hi[2] - lo[2], hi[1] - lo[1], hi[0] - lo[0])
         a, b = full.ravel(), ref.field(name)
         if name in ("p_rgh", "ph_rgh"):
-            assert np.linalg.norm(a - b) / max(np.linalg.norm(b - b.mean()), 1e-30) < 1e-6, name
+            assert np.linalg.norm(a - b) / max(np.linalg.norm(b - b.mean()), 1e-30) < (1e-9 if big else 1e-6), name
         elif np.linalg.norm(b) < 1e-30:
             assert np.abs(a).max() < 1e-12, name
         else:
-            assert rel_l2(a, b) < 1e-8, (name, rel_l2(a, b))
+            assert rel_l2(a, b) < tol, (name, rel_l2(a, b))
     ref.close()
