@@ -94,6 +94,7 @@ def lib():
         "ffm_ldu_ncells": ([vp], C.c_int),
         "ffm_ldu_nfaces": ([vp], C.c_int),
         "ffm_ldu_nlevels": ([vp], C.c_int),
+        "ffm_ldu_sweep_mode": ([vp], C.c_int),
         "ffm_ldu_is_native_order": ([vp], C.c_int),
         "ffm_ldu_get_cell_order": ([vp, ip], C.c_int),
         "ffm_renumber_levels": ([C.c_int, C.c_int, ip, ip, ip, ip], C.c_int),
@@ -330,6 +331,11 @@ class lduMatrix:
     @property
     def nLevels(self):
         return lib().ffm_ldu_nlevels(self.h)
+
+    @property
+    def sweep_mode(self):
+        """0 level-scheduled, 2 tiled wavefront, 1 pipelined groups (experimental)"""
+        return lib().ffm_ldu_sweep_mode(self.h)
 
     @property
     def native_order(self):

@@ -565,6 +565,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
 }
 
 extern "C" int ffm_ldu_ncells(const ffm_ldu *A) { return A ? A->nCells : FFM_ERR_ARG; }
+extern "C" int ffm_ldu_sweep_mode(const ffm_ldu *A) { return !A ? FFM_ERR_ARG : (A->sweepMode == 2 ? (ffm_tile_usable(A) ? 2 : 1) : A->sweepMode); }
 extern "C" int ffm_ldu_nowned(const ffm_ldu *A) { return A ? A->nOwned : FFM_ERR_ARG; }
 extern "C" int ffm_ldu_nfaces(const ffm_ldu *A) { return A ? A->nFaces : FFM_ERR_ARG; }
 extern "C" int ffm_ldu_nlevels(const ffm_ldu *A) { return A ? A->nLevels : FFM_ERR_ARG; }

@@ -125,6 +125,9 @@ int ffm_ldu_destroy(ffm_ldu *ldu);
 int ffm_ldu_ncells(const ffm_ldu *ldu);
 int ffm_ldu_nfaces(const ffm_ldu *ldu);
 int ffm_ldu_nlevels(const ffm_ldu *ldu);
+/* which sweep kernels DIC / DILU / Gauss-Seidel use on this matrix: 0 one launch per dependency level, 2 tiled wavefront
+ * (ffm_tile.hip: group hint or detected blockMesh box), 1 the experimental pipelined groups (FFM_SWEEP=pipe)          */
+int ffm_ldu_sweep_mode(const ffm_ldu *ldu);
 /* 1 when the caller's cell numbering is used as is (no permutation passes)   */
 int ffm_ldu_is_native_order(const ffm_ldu *ldu);
 /* new->old cell permutation chosen by the library (host, int[nCells])        */

@@ -21,7 +21,7 @@ def _build(ffm, ctx, n, mode, asym):
         A = ffm.lduMatrix(ctx, blk.nCells, l2, u2)
     finally:
         os.environ.pop("FFM_SWEEP", None)
-    assert A.native_order
+    assert A.native_order and A.sweep_mode == (2 if mode == "tile" else 0)
     up = s["upper"]
     lo = up * (1.0 + 0.3 * (H.hash_u(0xA1, blk.gface) - 0.5)) if asym else None
     A.set_coeffs(s["diag"][cOrd], up[fOrd], None if lo is None else lo[fOrd])
