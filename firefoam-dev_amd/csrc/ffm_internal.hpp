@@ -196,7 +196,8 @@ int ffm_allreduce_minmax(ffm_ctx *ctx, int slot, int isMax);
 void ffm_comm_finalize_i(ffm_ctx *ctx);
 int ffm_precond_setup_i(ffm_ldu *A, int precond);
 int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
-int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<int> &bl, const std::vector<int> &grpCell);
+int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<int> &bl, const std::vector<int> &grpCell,
+                   const std::vector<int> *bwdCells /* null: the backward order mirrors the forward order */);
 bool ffm_tile_feasible(int nOwn, int F, const int *l, const int *u);
 int ffm_tile_calc_rD(ffm_ldu *A);
 bool ffm_tile_gs_usable(const ffm_ldu *A);

@@ -210,6 +210,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
             if (done == nl) { hinted = true; G = nl; for (int c = 0; c < nOwn; c++) grpOfOld[c] = rank[gid[c]]; }
         }
         if (!hinted && autoMode) {           // unusable hint: level-scheduled sweeps
+            if (getenv("FFM_VERBOSE") && groupHint) fprintf(stderr, "ffm: the group hint gives a cyclic group graph: level-scheduled sweeps\n");
             LduAnalysis b;
             FFM_TRY(analyse(N, nOwn, F, l, u, renumber, sortByNewNeighbour, b, nullptr, 0));
             a = std::move(b);
@@ -353,7 +354,8 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         }
         a.bEntPos.push_back(nOwn);
     }
-    if (a.mode == 2 && !(a.bwdIsReverse && ffm_tile_feasible(nOwn, F, a.l.data(), a.u.data()))) {
+    if (a.mode == 2 && !ffm_tile_feasible(nOwn, F, a.l.data(), a.u.data())) {
+        if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm: tiled sweeps not applicable (more than 3 lower or upper neighbours): level-scheduled sweeps\n");
         // the tiled sweeps cannot take this mesh / grouping: level-scheduled sweeps instead
         LduAnalysis b;
         FFM_TRY(analyse(N, nOwn, F, l, u, renumber, sortByNewNeighbour, b, nullptr, 0));
@@ -503,7 +505,7 @@ extern "C" int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwn, int nGhost, int F, co
             hipMemsetAsync(A->pipeTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
         }
         if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
-        if (A->sweepMode == 2) { A->h_loEnt = loEnt; A->h_upNbr = upNbr; rc = ffm_tile_build(A, a.levNew, a.blNew, a.grpCell); A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit(); if (rc) break; }
+        if (A->sweepMode == 2) { A->h_loEnt = loEnt; A->h_upNbr = upNbr; rc = ffm_tile_build(A, a.levNew, a.blNew, a.grpCell, a.bwdIsReverse ? nullptr : &a.bwdCells); A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit(); if (rc) break; }
         {
             // XCD-aware schedule (see ffm_internal.hpp): chunks of 256 rows, binned by the eighth of their dependency level
             const int nChunks = (nOwn + 255) / 256;

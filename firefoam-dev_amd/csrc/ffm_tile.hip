@@ -63,6 +63,14 @@ struct ffm_tile_plan {
     double *mailAll = nullptr;
     long nMail = 0;
     unsigned long long *trace = nullptr;    // diagnostics (ffm_debug_tile_trace): per group {start, first entry done, end, re-loads} of the last launch
+    // ---- general backward order: when the backward dependency order inside a group is not the mirror image of the forward
+    // one (baffles, unstructured meshes), the backward sweep runs in "position space": position q holds cell cellOf[q]
+    // (cells of a group sorted by backward level), all backward streams are indexed by position, and the vectors of a
+    // sweep are permuted into / out of position space by a gather / scatter pass around the kernel
+    bool mirror = true;
+    const int *cellOf = nullptr;    // [nOwn] (= ffm_ldu::bwdCells, not owned)
+    double *wp = nullptr, *rDp = nullptr;
+    unsigned long rDpEpoch = ~0ul; int rDpKind = -1;
     // ---- tiled Amul (symmetric matrices): same groups and entries as the forward sweep
     bool amulUsable = false;
     std::vector<int> grpEntHost;    // forward entries of each group (host copy)
@@ -84,7 +92,7 @@ void ffm_tile_free(ffm_ldu *A)
 {
     if (!A->tile) return;
     free_dir(A->tile->f); free_dir(A->tile->b);
-    hipFree(A->tile->mailAll); hipFree(A->tile->trace);
+    hipFree(A->tile->mailAll); hipFree(A->tile->trace); hipFree(A->tile->wp); hipFree(A->tile->rDp);
     hipFree(A->tile->arec); hipFree(A->tile->acode); hipFree(A->tile->aext); hipFree(A->tile->aseg);
     hipFree(A->tile->tailCell); hipFree(A->tile->tailStart); hipFree(A->tile->tailFace); hipFree(A->tile->tailNbr);
     delete A->tile; A->tile = nullptr;
@@ -200,6 +208,77 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
 }
 
 
+// Backward direction in position space (see ffm_tile_plan::mirror): position q of the group-major array bwdCells holds the
+// cell processed q-th; neighbours = the owned upper neighbours of that cell, referred to by their positions (always smaller
+// inside the group).  Same outputs as build_dir, every per-cell array indexed by position.
+static int build_dir_pos(ffm_ldu *A, const std::vector<int> &bl, const std::vector<int> &grpCell, const std::vector<int> &grpOfCell,
+                         const std::vector<int> &bwdCells, TileDir &D, bool &ok)
+{
+    const int G = (int)grpCell.size() - 1, nOwn = A->nOwned, W = T_W;
+    std::vector<int> posOf(nOwn);
+    for (int q = 0; q < nOwn; q++) posOf[bwdCells[q]] = q;
+    std::vector<int> nbr((size_t)W * nOwn, -1), src((size_t)W * nOwn, -1);        // neighbour POSITIONS
+    std::vector<unsigned char> exposed(nOwn, 0);                                   // by position
+    auto isExt = [&](int q, int nq) { return grpOfCell[bwdCells[nq]] != grpOfCell[bwdCells[q]] || std::abs(q - nq) > T_RINGD; };
+    for (int q = 0; q < nOwn; q++) {
+        const int c = bwdCells[q], sl = c >> 6, lane = c & 63, wdt = (A->h_upOff[sl + 1] - A->h_upOff[sl]) / 64;
+        int k = 0;
+        for (int s = 0; s < wdt; s++) {
+            const int e = A->h_upOff[sl] + s * 64 + lane, nb = A->h_upNbr[e];
+            if (nb < 0 || nb >= nOwn) continue;
+            if (k >= W) { ok = false; return FFM_OK; }
+            const int nq = posOf[nb];
+            if (grpOfCell[nb] == grpOfCell[c] && nq >= q) { ok = false; return FFM_OK; }      // must have been processed earlier
+            nbr[(size_t)W * q + k] = nq; src[(size_t)W * q + k] = e;
+            if (isExt(q, nq)) exposed[nq] = 1;
+            k++;
+        }
+    }
+    std::vector<unsigned short> code((size_t)4 * nOwn, (unsigned short)T_NONE);
+    std::vector<int> grpEnt(G + 1, 0), mailIdx(nOwn, -1);                          // mailIdx by position
+    std::vector<int4> rec;
+    int nPub = 0;
+    auto extRefs = [&](int q) { int n = 0; for (int k = 0; k < W; k++) { const int nq = nbr[(size_t)W * q + k]; if (nq >= 0 && isExt(q, nq)) n++; } return n; };
+    for (int g = 0; g < G; g++) {
+        const int gs = grpCell[g], ge = grpCell[g + 1];
+        int prevLevel = -1;
+        for (int q = gs; q < ge;) {
+            int e = q, nx = 0;
+            while (e < ge && bl[bwdCells[e]] == bl[bwdCells[q]] && e - q < T_ENT) { const int x = extRefs(e); if (e > q && nx + x > T_XMAX) break; nx += x; e++; }
+            if (bl[bwdCells[q]] < prevLevel) { ok = false; return FFM_OK; }
+            prevLevel = bl[bwdCells[q]];
+            int slot = 0;
+            for (int p = q; p < e; p++) if (exposed[p]) { code[(size_t)4 * p + 3] = (unsigned short)slot; mailIdx[p] = nPub + slot; slot++; }
+            rec.push_back(make_int4(q, (e - q) | (nx << 16), nPub, 0));
+            nPub += slot;
+            q = e;
+        }
+        grpEnt[g + 1] = (int)rec.size();
+    }
+    std::vector<int> extSrc;
+    for (size_t ei = 0; ei < rec.size(); ei++) {
+        int4 &R = rec[ei];
+        const int q0 = R.x, cnt = R.y & 0xFFFF;
+        const int gs = cnt ? grpCell[grpOfCell[bwdCells[q0]]] : 0;
+        R.w = (int)extSrc.size();
+        int t = 0;
+        for (int q = q0; q < q0 + cnt; q++) for (int k = 0; k < W; k++) {
+            const int nq = nbr[(size_t)W * q + k];
+            if (nq < 0) continue;
+            if (isExt(q, nq)) {
+                if (mailIdx[nq] < 0) { ffm_set_error("internal: tile plan references an unpublished cell"); return FFM_ERR_ADDR; }
+                code[(size_t)4 * q + k] = (unsigned short)(T_RING + (int)(ei & 1) * T_XMAX + t); extSrc.push_back(mailIdx[nq]); t++;
+            } else code[(size_t)4 * q + k] = (unsigned short)((nq - gs) & (T_RING - 1));
+        }
+        if (t != (R.y >> 16)) { ffm_set_error("internal: tile plan external count mismatch"); return FFM_ERR_ADDR; }
+    }
+    D.nEnt = (int)rec.size(); D.nPub = nPub;
+    for (int k = 0; k < 2 * T_PF + 2; k++) rec.push_back(make_int4(0, 0, 0, 0));
+    for (int k = 0; k < T_THREADS; k++) extSrc.push_back(0);
+    FFM_TRY(upv(&D.grpEnt, grpEnt)); FFM_TRY(upv(&D.rec, rec)); FFM_TRY(upv(&D.extSrc, extSrc)); FFM_TRY(upv(&D.code, code)); FFM_TRY(upv(&D.src, src));
+    return FFM_OK;
+}
+
 // ------------------------------------------------------------------ tiled Amul: plan ---
 // y = A x for a symmetric matrix on the tile numbering.  One workgroup streams through one group entry by entry (the
 // forward sweep's entries); x and the upper coefficients of the entries [e-3, e+3] live in LDS rings, so a row finds its
@@ -294,7 +373,8 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
     return FFM_OK;
 }
 
-int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<int> &bl, const std::vector<int> &grpCell)
+int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<int> &bl, const std::vector<int> &grpCell,
+                   const std::vector<int> *bwdCells)
 {
     A->tile = new ffm_tile_plan();
     ffm_tile_plan *T = A->tile;
@@ -307,13 +387,17 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
     bool ok = true;
     std::vector<int4> recF;
     FFM_TRY(build_dir(A, true, lev, grpCell, grpOfCell, T->f, ok, &recF, &T->grpEntHost));
-    if (ok) FFM_TRY(build_dir(A, false, bl, grpCell, grpOfCell, T->b, ok));
+    T->mirror = bwdCells == nullptr;
+    if (ok) {
+        if (T->mirror) FFM_TRY(build_dir(A, false, bl, grpCell, grpOfCell, T->b, ok));
+        else { FFM_TRY(build_dir_pos(A, bl, grpCell, grpOfCell, *bwdCells, T->b, ok)); T->cellOf = A->bwdCells; }
+    }
     T->usable = ok;
     if (ok) {
         T->nMail = (long)T->f.nPub + T->b.nPub + 2;
         FFM_HIP(hipMalloc((void **)&T->mailAll, sizeof(double) * T->nMail));
         T->f.mail = T->mailAll; T->b.mail = T->mailAll + T->f.nPub + 1;
-        FFM_TRY(build_amul(A, grpOfCell, recF));
+        if (T->mirror) FFM_TRY(build_amul(A, grpOfCell, recF));
     }
     return FFM_OK;
 }
@@ -371,7 +455,7 @@ __device__ __noinline__ double t_wait_value(const double *addr, unsigned int *ti
 //     list -> mailbox values, each stage read ahead, re-loading a value while it still reads the sentinel.  Its few loads
 //     have a vmcnt stream of their own, so waiting for a mailbox value never waits for the compute waves' read-ahead.
 // Every wave executes the same number of workgroup barriers: one after the prologue, one per entry of the padded loop.
-template <int MODE, bool TRACE>
+template <int MODE, bool TRACE, bool POSB = false>
 __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const double *__restrict__ ca, const double *__restrict__ cb,
                                                          const double *__restrict__ dg, const double *__restrict__ r, double *w, double *aux)
 {
@@ -450,7 +534,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
 #define T_FETCH(k, e, R_) {                                                                             \
         const unsigned cnt_ = ((e) < e1) ? ((unsigned)R_.y & 0xFFFFu) : 0u;                              \
         const bool ok_ = tid < cnt_;                                                                     \
-        const unsigned cc_ = ok_ ? (ASC ? (unsigned)R_.x + tid : (unsigned)R_.x + cnt_ - 1u - tid) : gs; \
+        const unsigned cc_ = ok_ ? ((ASC || POSB) ? (unsigned)R_.x + tid : (unsigned)R_.x + cnt_ - 1u - tid) : gs; \
         const unsigned o8_ = cc_ * 8u, o24_ = cc_ * 24u;        /* 32-bit byte offsets: arrays < 4 GiB (host check) */  \
         pq[k] = *(const uint2 *)((const char *)t.code + o8_);                                            \
         { const T3 v_ = *(const T3 *)((const char *)ca + o24_); pa[k][0] = v_.a; pa[k][1] = v_.b; pa[k][2] = v_.c; }     \
@@ -528,6 +612,15 @@ __global__ void k_tile_fill(long n, unsigned long long *p, unsigned long long v)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// GATHER: out[q] = in[cellOf[q]]; else scatter: out[cellOf[q]] = in[q]
+template <bool GATHER>
+__global__ void k_tile_permute(long n, const int *__restrict__ cellOf, const double *__restrict__ in, double *__restrict__ out)
+{
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        if (GATHER) out[q] = in[cellOf[q]]; else out[cellOf[q]] = in[q];
+    }
+}
+
 static TileView tview(const ffm_ldu *A, const TileDir &d)
 {
     TileView t; t.G = A->tile->G; t.grpCell = A->grpCell; t.grpEnt = d.grpEnt; t.extSrc = d.extSrc; t.rec = d.rec;
@@ -568,6 +661,22 @@ int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, d
     FFM_TRY(tile_coef(A, T->f, fwdUpper, &cf));
     FFM_TRY(tile_coef(A, T->b, bwdUpper, &cb));
     tile_fill(A, T->mailAll, T->nMail);
+    if (!T->mirror) {
+        // backward sweep in position space: rD and the forward result are gathered to positions, the result scattered back
+        const long n = A->nOwned;
+        const int g = std::max(1, std::min(ffm_grid(n, 256), 8 * RED_BLOCKS));
+        if (!T->wp) { FFM_HIP(hipMalloc((void **)&T->wp, sizeof(double) * std::max<long>(n, 1))); FFM_HIP(hipMalloc((void **)&T->rDp, sizeof(double) * std::max<long>(n, 1))); }
+        if (T->rDpEpoch != A->rDEpoch || T->rDpKind != A->rDKind) {
+            hipLaunchKernelGGL(k_tile_permute<true>, dim3(g), dim3(256), 0, s, n, T->cellOf, (const double *)A->rD, T->rDp);
+            T->rDpEpoch = A->rDEpoch; T->rDpKind = A->rDKind;
+        }
+        hipLaunchKernelGGL((k_tile<TM_FWD, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr, (const double *)A->rD, r, w, (double *)nullptr);
+        hipLaunchKernelGGL(k_tile_permute<true>, dim3(g), dim3(256), 0, s, n, T->cellOf, (const double *)w, T->wp);
+        hipLaunchKernelGGL((k_tile<TM_BWD, false, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr, (const double *)T->rDp, r, T->wp, (double *)nullptr);
+        hipLaunchKernelGGL(k_tile_permute<false>, dim3(g), dim3(256), 0, s, n, T->cellOf, (const double *)T->wp, w);
+        FFM_HIP(hipGetLastError());
+        return FFM_OK;
+    }
     if (T->trace) {
         hipLaunchKernelGGL((k_tile<TM_FWD, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr, (const double *)A->rD, r, w, (double *)nullptr);
         hipLaunchKernelGGL((k_tile<TM_BWD, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr, (const double *)A->rD, r, w, (double *)nullptr);
@@ -590,7 +699,7 @@ __global__ void k_tile_gs_products(long n3, const int *__restrict__ nbrCell, con
     }
 }
 
-bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->nCells == A->nOwned; }
+bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->mirror && A->nCells == A->nOwned; }
 
 // One GaussSeidelSmoother / symGaussSeidelSmoother sweep (forward rows, then reverse rows when sym): psi in place, bP = bPrime
 // (source with the lagged interface terms), bSave = scratch [nCells].  prod = scratch [3*nCells].

@@ -16,9 +16,9 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "steckle
 @pytest.mark.parametrize("tiled", [False, True])
 def test_steckler_hydrostatic_solves_on_gpu(O, ffm, ctx, tiled):
     """tiled = False: the library sees an unstructured mesh (the baffles break the box pattern) and uses the level-scheduled
-    sweeps.  tiled = True: the host passes a group hint (8 x 8 tiles of cell columns from the cell indices); with the baffles
-    the backward dependency order inside a tile is no longer the mirror image of the forward one, which the tiled sweeps
-    need, so the library must fall back to the level-scheduled sweeps by itself (and say so through ffm_ldu_sweep_mode)."""
+    sweeps.  tiled = True: the host passes a group hint (8 x 8 tiles of cell columns from the cell indices) and the tiled
+    sweeps run; with the baffles the backward dependency order inside a tile is not the mirror image of the forward one, so
+    the backward sweep takes its position-space form (ffm_tile_plan::mirror == false)."""
     from oracle import steckler
     m = steckler.build_mesh()
     hint = None
@@ -26,7 +26,7 @@ def test_steckler_hydrostatic_solves_on_gpu(O, ffm, ctx, tiled):
         i, j, k = m.ijk
         hint = (j // 8 + 100 * (k // 8)).astype(np.int32)
     A = ffm.lduMatrix(ctx, m.nCells, m.l, m.u, groupHint=hint)      # natural numbering -> internal permutation
-    assert A.sweep_mode == 0
+    assert A.sweep_mode == (2 if tiled else 0)
 
     def gpu_solve(mesh, diag, upper, source, psi0):
         A.set_coeffs(diag, upper)

@@ -27,7 +27,7 @@ def meshes(O):
 @pytest.fixture(scope="module", params=["hex_natural", "hex_levelmajor", "dag_random", "chain", "plane",
                                         "hex_natural_g37", "dag_random_g23", "chain_g64", "plane_g50", "hex_levelmajor_g41",
                                         "hex_natural_t37", "dag_random_t23", "chain_t64", "plane_t50", "hex_natural_t500", "hex_tiles_t0",
-                                        "hex_natural_lv", "hex_levelmajor_lv", "chain_lv", "plane_lv", "hex_big", "hex_big_lv"])
+                                        "hex_natural_lv", "hex_levelmajor_lv", "chain_lv", "plane_lv", "hex_big", "hex_big_lv", "hex_baffled_t0"])
 def case(request, O, ffm, ctx):
     """`_gNN` variants force the pipelined sweep to split the mesh into groups of NN cells, so that the cross-workgroup
     hand-off (progress words, sc1 loads/stores, LDS ring wrap-around) is exercised on small meshes too.  `_tNN`: tiled
@@ -60,12 +60,16 @@ def _make_case(name, grp, O, ffm, ctx):
         N, l, u = O.hex_ldu(9, 7, 8)
         cOrd, fOrd = ffm.renumber_levels(N, l, u)
         l, u, _ = ffm.hexmesh.apply_renumbering(N, l, u, cOrd, fOrd)
-    elif name == "hex_tiles":
-        nx, ny, nz = 9, 7, 8
+    elif name in ("hex_tiles", "hex_baffled"):
+        nx, ny, nz = (9, 7, 8) if name == "hex_tiles" else (11, 13, 12)
         N, l, u = O.hex_ldu(nx, ny, nz)
+        if name == "hex_baffled":       # a fifth of the faces removed (baffles): inside a tile the backward dependency order is
+            keep = O.hash_u(0xBAF, np.arange(len(l))) > 0.2          # no longer the mirror image of the forward order
+            l, u = l[keep], u[keep]
         c = np.arange(N)
         hint = ((c // nx) % ny) // 3 + 10 * ((c // (nx * ny)) // 3)      # 3x3 tiles of cell columns (j,k)
         A = ffm.lduMatrix(ctx, N, l, u, groupHint=hint)
+        assert A.sweep_mode == 2
         yield name, N, l, u, A
         A.close()
         return
