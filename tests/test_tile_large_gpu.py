@@ -46,6 +46,46 @@ def test_tiled_kernels_equal_level_kernels_at_scale(ffm, ctx, asym):
         y = nat(A.Amul(ctx.to_device(s["x"][cOrd])))
         out[mode] = (rD, w1, w2, w3, y)
         A.close()
-    for a, b in zip(out["tile"], out["levels"]):
-        assert np.array_equal(a, b)
+    for idx, (a, b) in enumerate(zip(out["tile"], out["levels"])):
+        bad = np.nonzero(~((a == b) | (np.isnan(a) & np.isnan(b))))[0]
+        assert len(bad) == 0, (idx, len(bad), bad[:5], a[bad[:5]], b[bad[:5]], int(np.isnan(a).sum()), int(np.isnan(b).sum()))
     assert np.array_equal(out["tile"][1], out["tile"][3])
+
+
+def test_tiled_sweeps_on_a_baffled_box_equal_the_serial_loops(O, ffm, ctx):
+    """96^3 box with a fifth of the faces removed: the backward sweep takes its position-space form (the backward order inside
+    a tile is not the mirror image of the forward order); 36 tiles, mailboxes across all of them.  Compared bitwise with the
+    oracle's serial face loops ON THE SAME NUMBERING (with baffles the relative order of a cell's neighbours, hence the order
+    of its sums, depends on the numbering, so the level-scheduled kernels on their own numbering are no bitwise reference)."""
+    H = ffm.hexmesh
+    n = 96
+    blk = H.HexBlock((n, n, n))
+    keep = H.hash_u(0xBAF1, blk.gface) > 0.2
+    l, u = blk.l[keep], blk.u[keep]
+    N = blk.nCells
+    up = -(1e-3 * (0.5 + H.hash_u(0xF1, blk.gface[keep]))) * 0.05
+    lo = up * (1.0 + 0.3 * (H.hash_u(0xA1, blk.gface[keep]) - 0.5))
+    diag = np.zeros(N); np.add.at(diag, l, -up); np.add.at(diag, u, -lo); diag += 1e-6
+    r0 = 2.0 * H.hash_u(0xF3, np.arange(N)) - 1.0
+    hint = (blk.j // 16 + 1000 * (blk.k // 16)).astype(np.int32)
+    cOrd, fOrd = ffm.renumber_levels(N, l, u, groupHint=hint)
+    l2, u2, _ = H.apply_renumbering(N, l, u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2, groupHint=hint[cOrd])
+    assert A.native_order and A.sweep_mode == 2
+    Ao = O.Ldu(N, l2, u2)
+    r = r0[cOrd]
+    rd = ctx.to_device(r)
+    # DIC
+    A.set_coeffs(diag[cOrd], up[fOrd]); Ao.set_coeffs(diag[cOrd], up[fOrd], None)
+    rD = Ao.dic_rD()
+    assert np.array_equal(A.reciprocalD("DIC").cpu().numpy(), rD)
+    ref = Ao.dic_precondition(rD, r)
+    assert np.array_equal(A.precondition("DIC", rd).cpu().numpy(), ref)
+    assert np.array_equal(A.precondition("DIC", rd).cpu().numpy(), ref)         # mailboxes re-armed
+    # DILU and its transpose
+    A.set_coeffs(diag[cOrd], up[fOrd], lo[fOrd]); Ao.set_coeffs(diag[cOrd], up[fOrd], lo[fOrd])
+    rD = Ao.dilu_rD()
+    assert np.array_equal(A.reciprocalD("DILU").cpu().numpy(), rD)
+    assert np.array_equal(A.precondition("DILU", rd).cpu().numpy(), Ao.dilu_precondition(rD, r))
+    assert np.array_equal(A.precondition("DILU", rd, transpose=True).cpu().numpy(), Ao.dilu_precondition(rD, r, transpose=True))
+    A.close()
