@@ -77,6 +77,11 @@ struct ffm_tile_plan {
     int4 *arec = nullptr;           // [nEnt + pad] {first cell, cells | externals << 16, first index into aext, 0}
     uint4 *acode = nullptr;         // [nOwn] 8 x 16 bit: 3 lower codes, 3 upper codes (A_* encoding below), 2 spare
     int2 *aext = nullptr;           // per external reference {cell whose x is needed, native index of the coefficient or -1}
+    // owned upper neighbours of every cell in CELL space (the backward direction's tables are in position space when
+    // !mirror): native coefficient index and neighbour cell of slot k, and the upper coefficients gathered through them
+    int *upSrcCell = nullptr, *upNbrCell = nullptr;
+    double *upCoefCell = nullptr, *diagp = nullptr;
+    unsigned long upCoefEpoch = ~0ul, diagpEpoch = ~0ul;
     int nSeg = 0;                   // workgroups of the tiled Amul: a segment = a run of entries of one group
     int4 *aseg = nullptr;           // [nSeg] {group, first entry, end entry, end entry of the group}
     int nTail = 0;                  // cells that own faces towards ghost cells (processed after the tiled kernel, in face order)
@@ -94,6 +99,7 @@ void ffm_tile_free(ffm_ldu *A)
     free_dir(A->tile->f); free_dir(A->tile->b);
     hipFree(A->tile->mailAll); hipFree(A->tile->trace); hipFree(A->tile->wp); hipFree(A->tile->rDp);
     hipFree(A->tile->arec); hipFree(A->tile->acode); hipFree(A->tile->aext); hipFree(A->tile->aseg);
+    hipFree(A->tile->upSrcCell); hipFree(A->tile->upNbrCell); hipFree(A->tile->upCoefCell); hipFree(A->tile->diagp);
     hipFree(A->tile->tailCell); hipFree(A->tile->tailStart); hipFree(A->tile->tailFace); hipFree(A->tile->tailNbr);
     delete A->tile; A->tile = nullptr;
 }
@@ -304,6 +310,7 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
     std::vector<int4> arec(nEnt);
     std::vector<int2> aext;
     std::vector<int> tailCell, tailStart(1, 0), tailFace, tailNbr;
+    std::vector<int> upSrc((size_t)3 * nOwn, -1), upNb((size_t)3 * nOwn, -1);
     auto inRing = [&](int c, int nb) { return grpOfCell[nb] == grpOfCell[c] && std::abs(entOf[nb] - entOf[c]) <= A_WIN; };
     for (int e = 0; e < nEnt; e++) {
         const int c0 = recF[e].x, cnt = recF[e].y & 0xFFFF;
@@ -340,6 +347,7 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
                     continue;
                 }
                 if (ghostSeen || k >= 3) return FFM_OK;                      // owned after ghost, or too many: not usable
+                upSrc[(size_t)3 * c + k] = idx; upNb[(size_t)3 * c + k] = nb;
                 if (inRing(c, nb) && nb - c < 2048) code[(size_t)8 * c + 3 + k] = (unsigned short)(nb - c);
                 else {
                     if (t >= A_XMAX) return FFM_OK;
@@ -357,6 +365,7 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
     FFM_TRY(upv(&T->arec, arec)); FFM_TRY(upv(&T->aext, aext));
     FFM_HIP(hipMalloc((void **)&T->acode, sizeof(unsigned short) * 8 * std::max<size_t>(nOwn, 1)));
     FFM_HIP(hipMemcpy(T->acode, code.data(), sizeof(unsigned short) * code.size(), hipMemcpyHostToDevice));
+    FFM_TRY(upv(&T->upSrcCell, upSrc)); FFM_TRY(upv(&T->upNbrCell, upNb));
     T->nTail = (int)tailCell.size();
     FFM_TRY(upv(&T->tailCell, tailCell)); FFM_TRY(upv(&T->tailStart, tailStart)); FFM_TRY(upv(&T->tailFace, tailFace)); FFM_TRY(upv(&T->tailNbr, tailNbr));
     // segments: enough workgroups to fill the chip, each long enough to amortise the A_WIN entries read twice at either end
@@ -397,7 +406,7 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
         T->nMail = (long)T->f.nPub + T->b.nPub + 2;
         FFM_HIP(hipMalloc((void **)&T->mailAll, sizeof(double) * T->nMail));
         T->f.mail = T->mailAll; T->b.mail = T->mailAll + T->f.nPub + 1;
-        if (T->mirror) FFM_TRY(build_amul(A, grpOfCell, recF));
+        FFM_TRY(build_amul(A, grpOfCell, recF));
     }
     return FFM_OK;
 }
@@ -650,6 +659,23 @@ static void tile_fill(ffm_ldu *A, double *p, long n)
     hipLaunchKernelGGL(k_tile_fill, dim3(g), dim3(256), 0, A->ctx->stream, n, (unsigned long long *)p, T_SENT);
 }
 
+// upper coefficients of the owned upper neighbours in cell space: the backward direction's gathered array on mirror-ordered
+// meshes, a gather of its own otherwise
+static int tile_up_coef_cell(ffm_ldu *A, const double **out)
+{
+    ffm_tile_plan *T = A->tile;
+    if (T->mirror) return tile_coef(A, T->b, true, out);
+    const long n = (long)T_W * A->nOwned;
+    if (!T->upCoefCell) { FFM_HIP(hipMalloc((void **)&T->upCoefCell, sizeof(double) * std::max<long>(n, 1))); T->upCoefEpoch = ~0ul; }
+    if (T->upCoefEpoch != A->offDiagEpoch) {
+        hipLaunchKernelGGL(k_tile_gather, dim3(std::max(1, std::min(ffm_grid(n, 256), 8 * RED_BLOCKS))), dim3(256), 0, A->ctx->stream, n,
+                           (const int *)T->upSrcCell, (const double *)A->upper, T->upCoefCell);
+        T->upCoefEpoch = A->offDiagEpoch;
+    }
+    *out = T->upCoefCell;
+    return FFM_OK;
+}
+
 int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w)
 {
     ffm_tile_plan *T = A->tile;
@@ -699,7 +725,7 @@ __global__ void k_tile_gs_products(long n3, const int *__restrict__ nbrCell, con
     }
 }
 
-bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->mirror && A->nCells == A->nOwned; }
+bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable && A->nCells == A->nOwned; }
 
 // One GaussSeidelSmoother / symGaussSeidelSmoother sweep (forward rows, then reverse rows when sym): psi in place, bP = bPrime
 // (source with the lagged interface terms), bSave = scratch [nCells].  prod = scratch [3*nCells].
@@ -707,17 +733,33 @@ int ffm_tile_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSa
 {
     ffm_tile_plan *T = A->tile;
     hipStream_t s = A->ctx->stream;
-    const double *cl, *cu;
+    const double *cl, *cuCell, *cuB;
     FFM_TRY(tile_coef(A, T->f, A->lower == A->upper, &cl));        // lower coefficients, lower-neighbour layout
-    FFM_TRY(tile_coef(A, T->b, true, &cu));                         // upper coefficients, upper-neighbour layout
-    const long n3 = (long)T_W * A->nOwned;
+    FFM_TRY(tile_up_coef_cell(A, &cuCell));                         // upper coefficients, cell space
+    FFM_TRY(tile_coef(A, T->b, true, &cuB));                        // upper coefficients in the backward direction's layout
+    const long n = A->nOwned, n3 = (long)T_W * n;
+    const int g1 = std::max(1, std::min(ffm_grid(n, 256), 8 * RED_BLOCKS));
     hipLaunchKernelGGL(k_tile_gs_products, dim3(std::max(1, std::min(ffm_grid(n3, 256), 8 * RED_BLOCKS))), dim3(256), 0, s, n3,
-                       (const int *)T->b.nbrCell, cu, (const double *)psi, prod);
+                       (const int *)T->upNbrCell, cuCell, (const double *)psi, prod);
     tile_fill(A, T->mailAll, T->nMail);
     hipLaunchKernelGGL((k_tile<TM_GSF, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cl, (const double *)prod, (const double *)A->diag, bP, psi, bSave);
-    if (sym)
-        hipLaunchKernelGGL((k_tile<TM_GSB, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cu, (const double *)nullptr, (const double *)A->diag,
+    if (sym && T->mirror)
+        hipLaunchKernelGGL((k_tile<TM_GSB, false>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cuB, (const double *)nullptr, (const double *)A->diag,
                            (const double *)bSave, psi, (double *)nullptr);
+    else if (sym) {
+        // reverse sweep in position space: bSave and diag gathered to positions, psi scattered back
+        if (!T->wp) { FFM_HIP(hipMalloc((void **)&T->wp, sizeof(double) * std::max<long>(n, 1))); FFM_HIP(hipMalloc((void **)&T->rDp, sizeof(double) * std::max<long>(n, 1))); T->rDpEpoch = ~0ul; }
+        if (!T->diagp) { FFM_HIP(hipMalloc((void **)&T->diagp, sizeof(double) * std::max<long>(n, 1))); T->diagpEpoch = ~0ul; }
+        if (T->diagpEpoch != A->coeffEpoch) {
+            hipLaunchKernelGGL(k_tile_permute<true>, dim3(g1), dim3(256), 0, s, n, T->cellOf, (const double *)A->diag, T->diagp);
+            T->diagpEpoch = A->coeffEpoch;
+        }
+        double *bSp = prod;                                         // the products are consumed: reuse their first n doubles
+        hipLaunchKernelGGL(k_tile_permute<true>, dim3(g1), dim3(256), 0, s, n, T->cellOf, (const double *)bSave, bSp);
+        hipLaunchKernelGGL((k_tile<TM_GSB, false, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cuB, (const double *)nullptr, (const double *)T->diagp,
+                           (const double *)bSp, T->wp, (double *)nullptr);
+        hipLaunchKernelGGL(k_tile_permute<false>, dim3(g1), dim3(256), 0, s, n, T->cellOf, (const double *)T->wp, psi);
+    }
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
@@ -905,7 +947,7 @@ int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot)
     ffm_tile_plan *T = A->tile;
     hipStream_t s = A->ctx->stream;
     const double *bcoef;
-    FFM_TRY(tile_coef(A, T->b, true, &bcoef));
+    FFM_TRY(tile_up_coef_cell(A, &bcoef));
     AmulView v; v.G = T->G; v.grpCell = A->grpCell; v.grpEnt = T->f.grpEnt; v.rec = T->arec; v.seg = T->aseg; v.code = T->acode; v.ext = T->aext;
     const bool fusedDot = dotSlot >= 0 && T->nTail == 0 && T->nSeg <= 4 * RED_BLOCKS;
     if (fusedDot) {
