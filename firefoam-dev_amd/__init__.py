@@ -8,7 +8,7 @@ binding of the C ABI in ``include/ffm.h`` (implemented by the HIP kernels in
 fallback: every compute entry point needs libffm.so and a GPU.
 """
 from .binding import (  # noqa: F401
-    Context, lduMatrix, FfmError, lib, build, libpath, SOLVERS, PRECONDS,
+    Context, lduMatrix, FfmError, lib, build, libpath, SOLVERS, PRECONDS, tile_hint_from_centres,
     renumber_levels, exported_symbols, declared_symbols, Plume, fvMesh,
 )
 from . import hexmesh  # noqa: F401

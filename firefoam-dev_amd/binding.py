@@ -94,6 +94,7 @@ def lib():
         "ffm_ldu_ncells": ([vp], C.c_int),
         "ffm_ldu_nfaces": ([vp], C.c_int),
         "ffm_ldu_nlevels": ([vp], C.c_int),
+        "ffm_tile_hint_from_centres": ([C.c_int, hp, C.c_int, ip], C.c_int),
         "ffm_ldu_sweep_mode": ([vp], C.c_int),
         "ffm_ldu_is_native_order": ([vp], C.c_int),
         "ffm_ldu_get_cell_order": ([vp, ip], C.c_int),
@@ -193,6 +194,15 @@ def _ip(a):
 
 def _hp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def tile_hint_from_centres(C_, tileCells=0):
+    """group hint (int32[nCells]) for ffm.renumber_levels / lduMatrix from cell centres C_[3][nCells] (ffm_tile_hint_from_centres)"""
+    C_ = np.ascontiguousarray(C_, np.float64)
+    n = C_.shape[1]
+    hint = np.empty(n, np.int32)
+    _check(lib().ffm_tile_hint_from_centres(n, _hp(C_), int(tileCells), _ip(hint)), "ffm_tile_hint_from_centres")
+    return hint
 
 
 def renumber_levels(nCells, lowerAddr, upperAddr, groupHint=None):

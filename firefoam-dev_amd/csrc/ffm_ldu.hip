@@ -364,6 +364,45 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
     return FFM_OK;
 }
 
+// Group hint from cell centres, for hosts that have geometry but no structured indices (an OpenFOAM fvMesh): columns run
+// along the axis that consecutive cell labels follow most often (the fastest index of a blockMesh block), the other two
+// axes are cut into strips about `tileCells` cells wide (cell spacing estimated from the bounding box and the cell count).
+// The result is only a hint: ffm_renumber_hint / ffm_ldu_create_hint check that the label classes form an acyclic group graph
+// and fall back to the level-scheduled sweeps otherwise.
+extern "C" int ffm_tile_hint_from_centres(int nCells, const double *C /* [3][nCells] */, int tileCells, int *hint)
+{
+    if (nCells < 0 || (nCells && (!C || !hint))) return FFM_ERR_ARG;
+    if (nCells == 0) return FFM_OK;
+    if (tileCells <= 0) tileCells = tile_edge();
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; d++) { lo[d] = hi[d] = C[(size_t)d * nCells]; }
+    long votes[3] = {0, 0, 0};
+    for (int c = 0; c < nCells; c++) {
+        for (int d = 0; d < 3; d++) { const double v = C[(size_t)d * nCells + c]; lo[d] = std::min(lo[d], v); hi[d] = std::max(hi[d], v); }
+        if (c + 1 < nCells) {
+            double best = -1; int bd = 0;
+            for (int d = 0; d < 3; d++) { const double dv = std::fabs(C[(size_t)d * nCells + c + 1] - C[(size_t)d * nCells + c]); if (dv > best) { best = dv; bd = d; } }
+            votes[bd]++;
+        }
+    }
+    // the axis that changes between most consecutive labels is the column axis... unless it is the row-wrap axis: take the
+    // axis with the most votes (the fastest index changes N - N/nx times, the others far less)
+    int col = 0;
+    for (int d = 1; d < 3; d++) if (votes[d] > votes[col]) col = d;
+    const int a = (col + 1) % 3, b = (col + 2) % 3;
+    double L[3];
+    for (int d = 0; d < 3; d++) L[d] = std::max(hi[d] - lo[d], 1e-300);
+    // cells per axis from N and the aspect ratios (cell centres span L = (n-1) h): n_d ~ (N L_d^2/(L_e L_f))^(1/3)
+    auto cellsAlong = [&](int d) { const int e = (d + 1) % 3, f = (d + 2) % 3; return std::max(1.0, std::cbrt((double)nCells * L[d] * L[d] / (L[e] * L[f]))); };
+    const double ha = L[a] / std::max(cellsAlong(a) - 1.0, 1.0), hb = L[b] / std::max(cellsAlong(b) - 1.0, 1.0);
+    for (int c = 0; c < nCells; c++) {
+        const int ta = (int)std::floor((C[(size_t)a * nCells + c] - lo[a]) / (tileCells * ha) + 1e-9);
+        const int tb = (int)std::floor((C[(size_t)b * nCells + c] - lo[b]) / (tileCells * hb) + 1e-9);
+        hint[c] = std::min(ta, 32767) + 32768 * std::min(tb, 32767);
+    }
+    return FFM_OK;
+}
+
 extern "C" int ffm_renumber_levels_ext(int nOwned, int nGhost, int nFaces, const int *l, const int *u,
                                        int *newToOldCell, int *newToOldFace)
 { return ffm_renumber_hint(nOwned, nGhost, nFaces, l, u, nullptr, newToOldCell, newToOldFace); }

@@ -115,6 +115,9 @@ int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwned, int nGhost, int nFaces, const 
                         const int *upperAddr, const int *groupHint, ffm_ldu **out);
 int ffm_renumber_hint(int nOwned, int nGhost, int nFaces, const int *lowerAddr, const int *upperAddr,
                       const int *groupHint, int *newToOldCell, int *newToOldFace);
+/* a group hint from the cell centres C[3][nCells] (mesh.C()): 2-D tiles, about tileCells (0: default 16) cells wide, of
+ * columns along the axis consecutive cell labels follow; pure host code                                              */
+int ffm_tile_hint_from_centres(int nCells, const double *C, int tileCells, int *hint);
 /* neighbour q (rank nbrRank[q]) receives this rank's cells sendCells[...] (sendCount[q] of
  * them, concatenated) and fills recvCount[q] consecutive ghost cells, in neighbour order    */
 int ffm_ldu_set_ghost_exchange(ffm_ldu *ldu, int nNbr, const int *nbrRank, const int *sendCount,
