@@ -201,6 +201,8 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
 bool ffm_tile_feasible(int nOwn, int F, const int *l, const int *u);
 int ffm_tile_calc_rD(ffm_ldu *A);
 bool ffm_tile_gs_usable(const ffm_ldu *A);
+int ffm_tile_gs_ghost_terms(ffm_ldu *A, const double *psi, double *bP);
+int ffm_ghost_exchange(ffm_ldu *A, double *x);
 int ffm_tile_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSave, double *prod3);
 bool ffm_tile_amul_usable(const ffm_ldu *A);
 int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot);     // returns 1 if the dot product is left to the caller

@@ -500,6 +500,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     ffm_plume *P = new ffm_plume();
     P->ctx = ctx; P->nx = nx; P->ny = ny; P->nz = nz; P->h = h; P->dt = dt; P->rdt = 1.0 / dt;
     P->tight = getenv("FFM_PLUME_TIGHT") != nullptr;      // tests only: see ffm_plume_set_tight
+    if (const char *e = getenv("FFM_PLUME_SOLVERS")) P->stecklerSolvers = e[0] == 's';     // "steckler": see ffm_plume_set_solvers
     const long nOwn = (long)nx * ny * nz;
     // ---- ghost layers, one per coupled side, in side order -x,+x,-y,+y,-z,+z; inside a layer in natural order
     const int cnt[6] = {ny * nz, ny * nz, nx * nz, nx * nz, nx * ny, nx * ny};

@@ -467,6 +467,11 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             bUse = bP;
         }
         if (A->sweepMode == 2 && ffm_tile_gs_usable(A)) {
+            if (!A->ghNbrRank.empty()) {        // decomposed block: refresh the ghost values, move their terms into bPrime
+                FFM_TRY(ffm_ghost_exchange(A, psi));
+                if (bUse == b) { hipLaunchKernelGGL(k_copy, dim3(sgrid(N)), dim3(256), 0, s, N, bP, b); bUse = bP; }
+                FFM_TRY(ffm_tile_gs_ghost_terms(A, psi, bP));
+            }
             if (!A->gsProd) FFM_HIP(hipMalloc((void **)&A->gsProd, sizeof(double) * 3 * (size_t)std::max(A->nCells, 1)));
             FFM_TRY(ffm_tile_gs(A, sym, psi, bUse, bSave, A->gsProd));
             continue;

@@ -725,7 +725,7 @@ __global__ void k_tile_gs_products(long n3, const int *__restrict__ nbrCell, con
     }
 }
 
-bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable && A->nCells == A->nOwned; }
+bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable; }
 
 // One GaussSeidelSmoother / symGaussSeidelSmoother sweep (forward rows, then reverse rows when sym): psi in place, bP = bPrime
 // (source with the lagged interface terms), bSave = scratch [nCells].  prod = scratch [3*nCells].
@@ -919,6 +919,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
 }
 
 // faces towards ghost cells, in slot order, added to the finished owned part of the row
+template <bool SUB>
 __global__ void k_amul_tail(int n, const int *__restrict__ cell, const int *__restrict__ start, const int *__restrict__ face,
                             const int *__restrict__ nbr, const double *__restrict__ upper, const double *__restrict__ x, double *__restrict__ y)
 {
@@ -926,8 +927,20 @@ __global__ void k_amul_tail(int n, const int *__restrict__ cell, const int *__re
     if (i >= n) return;
     const int c = cell[i];
     double acc = y[c];
-    for (int q = start[i]; q < start[i + 1]; q++) acc += upper[face[q]] * x[nbr[q]];
+    for (int q = start[i]; q < start[i + 1]; q++) { const double t = upper[face[q]] * x[nbr[q]]; acc = SUB ? acc - t : acc + t; }
     y[c] = acc;
+}
+
+// Gauss-Seidel on a block with ghost cells: bPrime = source - (faces towards ghost cells)*psi_ghost, the lagged explicit
+// treatment OpenFOAM gives coupled patches (GaussSeidelSmoother: bPrime = source; updateMatrixInterfaces with negated coeffs)
+int ffm_tile_gs_ghost_terms(ffm_ldu *A, const double *psi, double *bP)
+{
+    ffm_tile_plan *T = A->tile;
+    if (T->nTail > 0)
+        hipLaunchKernelGGL(k_amul_tail<true>, dim3((T->nTail + 255) / 256), dim3(256), 0, A->ctx->stream, T->nTail, (const int *)T->tailCell,
+                           (const int *)T->tailStart, (const int *)T->tailFace, (const int *)T->tailNbr, (const double *)A->upper, psi, bP);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
 }
 
 __global__ __launch_bounds__(1024) void k_tile_sum_partials(int n, const double *__restrict__ partials, double *__restrict__ scal, int slot)
@@ -956,7 +969,7 @@ int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot)
     } else {
         hipLaunchKernelGGL((k_tile_amul<false>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, (double *)nullptr);
         if (T->nTail > 0)
-            hipLaunchKernelGGL(k_amul_tail, dim3((T->nTail + 255) / 256), dim3(256), 0, s, T->nTail, (const int *)T->tailCell, (const int *)T->tailStart,
+            hipLaunchKernelGGL(k_amul_tail<false>, dim3((T->nTail + 255) / 256), dim3(256), 0, s, T->nTail, (const int *)T->tailCell, (const int *)T->tailStart,
                                (const int *)T->tailFace, (const int *)T->tailNbr, (const double *)A->upper, x, y);
     }
     FFM_HIP(hipGetLastError());

@@ -20,12 +20,25 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # with its ghost-face tail and the mailboxes all run across tile AND rank boundaries
 @pytest.mark.parametrize("glob,grid", [((12, 16, 12), (2, 1, 1)), ((12, 16, 12), (1, 2, 2)), ((20, 36, 34), (2, 1, 1))])
 def test_decomposed_plume_matches_single_rank(ffm, ctx, glob, grid):
+    _run(ffm, ctx, glob, grid, {})
+
+
+def test_decomposed_plume_with_the_steckler_solver_selection(ffm, ctx):
+    """smoothSolver + symGaussSeidel for U, Yi, h on two ranks: the tiled Gauss-Seidel sweeps with the faces towards ghost
+    cells treated explicitly (lagged) through bPrime, as OpenFOAM treats processor patches"""
+    _run(ffm, ctx, (12, 16, 12), (2, 1, 1), {"FFM_PLUME_SOLVERS": "steckler"})
+
+
+def _run(ffm, ctx, glob, grid, extraEnv):
     world = grid[0] * grid[1] * grid[2]
     os.environ["FFM_PLUME_TIGHT"] = "1"   # every solve (hydrostatic start-up included) to 1e-13: block-Jacobi vs serial
+    os.environ.update(extraEnv)
     try:                                  # DIC then only changes the iteration path, not the converged fields
         ref = ffm.Plume(ctx, glob)
     finally:
         del os.environ["FFM_PLUME_TIGHT"]
+        for k_ in extraEnv:
+            del os.environ[k_]
     # the multi-tile case runs one step and is compared at 1e-10 (after one step the decomposed and the single-rank run differ
     # by solver-tolerance noise only, ~1e-13; from the second step on that noise flips limiter switches here and there)
     big = glob[0] * glob[1] * glob[2] > 10000
@@ -37,7 +50,7 @@ def test_decomposed_plume_matches_single_rank(ffm, ctx, glob, grid):
     with tempfile.TemporaryDirectory() as tmp:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "plume_rank.py"), str(r), str(world), str(port),
                                    *map(str, glob), *map(str, grid), str(nSteps), tmp],
-                                  env=dict(os.environ, FFM_PLUME_TIGHT="1")) for r in range(world)]
+                                  env=dict(os.environ, FFM_PLUME_TIGHT="1", **extraEnv)) for r in range(world)]
         rcs = [p.wait(timeout=300) for p in procs]
         assert rcs == [0] * world
         parts = [np.load(os.path.join(tmp, "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
