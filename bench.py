@@ -63,10 +63,24 @@ def main():
         grid = (1, 1, 1)
     else:
         # strong scaling: the same global box, block-decomposed (2x1x1, 2x2x1, 2x2x2), one block per rank
-        if args.transport == "rccl":
+        transport = args.transport
+        if transport == "rccl":
             ids = [ffm.Context.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            ctx.comm_init_rccl(rank, world, ids[0])
+            ok = 1
+            try:
+                ctx.comm_init_rccl(rank, world, ids[0])
+            except Exception as e:                       # keep the run alive: every rank falls back to the host transport
+                ok = 0
+                sys.stderr.write("bench.py: rank %d: RCCL communicator failed (%s)\n" % (rank, e))
+            t = torch.tensor([ok], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                transport = "host"
+                sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
+                import gloo_comm
+                gloo_comm.GROUP = dist.new_group(backend="gloo")
+                ctx.comm_init_host(rank, world, gloo_comm.allreduce, gloo_comm.exchange)
         else:
             sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
             import gloo_comm
@@ -95,7 +109,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda" if args.transport == "rccl" else "cpu")
+        t = torch.tensor([dt], device="cuda" if args.transport == "rccl" else "cpu")      # (the default group: nccl or gloo)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     solves = case.solves()
@@ -152,7 +166,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic %d^3 hex box (%d cells), buoyant plume + 5-species EDC-shaped source, "
                                    "PIMPLE 1/2/0: rhoEqn + UEqn + YEEqn(4 Yi + h) + 2 pEqn per step" % (n, N),
-                       "cells": N, "faces": F, "deltaT": 1e-3, "parallelism": "1 GPU" if world == 1 else "%dx%dx%d block decomposition, one block per GPU, RCCL halo + all-reduce" % grid,
+                       "cells": N, "faces": F, "deltaT": 1e-3, "parallelism": "1 GPU" if world == 1 else ("%dx%dx%d block decomposition, one block per GPU, " % grid)
+                                      + ("RCCL halo + all-reduce" if transport == "rccl" else "halo + all-reduce through the host (gloo)"),
                        "p_rgh_iterations_last_step": pIters, "setup_s": round(setup_s, 1),
                        "transport_solvers": "PBiCGStab+DILU" if args.solvers == "krylov" else "smoothSolver+symGaussSeidel maxIter 10"},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -5,13 +5,16 @@ import torch
 import torch.distributed as dist
 
 
+GROUP = None        # process group to use (None: the default group); bench.py sets a gloo group here when it falls back from RCCL
+
+
 def init(rank, world, port):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
 
 
 def allreduce(vals, op=0):
     t = torch.from_numpy(np.array(vals, dtype=np.float64, copy=True))
-    dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[op])
+    dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[op], group=GROUP)
     vals[:] = t.numpy()
 
 
@@ -24,7 +27,7 @@ def exchange(sizes, ranks, offs, send, recv):
             continue
         ts = torch.from_numpy(np.ascontiguousarray(send[o:o + n]).copy())
         tr = torch.empty(n, dtype=torch.float64)
-        reqs.append(dist.isend(ts, r)); reqs.append(dist.irecv(tr, r))
+        reqs.append(dist.isend(ts, r, group=GROUP)); reqs.append(dist.irecv(tr, r, group=GROUP))
         bufs.append((o, n, tr, ts))
     for q in reqs:
         q.wait()
