@@ -24,14 +24,17 @@ from . import fv, oracle as O
 RR = 6.0221417930e26 * 1.38065e-23      # OpenFOAM-dev etc/controlDict SI constants: NA*k = 8314.47 J/(kmol K)
 
 
-def build_mesh(door_k=(7, 12)):
-    n = (30, 15, 20)
+def build_mesh(door_k=(7, 12), refine=1):
+    """refine = r: every cell of the 30 x 15 x 20 base mesh split r x r x r (the `refineMesh` step of the reference's larger
+    runs; BASELINE config 2 = r 4 = 576 000 cells); room, baffles and doorway keep their place."""
+    r = int(refine)
+    n = (30 * r, 15 * r, 20 * r)
     base = fv.HexMesh(n, (-2, 0, -2), (4, 3, 2))
     i, j, k = base.ijk
-    inside = (i >= 3) & (i <= 16) & (j <= 10) & (k >= 3) & (k <= 16)
+    inside = (i >= 3 * r) & (i <= 17 * r - 1) & (j <= 11 * r - 1) & (k >= 3 * r) & (k <= 17 * r - 1)
     l, u, fd = base.l, base.u, base.fdir
     baffle = inside[l] != inside[u]
-    door = (fd == 0) & (i[l] == 16) & (j[l] <= 4) & (k[l] >= door_k[0]) & (k[l] <= door_k[1]) & baffle
+    door = (fd == 0) & (i[l] == 17 * r - 1) & (j[l] <= 5 * r - 1) & (k[l] >= door_k[0] * r) & (k[l] <= (door_k[1] + 1) * r - 1) & baffle
     m = fv.HexMesh(n, (-2, 0, -2), (4, 3, 2), baffle=baffle & ~door, baffle_name="baffle1DWall")
     m.set_patches([("top", ["ymax"]), ("sides", ["zmax", "zmin", "xmax", "xmin"]), ("base", ["ymin"]),
                    ("baffle1DWall_master", ["baffle1DWall_master"]), ("baffle1DWall_slave", ["baffle1DWall_slave"])])
