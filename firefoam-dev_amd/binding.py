@@ -155,6 +155,7 @@ def lib():
         "ffm_plume_step": ([vp], C.c_int),
         "ffm_plume_set_tight": ([vp, C.c_int], C.c_int),
         "ffm_plume_set_solvers": ([vp, C.c_int], C.c_int),
+        "ffm_plume_set_radiation": ([vp, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
         "ffm_plume_ncells": ([vp], C.c_int),
         "ffm_plume_nfaces": ([vp], C.c_int),
         "ffm_plume_get_field": ([vp, C.c_char_p, hp], C.c_int),
@@ -491,6 +492,18 @@ class Plume:
     def set_solvers(self, steckler=True):
         """transport equations with smoothSolver + symGaussSeidel (maxIter 10) as cases/steckler/system/fvSolution:49-62"""
         _check(lib().ffm_plume_set_solvers(self.h, 1 if steckler else 0), "ffm_plume_set_solvers")
+
+    def set_radiation(self, solverFreq=100, nPhi=2, nTheta=4, rays=None):
+        """fvDOM stand-in: 4*nPhi*nTheta upwind ray solves every solverFreq steps; rays = [(dAve[3], omega)] or None"""
+        if rays is None:
+            _check(lib().ffm_plume_set_radiation(self.h, solverFreq, nPhi, nTheta, None, None), "ffm_plume_set_radiation")
+            return
+        import numpy as np
+        d = np.ascontiguousarray(np.concatenate([np.asarray(r[0], dtype=np.float64) for r in rays]))
+        o = np.ascontiguousarray(np.array([r[1] for r in rays], dtype=np.float64))
+        if len(o) != 4 * nPhi * nTheta:
+            raise ValueError("rays must hold 4*nPhi*nTheta entries")
+        _check(lib().ffm_plume_set_radiation(self.h, solverFreq, nPhi, nTheta, d.ctypes.data, o.ctypes.data), "ffm_plume_set_radiation")
 
     def set_tight(self, on=True):
         _check(lib().ffm_plume_set_tight(self.h, 1 if on else 0), "ffm_plume_set_tight")

@@ -84,6 +84,10 @@ struct ffm_plume {
     double *Udiag, *Uupper, *Ulower, *Usrc[3], *Uic[3], *Ubc[3];
     std::vector<SolveLog> log;
     bool tight = false;                    // tests: every solve to 1e-13 / relTol 0 (removes the stopping-rule noise)
+    // fvDOM stand-in: off unless ffm_plume_set_radiation() was called
+    int stepNo = 0, radFreq = 0;
+    std::vector<double> rayD, rayOmega;    // dAve[3] and omega per ray
+    std::vector<double *> I; double *G = nullptr, *radJ = nullptr, *radW = nullptr, *radJb = nullptr, *radF = nullptr, *radRef = nullptr, *radSrc = nullptr;
     bool stecklerSolvers = false;          // transport equations with smoothSolver + symGaussSeidel, maxIter 10
                                            // (cases/steckler/system/fvSolution:49-62) instead of PBiCGStab + DILU
 };
@@ -137,14 +141,14 @@ static void bc_update_f(ffm_plume *P, double *f, const double *fStatic)
 { const double *pb = P->phib; forN(P, P->B, [=] __device__(long k) { f[k] = fStatic[k] < 0 ? 1.0 - (pb[k] >= 0 ? 1.0 : 0.0) : fStatic[k]; }); }
 
 static int solve_named(ffm_plume *P, const char *name, int solver, int pre, double tol, double relTol, const double *d,
-                       const double *up, const double *lo, double *psi, const double *src, bool sameOffDiag = false)
+                       const double *up, const double *lo, double *psi, const double *src, bool sameOffDiag = false, bool keepSolver = false)
 {
     // zero-copy: the driver's coefficient arrays stay untouched until the solve has returned
     FFM_TRY(ffm_ldu_bind_coeffs_native_d(P->A, d, up, lo, sameOffDiag ? 1 : 0));
     SolveLog L; memset(&L, 0, sizeof(L)); strncpy(L.name, name, sizeof(L.name) - 1);
     if (P->tight) { tol = 1e-13; relTol = 0.0; }
     int maxIter = 1000;
-    if (P->stecklerSolvers && solver == FFM_PBICGSTAB) { solver = FFM_SMOOTH; pre = FFM_SYMGS; maxIter = P->tight ? 1000 : 10; }
+    if (P->stecklerSolvers && solver == FFM_PBICGSTAB && !keepSolver) { solver = FFM_SMOOTH; pre = FFM_SYMGS; maxIter = P->tight ? 1000 : 10; }
     FFM_TRY(ffm_solve_d(P->A, solver, pre, tol, relTol, 0, maxIter, 1, psi, src, &L.perf));
     P->log.push_back(L);
     return FFM_OK;
@@ -249,6 +253,46 @@ static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *
     FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, s2, nullptr, P->dWork, P->sWork));
     FFM_TRY(solve_named(P, name, FFM_PBICGSTAB, FFM_DILU, tol, 0.0, P->dWork, P->upper, P->lower, vf, P->sWork));
     return HX(P, vf);
+}
+
+// ---- fvDOM stand-in: radiation->correct() of solver/YEEqn.H:80 -------------------------------------------------------
+// per ray i (direction dAve_i, solid angle omega_i; fvDOM.C:55-90, radiativeIntensityRay.C:126-143):
+//   fvm::div(Ji, Ii) + fvm::Sp(k*omega, Ii) == 1/pi*omega*(k*sigma*T^4),  Ji = dAve & Sf, div scheme upwind
+// (radiativeIntensityRay.C:267-322), inflow faces at the ambient black-body intensity, outflow zero-gradient; then
+// G = sum Ii*omega (fvDOM::updateG).  Constant k, no scattering, no coupling back into the enthalpy equation.
+constexpr double SIGMA_SB = 5.670367e-8, K_ABS = 0.1;
+static int radiation_correct(ffm_plume *P)
+{
+    ffm_mesh *m = P->mesh; const int N = P->N, B = P->B; const long nNat = P->nNat;
+    const double *V = ffm_mesh_geom(m, 0);
+    const double *sx = ffm_mesh_geom(m, 9), *sy = ffm_mesh_geom(m, 10), *sz = ffm_mesh_geom(m, 11);
+    const double *bx = ffm_mesh_geom(m, 6), *by = ffm_mesh_geom(m, 7), *bz = ffm_mesh_geom(m, 8);
+    const double Ib = SIGMA_SB * ((TREF * TREF) * (TREF * TREF)) / M_PI;
+    double *G = P->G, *J = P->radJ, *w = P->radW, *Jb = P->radJb, *f = P->radF, *ref = P->radRef, *su = P->radSrc;
+    const double *T = P->T;
+    forN(P, N, [=] __device__(long c) { G[c] = 0.0; });
+    forN(P, B, [=] __device__(long k) { ref[k] = Ib; });
+    const int nRay = (int)P->rayOmega.size();
+    for (int i = 0; i < nRay; i++) {
+        const double d0 = P->rayD[3 * i], d1 = P->rayD[3 * i + 1], d2 = P->rayD[3 * i + 2], omega = P->rayOmega[i];
+        forN(P, nNat, [=] __device__(long e) { const double j = (d0 * sx[e] + d1 * sy[e]) + d2 * sz[e]; J[e] = j; w[e] = j >= 0 ? 1.0 : 0.0; });
+        forN(P, B, [=] __device__(long k) { const double j = (d0 * bx[k] + d1 * by[k]) + d2 * bz[k]; Jb[k] = j; f[k] = 1.0 - (j >= 0 ? 1.0 : 0.0); });
+        FFM_TRY(ffm_fvm_transport(m, 0.0, nullptr, J, w, nullptr, -1, P->diag, P->upper, P->lower));
+        FFM_TRY(ffm_fvm_boundary_coeffs(m, Jb, nullptr, -1, f, ref, P->zeroB, P->ic[0], P->bc[0]));
+        double *dg = P->diag; const double kO = K_ABS * omega, cS = 1.0 / M_PI * omega, kS = K_ABS * SIGMA_SB;
+        forN(P, N, [=] __device__(long c) {
+            dg[c] = dg[c] + V[c] * kO;
+            const double t = T[c];
+            su[c] = V[c] * (cS * (kS * ((t * t) * (t * t))));
+        });
+        FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, su, nullptr, P->dWork, P->sWork));
+        char nm[16]; snprintf(nm, sizeof(nm), "I%d", i);
+        FFM_TRY(solve_named(P, nm, FFM_PBICGSTAB, FFM_DILU, 1e-4, 0.0, P->dWork, P->upper, P->lower, P->I[i], P->sWork, false, true));
+        FFM_TRY(HX(P, P->I[i]));
+        const double *Ii = P->I[i];
+        forN(P, N, [=] __device__(long c) { G[c] = G[c] + Ii[c] * omega; });
+    }
+    return FFM_OK;
 }
 
 static int p_corrector(ffm_plume *P, bool final)
@@ -446,6 +490,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         double *Yn = P->Y[INERT];
         forN(P, N, [=] __device__(long c) { Yn[c] = fmax(1.0 - Yt[c], 0.0); });
     }
+    if (P->radFreq > 0 && P->stepNo % P->radFreq == 0) FFM_TRY(radiation_correct(P));       // radiation->correct(), solver/YEEqn.H:80
     // EEqn: explicit LHS terms fvc::ddt(rho,K) + fvc::div(phi,K) - dpdt
     {
         FFM_TRY(U_boundary(P, Ub));     // U.correctBoundaryConditions() after the momentum solve
@@ -473,7 +518,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
     { const char *st = getenv("FFM_PLUME_STOP"); if (st && atoi(st) == 3) { PL_HIP(hipStreamSynchronize(P->ctx->stream)); return FFM_OK; } }
     FFM_TRY(p_corrector(P, true));
     mul(P, P->rho, P->psi, P->p, N);
-    P->time += P->dt;
+    P->time += P->dt; P->stepNo++;
     PL_HIP(hipStreamSynchronize(P->ctx->stream));
     return FFM_OK;
 }
@@ -667,6 +712,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     mul(P, P->rho, P->psi, P->p, N);
     FFM_TRY(hydrostatic_init(P));
     PL_HIP(hipStreamSynchronize(ctx->stream));
+    if (const char *e = getenv("FFM_PLUME_RADIATION")) { if (atoi(e) > 0) FFM_TRY(ffm_plume_set_radiation(P, atoi(e), 2, 4, nullptr, nullptr)); }   // solverFreq
     *out = P;
     return FFM_OK;
 }
@@ -682,6 +728,37 @@ extern "C" int ffm_plume_destroy(ffm_plume *P)
 }
 
 extern "C" int ffm_plume_set_tight(ffm_plume *P, int on) { if (!P) return FFM_ERR_ARG; P->tight = on != 0; return FFM_OK; }
+// Switch the fvDOM stand-in on: every `solverFreq` steps (cases/steckler/constant/radiationProperties:32-40: solverFreq 100,
+// nPhi 2, nTheta 4 -> 32 rays) the step solves one upwind transport equation per ray before the enthalpy equation.
+// dAve[3*nRay] / omega[nRay] may be given by the caller (the shim passes fvDOM's own); null -> built here from nPhi, nTheta.
+extern "C" int ffm_plume_set_radiation(ffm_plume *P, int solverFreq, int nPhi, int nTheta, const double *dAve, const double *omega)
+{
+    if (!P || solverFreq < 0 || nPhi < 1 || nTheta < 1 || ((dAve == nullptr) != (omega == nullptr))) return FFM_ERR_ARG;
+    PL_HIP(hipSetDevice(P->ctx->device));
+    const int nRay = 4 * nPhi * nTheta;
+    P->rayD.assign(3 * (size_t)nRay, 0.0); P->rayOmega.assign(nRay, 0.0);
+    if (dAve) { std::copy(dAve, dAve + 3 * nRay, P->rayD.begin()); std::copy(omega, omega + nRay, P->rayOmega.begin()); }
+    else {
+        const double dPhi = M_PI / (2.0 * nPhi), dTheta = M_PI / nTheta; int i = 0;
+        for (int n = 1; n <= nTheta; n++) for (int mm = 1; mm <= 4 * nPhi; mm++, i++) {
+            const double theta = (2.0 * n - 1.0) * dTheta / 2.0, phi = (2.0 * mm - 1.0) * dPhi / 2.0;
+            const double a = sin(0.5 * dPhi) * (dTheta - cos(2.0 * theta) * sin(dTheta));
+            P->rayOmega[i] = 2.0 * sin(theta) * sin(dTheta / 2.0) * dPhi;
+            P->rayD[3 * i] = sin(phi) * a; P->rayD[3 * i + 1] = cos(phi) * a; P->rayD[3 * i + 2] = 0.5 * dPhi * sin(2.0 * theta) * sin(dTheta);
+        }
+    }
+    if ((int)P->I.size() < nRay) {
+        for (int i = (int)P->I.size(); i < nRay; i++) { double *p = dalloc(P, P->N); if (!p) return FFM_ERR_HIP; P->I.push_back(p); }
+    }
+    if (!P->G) {
+        P->G = dalloc(P, P->N); P->radSrc = dalloc(P, P->N); P->radJ = dalloc(P, P->nNat); P->radW = dalloc(P, P->nNat);
+        P->radJb = dalloc(P, P->B); P->radF = dalloc(P, P->B); P->radRef = dalloc(P, P->B);
+        if (!P->G || !P->radSrc || !P->radJ || !P->radW || !P->radJb || !P->radF || !P->radRef) return FFM_ERR_HIP;
+    }
+    P->radFreq = solverFreq;
+    return FFM_OK;
+}
+
 extern "C" int ffm_plume_set_solvers(ffm_plume *P, int stecklerSelection) { if (!P) return FFM_ERR_ARG; P->stecklerSolvers = stecklerSelection != 0; return FFM_OK; }
 extern "C" int ffm_plume_ncells(const ffm_plume *P) { return P ? P->nOwn : FFM_ERR_ARG; }
 extern "C" int ffm_plume_nfaces(const ffm_plume *P) { return P ? P->F : FFM_ERR_ARG; }
@@ -695,6 +772,8 @@ extern "C" int ffm_plume_get_field(ffm_plume *P, const char *name, double *out)
     if (n == "rho") src = P->rho; else if (n == "p") src = P->p; else if (n == "p_rgh") src = P->p_rgh; else if (n == "T") src = P->T;
     else if (n == "h") src = P->hs; else if (n == "K") src = P->K; else if (n == "Ux") src = P->U[0]; else if (n == "Uy") src = P->U[1];
     else if (n == "Uz") src = P->U[2]; else if (n == "psi") src = P->psi; else if (n == "ph_rgh") src = P->ph_rgh;
+    else if (n == "G") src = P->G;
+    else if (n.size() > 1 && n[0] == 'I' && isdigit((unsigned char)n[1])) { const int i = atoi(n.c_str() + 1); if (i < (int)P->I.size()) src = P->I[i]; }
     else for (int i = 0; i < NSP; i++) if (n == SPN[i]) src = P->Y[i];
     if (!src) { ffm_set_error("unknown field %s", name); return FFM_ERR_ARG; }
     std::vector<double> v(P->N);

@@ -308,6 +308,11 @@ int ffm_plume_set_tight(ffm_plume *p, int on);
 /* linear solvers of the transport equations (U, Yi, h): 0 = PBiCGStab + DILU (default, the kernels BASELINE names),
  * 1 = smoothSolver + symGaussSeidel with maxIter 10, the selection of cases/steckler/system/fvSolution:49-62 */
 int ffm_plume_set_solvers(ffm_plume *plume, int stecklerSelection);
+/* SURVEY 8(f) N1 stand-in: the reference's radiation->correct() (solver/YEEqn.H:80; fvDOM with nPhi 2, nTheta 4, solverFreq 100,
+ * cases/steckler/constant/radiationProperties:32-40) as 4*nPhi*nTheta upwind ray-transport solves every `solverFreq` steps
+ * (0 = off, the default).  dAve[3*nRay], omega[nRay]: the rays' mean directions and solid angles as fvDOM.C:55-90 builds
+ * them, or both NULL to have them built from nPhi, nTheta.  Fields "G" and "I<n>" become readable with ffm_plume_get_field. */
+int ffm_plume_set_radiation(ffm_plume *plume, int solverFreq, int nPhi, int nTheta, const double *dAve, const double *omega);
 int ffm_plume_ncells(const ffm_plume *p);
 int ffm_plume_nfaces(const ffm_plume *p);
 int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);

@@ -67,6 +67,7 @@ class Solvers:
         "U": dict(solver="PBICGSTAB", pre="DILU", tolerance=1e-6, relTol=0.0),
         "Yi": dict(solver="PBICGSTAB", pre="DILU", tolerance=1e-8, relTol=0.0),
         "h": dict(solver="PBICGSTAB", pre="DILU", tolerance=1e-8, relTol=0.0),
+        "Ii": dict(solver="PBICGSTAB", pre="DILU", tolerance=1e-4, relTol=0.0),      # reference: GAMG + DILU smoother, 1e-4
     }
 
     def __init__(self):
@@ -87,6 +88,30 @@ class StecklerSolvers(Solvers):
                     U=dict(solver="SMOOTH", pre="SYMGS", tolerance=1e-6, relTol=0.0, maxIter=10),
                     Yi=dict(solver="SMOOTH", pre="SYMGS", tolerance=1e-8, relTol=0.0, maxIter=10),
                     h=dict(solver="SMOOTH", pre="SYMGS", tolerance=1e-8, relTol=0.0, maxIter=10))
+
+
+# ---- fvDOM stand-in: the ray set and the per-ray transport equation of the reference's
+# packages/thermophysicalModels/radiation/radiationModels/fvDOM (fvDOM/fvDOM.C:55-90, radiativeIntensityRay/
+# radiativeIntensityRay.C:126-143,267-322), with a constant absorption coefficient, no scattering, no emission term E
+# and the intensity decoupled from the enthalpy equation (radiation->Sh = 0).
+SIGMA_SB = 5.670367e-8
+K_ABS = 0.1                                                   # 1/m
+
+
+def ray_set(nPhi=2, nTheta=4):
+    """(dAve, omega) of the 4*nPhi*nTheta rays, theta outer / phi inner as fvDOM.C builds them."""
+    dPhi, dTheta = np.pi / (2.0 * nPhi), np.pi / nTheta
+    rays = []
+    for n in range(1, nTheta + 1):
+        theta = (2.0 * n - 1.0) * dTheta / 2.0
+        for mm in range(1, 4 * nPhi + 1):
+            phi = (2.0 * mm - 1.0) * dPhi / 2.0
+            omega = 2.0 * np.sin(theta) * np.sin(dTheta / 2.0) * dPhi
+            dAve = np.array([np.sin(phi) * np.sin(0.5 * dPhi) * (dTheta - np.cos(2.0 * theta) * np.sin(dTheta)),
+                             np.cos(phi) * np.sin(0.5 * dPhi) * (dTheta - np.cos(2.0 * theta) * np.sin(dTheta)),
+                             0.5 * dPhi * np.sin(2.0 * theta) * np.sin(dTheta)])
+            rays.append((dAve, omega))
+    return rays
 
 
 class Plume:
@@ -111,8 +136,16 @@ class Plume:
         self.K = np.zeros(N); self.dpdt = np.zeros(N)
         self.hydrostatic_init()
         self.time = 0.0
+        self.stepNo, self.radFreq = 0, 0                      # set_radiation() switches the fvDOM stand-in on
+        self.rays, self.I, self.G = [], [], np.zeros(N)
 
     # ---- thermo stand-in -------------------------------------------------------------------
+    def set_radiation(self, solverFreq=100, nPhi=2, nTheta=4):
+        """cases/steckler/constant/radiationProperties:32-40: nPhi 2, nTheta 4 (32 rays), solverFreq 100"""
+        self.radFreq = solverFreq
+        self.rays = ray_set(nPhi, nTheta)
+        self.I = [np.zeros(self.m.nCells) for _ in self.rays]
+
     def calc_psi(self):
         return 1.0 / (RR * self.T * (self.Y / WMOL[:, None]).sum(axis=0))
 
@@ -251,6 +284,8 @@ class Plume:
             self.Y[i] = np.maximum(self.sol.solve("Yi", SPECIES[i], m, d, E.upper, E.lower, s, self.Y[i]), 0.0)
             Yt += self.Y[i]
         self.Y[INERT] = np.maximum(1.0 - Yt, 0.0)
+        if self.radFreq > 0 and self.stepNo % self.radFreq == 0:          # radiation->correct(), solver/YEEqn.H:80
+            self.radiation_correct()
         bch = self.bc_scalar(CP * (T_IN - TREF), 0.0, floor_fixed=0.0)
         hb = bch.values(m, self.h)
         wh = fv.limited_weights(m, "limitedLinear", self.phi, self.h, fv.grad(m, self.h, hb), 1.0)
@@ -275,6 +310,26 @@ class Plume:
             self.p_corrector(UEqn, final=(corr == 1))
         self.rho = self.psi * self.p
         self.time += self.dt
+        self.stepNo += 1
+
+    def radiation_correct(self):
+        """One fvDOM sweep: per ray  fvm::div(Ji, Ii) + fvm::Sp(k*omega, Ii) == 1/pi*omega*(k*sigma*T^4), div scheme upwind
+        (cases/steckler/system/fvSchemes:60), inflow faces fixed to the ambient black-body intensity, outflow zeroGradient
+        (stand-in for greyDiffusiveRadiation); then G = sum_i Ii*omega_i (fvDOM::updateG)."""
+        m = self.m
+        Ib = SIGMA_SB * ((TREF * TREF) * (TREF * TREF)) / np.pi
+        T4 = (self.T * self.T) * (self.T * self.T)
+        self.G = np.zeros(m.nCells)
+        for i, (dAve, omega) in enumerate(self.rays):
+            Ji = (dAve[0] * m.Sf[:, 0] + dAve[1] * m.Sf[:, 1]) + dAve[2] * m.Sf[:, 2]
+            Jib = [(dAve[0] * p.Sf[:, 0] + dAve[1] * p.Sf[:, 1]) + dAve[2] * p.Sf[:, 2] for p in m.patches]
+            bc = fv.MixedBC(m, f=[1.0 - fv.pos0(jb) for jb in Jib], ref=[np.full(p.size, Ib) for p in m.patches])
+            E = fv.fvm_div(m, Ji, Jib, fv.pos0(Ji), [bc])
+            E.diag += m.V * (K_ABS * omega)                              # fvm::Sp(k*omega, Ii)
+            E.add_su(1.0 / np.pi * omega * (K_ABS * SIGMA_SB * T4))
+            d, s = E.solve_system()
+            self.I[i] = self.sol.solve("Ii", "I%d" % i, m, d, E.upper, E.lower, s, self.I[i])
+            self.G = self.G + self.I[i] * omega
 
     def p_corrector(self, UEqn, final):
         m, rdt = self.m, self.rDeltaT

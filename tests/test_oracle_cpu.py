@@ -150,3 +150,17 @@ def test_multi_domain_matches_serial(O, ffm, grid):
     for b, p in zip(blocks, psis):
         full[b.gcell] = p
     assert rel_l2(full, psiS) < 1e-10
+
+
+def test_fvdom_ray_set_properties(O):
+    """the 32-ray set of the fvDOM stand-in (fvDOM.C:55-90, radiativeIntensityRay.C:126-143): solid angles tile the sphere, the
+    mean directions cancel, and an isothermal box at the ambient temperature is in radiative equilibrium (G = 4 sigma T^4)."""
+    from oracle import plume
+    rays = plume.ray_set(2, 4)
+    assert len(rays) == 32
+    assert abs(sum(o for _, o in rays) - 4 * np.pi) < 1e-13
+    assert np.abs(sum(d for d, _ in rays)).max() < 1e-14
+    P = plume.Plume((6, 8, 6)); P.set_radiation(solverFreq=1)
+    P.T[:] = plume.TREF
+    P.radiation_correct()
+    assert np.abs(P.G / (4 * plume.SIGMA_SB * plume.TREF ** 4) - 1).max() < 1e-4       # solves stop at 1e-4

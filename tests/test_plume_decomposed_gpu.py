@@ -29,7 +29,12 @@ def test_decomposed_plume_with_the_steckler_solver_selection(ffm, ctx):
     _run(ffm, ctx, (12, 16, 12), (2, 1, 1), {"FFM_PLUME_SOLVERS": "steckler"})
 
 
-def _run(ffm, ctx, glob, grid, extraEnv):
+def test_decomposed_plume_with_the_fvdom_ray_sweep(ffm, ctx):
+    """the 32 upwind ray solves (SURVEY 8f N1 stand-in) on 2 x 2 ranks: every ray crosses rank boundaries in its own direction"""
+    _run(ffm, ctx, (12, 16, 12), (2, 1, 2), {"FFM_PLUME_RADIATION": "1"}, extraFields=["G", "I0", "I13", "I31"])
+
+
+def _run(ffm, ctx, glob, grid, extraEnv, extraFields=()):
     world = grid[0] * grid[1] * grid[2]
     os.environ["FFM_PLUME_TIGHT"] = "1"   # every solve (hydrostatic start-up included) to 1e-13: block-Jacobi vs serial
     os.environ.update(extraEnv)
@@ -55,7 +60,7 @@ def _run(ffm, ctx, glob, grid, extraEnv):
         assert rcs == [0] * world
         parts = [np.load(os.path.join(tmp, "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
     nx, ny, nz = glob
-    for name in ["rho", "p", "T", "Ux", "Uy", "Uz", "O2", "C3H8", "CO2", "ph_rgh", "p_rgh"]:
+    for name in ["rho", "p", "T", "Ux", "Uy", "Uz", "O2", "C3H8", "CO2", "ph_rgh", "p_rgh", *extraFields]:
         full = np.empty((nz, ny, nx))
         for pt in parts:
             lo, hi = pt["lo"], pt["hi"]

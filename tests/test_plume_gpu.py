@@ -62,3 +62,31 @@ def test_plume_with_the_steckler_solver_selection(O, ffm, ctx):
             else:
                 assert rel_l2(a, b) < 1e-8, (step, name, rel_l2(a, b))
     gpu.close()
+
+
+def test_plume_with_the_fvdom_ray_sweep(O, ffm, ctx):
+    """SURVEY 8(f) N1 stand-in: radiation->correct() (solver/YEEqn.H:80) as 32 upwind ray-transport solves (nPhi 2, nTheta 4,
+    cases/steckler/constant/radiationProperties:32-40) before the enthalpy equation; here every step instead of every 100th.
+    Each ray's intensity and the incident radiation G against the oracle's, same ray set, plus the usual fields."""
+    from oracle import plume
+    n = (12, 16, 12)
+    ref = plume.Plume(n); ref.set_radiation(solverFreq=1)
+    gpu = ffm.Plume(ctx, n); gpu.set_radiation(solverFreq=1, rays=ref.rays)
+    for step in range(2):
+        ref.step(); gpu.step()
+        it_ref = [(nme, pf["nIterations"]) for nme, pf in ref.sol.log]
+        it_gpu = [(nme, pf["nIterations"]) for nme, pf in gpu.solves()]
+        assert it_ref == it_gpu, (step, it_ref, it_gpu)
+        assert sum(1 for nme, _ in it_gpu if nme.startswith("I")) == 32
+        for i in range(32):
+            assert rel_l2(gpu.field("I%d" % i), ref.I[i]) < 1e-12, (step, i)
+        assert rel_l2(gpu.field("G"), ref.G) < 1e-12
+        f = ref.fields()
+        for name in FIELDS:
+            a, b = gpu.field(name), f[name]
+            if np.linalg.norm(b) > 1e-30:
+                assert rel_l2(a, b) < 1e-8, (step, name, rel_l2(a, b))
+    # the library's own ray set (libm) agrees with the oracle's (numpy) to rounding
+    own = ffm.Plume(ctx, n); own.set_radiation(solverFreq=1); own.step()
+    assert rel_l2(own.field("G"), gpu.field("G")) < 1e-3          # one step vs two: the flame has barely moved
+    gpu.close(); own.close()

@@ -25,6 +25,9 @@ iters = []
 for _ in range(nSteps):
     case.step()
     iters.append([(n, p["nIterations"]) for n, p in case.solves()])
-out = {name: case.field(name) for name in ["rho", "p", "p_rgh", "T", "Ux", "Uy", "Uz", "O2", "C3H8", "CO2", "ph_rgh"]}
+names = ["rho", "p", "p_rgh", "T", "Ux", "Uy", "Uz", "O2", "C3H8", "CO2", "ph_rgh"]
+if os.environ.get("FFM_PLUME_RADIATION"):
+    names += ["G", "I0", "I13", "I31"]
+out = {name: case.field(name) for name in names}
 np.savez(os.path.join(outdir, "rank%d.npz" % rank), lo=np.array(lo), hi=np.array(hi), iters=np.array(iters, dtype=object), **out)
 case.close(); ctx.close()
