@@ -42,7 +42,11 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
     mesh.solvers["rho"] = {FFM_DIAGONAL, FFM_NONE, 1e-6, 0, 0, 1000, 1};
     mesh.solvers["Yi"] = {FFM_PBICGSTAB, FFM_DILU, 1e-10, 0, 0, 1000, 1};
     mesh.solvers["U"] = {FFM_PBICGSTAB, FFM_DILU, 1e-10, 0, 0, 1000, 1};
-    mesh.solvers["p_rgh"] = {FFM_PCG, FFM_DIC, 1e-10, 0, 0, 1000, 1};
+    mesh.solvers["p_rgh"] = {FFM_PCG, FFM_DIC, 1e-6, 0.01, 0, 1000, 1};
+    mesh.solvers["p_rghFinal"] = {FFM_PCG, FFM_DIC, 1e-10, 0, 0, 1000, 1};      // cf. fvSolution:36-41: relTol 0 on the final corrector
+    mesh.solvers["UFinal"] = mesh.solvers["U"];                                  // "(U|Yi|h|k)Final", fvSolution:57-62
+    pimpleDict pd; pd.nOuterCorrectors = 1; pd.nCorrectors = 1; pd.nNonOrthogonalCorrectors = 0;
+    pimpleControl pimple(mesh, pd);
     mesh.divSchemes["div(phi,U)"] = {4, 1, 0, 1};               // Gauss LUST grad(U)
     mesh.divSchemes["div(phi,Yi_h)"] = {3, 1, 0, 1};            // Gauss limitedLinear01 1 (multivariateSelection entry)
     mesh.equationRelaxation["Yi"] = alphaY;
@@ -61,6 +65,8 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
     }
     rho.v.toHost(rhoOut);
 
+    // ---- PIMPLE loop (solver/fireFoam.C:102-119); the fields below outlive it only because the demo hands them back
+    if (!pimple.loop()) FatalError("pimple.loop()");
     // ---- YEEqn.H, one specie
     volScalarField Yi("Yi", mesh); Yi.v.assignHost(Yi0); Yi.bc = makeBC(mesh, bcY[0], bcY[1], bcY[2]);
     Yi.correctBoundaryConditions(); Yi.storeOldTime();
@@ -103,6 +109,7 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
       - fvm::laplacian(mu, U)
     );
     UEqn.relax();
+    if (pimple.momentumPredictor())
     solve
     (
         UEqn
@@ -119,7 +126,8 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
     for (int d = 0; d < 3; d++) U.v[d].toHost(UOut + (size_t)d*N);
     K.v.toHost(KOut);
 
-    // ---- pEqn.H (one corrector)
+    // ---- pEqn.H (nCorrectors 1)
+    while (pimple.correct())
     {
         U.fixesValue = std::make_shared<dField>(mesh.ctx, mesh.nBoundary); U.fixesValue->assignHost(UfixedB);
         dField fluxMask(mesh.ctx, mesh.nBoundary); fluxMask.assignHost(fluxMaskB);
@@ -157,11 +165,18 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
           + fvc::div(phiHbyA)
           - fvm::laplacian(rhorAUf, p_rgh)
         );
-        p_rghEqn.solve(mesh.solver("p_rgh"));
+        surfaceScalarField phiNew("phi", phiHbyA);
+        while (pimple.correctNonOrthogonal())
+        {
+            p_rghEqn.solve(mesh.solver(p_rgh.select(pimple.finalInnerIter())));
 
-        surfaceScalarField phiNew("phi", phiHbyA + p_rghEqn.flux());
-        U = HbyA + rAU*fvc::reconstruct((p_rghEqn.flux() + phig)/rhorAUf);
-        U.correctBoundaryConditions();
+            if (pimple.finalNonOrthogonalIter())
+            {
+                phiNew = phiHbyA + p_rghEqn.flux();
+                U = HbyA + rAU*fvc::reconstruct((p_rghEqn.flux() + phig)/rhorAUf);
+                U.correctBoundaryConditions();
+            }
+        }
 
         p_rgh.v.toHost(p_rghOut);
         FFM_FOAM_CHK(ffm_faces_from_native(mesh.msh, phiNew.v.data(), phiOutF));
@@ -169,8 +184,37 @@ extern "C" int b1_demo(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double deltaT,
         for (int d = 0; d < 3; d++) U.v[d].toHost(UcorrOut + (size_t)d*N);
     }
 
+    if (pimple.loop()) FatalError("pimple.loop(): nOuterCorrectors 1 must end after one pass");
     FFM_FOAM_CHK(ffm_ctx_sync(ctx));
     int n = 0;
     for (const solverPerformance& sp : mesh.log) nIterOut[n++] = sp.nIterations;
+    return n;
+}
+
+// The order in which pimpleControl walks one time step (no device work): for every pass of the innermost loop one int
+//   outer*10000 + corrector*100 + nonOrthogonal*10 + finalInnerIter, then -1 at the end of each outer pass.
+extern "C" int b1_pimple_sequence(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, int nOuter, int nCorr, int nNonOrth, int* out, int cap)
+{
+    fvMesh mesh(ctx, ldu, msh, 1.0);
+    pimpleDict pd; pd.nOuterCorrectors = nOuter; pd.nCorrectors = nCorr; pd.nNonOrthogonalCorrectors = nNonOrth;
+    pimpleControl pimple(mesh, pd);
+    int n = 0, outer = 0;
+    while (pimple.loop())
+    {
+        outer++;
+        int corr = 0;
+        while (pimple.correct())
+        {
+            corr++;
+            int no = 0;
+            while (pimple.correctNonOrthogonal())
+            {
+                if (n < cap) out[n] = outer*10000 + corr*100 + (no++)*10 + (pimple.finalInnerIter() ? 1 : 0);
+                n++;
+            }
+        }
+        if (n < cap) out[n] = (mesh.finalIteration && pimple.turbCorr()) ? -1 : -2;
+        n++;
+    }
     return n;
 }

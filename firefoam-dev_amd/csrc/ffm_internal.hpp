@@ -189,6 +189,7 @@ int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose);
 int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot);  // y=Ax, scal[slot]=x.y (local)
 int ffm_k_residual(ffm_ldu *A, const double *x, const double *b, double *r);
 int ffm_k_sumA(ffm_ldu *A, double *s);
+int ffm_k_spmv_sumA(ffm_ldu *A, const double *x, double *y, double *s);
 int ffm_halo_update(ffm_ldu *A, const double *x, double *y, const double *coeffs, double sign);  // exchange + apply
 int ffm_halo_apply(ffm_ldu *A, double *y, const double *coeffs, const double *vals /*null => 1*/, double sign);
 int ffm_allreduce_slots(ffm_ctx *ctx, int firstSlot, int n);   // sum over ranks, in stream

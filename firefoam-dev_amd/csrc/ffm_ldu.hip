@@ -763,6 +763,8 @@ LduView ffm_view(const ffm_ldu *A)
 // One thread per row, grid-stride over a fixed grid; a wave = one slice, so all
 // index/coefficient loads are unit-stride and the slot loops are wave-uniform.
 // MODE 0: y = A x.  MODE 1: r = b - A x (lduMatrix::residual order).  MODE 2: s = sumA.
+// MODE 3: y = A x and sumA (written through `partials`) in one pass over the coefficients -- the first two things every
+// solver does with a freshly bound matrix (wA = A psi; normFactor needs sumA).
 // DOT: additionally accumulates the block-partial of x[c]*y[c] (PCG's wApA).
 template <int MODE, bool DOT, int W>
 __global__ __launch_bounds__(256) void k_rows(LduView v, const double *__restrict__ diag,
@@ -789,22 +791,26 @@ __global__ __launch_bounds__(256) void k_rows(LduView v, const double *__restric
         double xc = 0.0, acc;
         if (MODE != 2) xc = x[c];
         const double dc = __builtin_nontemporal_load(&diag[c]);
-        if (MODE == 0) acc = dc * xc;
+        double sum = dc;
+        if (MODE == 0 || MODE == 3) acc = dc * xc;
         else if (MODE == 1) acc = __builtin_nontemporal_load(&b[c]) - dc * xc;
         else acc = dc;
 #pragma unroll
         for (int s = 0; s < W; s++) if (L.on[s]) {
-            if (MODE == 0) acc += al[s] * xl[s];
+            if (MODE == 0 || MODE == 3) acc += al[s] * xl[s];
             else if (MODE == 1) acc -= al[s] * xl[s];
             else acc += al[s];
+            if (MODE == 3) sum += al[s];
         }
 #pragma unroll
         for (int s = 0; s < W; s++) if (U.on[s]) {
-            if (MODE == 0) acc += au[s] * xu[s];
+            if (MODE == 0 || MODE == 3) acc += au[s] * xu[s];
             else if (MODE == 1) acc -= au[s] * xu[s];
             else acc += au[s];
+            if (MODE == 3) sum += au[s];
         }
         __builtin_nontemporal_store(acc, &y[c]);
+        if (MODE == 3) __builtin_nontemporal_store(sum, &partials[c]);
         if (DOT) dot += acc * xc;
     }
     if (DOT) {
@@ -871,6 +877,24 @@ int ffm_k_residual(ffm_ldu *A, const double *x, const double *b, double *r)
                                                A->diag, A->upper, A->lower, x, b, r, (double *)nullptr));
     FFM_HIP(hipGetLastError());
     if (!A->ifaces.empty()) FFM_TRY(ffm_halo_update(A, x, r, A->ifBou, +1.0));
+    return FFM_OK;
+}
+
+// y = A x and s = sumA of the same matrix: one pass where the row kernel does the Amul, two where the tiled kernel does
+int ffm_k_spmv_sumA(ffm_ldu *A, const double *x, double *y, double *s)
+{
+    if ((ffm_tile_amul_usable(A) && !getenv("FFM_NO_TILE_AMUL")) || getenv("FFM_NO_FUSED_SUMA")) {
+        FFM_TRY(ffm_k_spmv(A, x, y, false));
+        return ffm_k_sumA(A, s);
+    }
+    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));
+    FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<3, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
+                                               A->diag, A->upper, A->lower, x, (const double *)nullptr, y, s));
+    FFM_HIP(hipGetLastError());
+    if (!A->ifaces.empty()) {
+        FFM_TRY(ffm_halo_update(A, x, y, A->ifBou, -1.0));
+        FFM_TRY(ffm_halo_apply(A, s, A->ifBou, nullptr, -1.0));
+    }
     return FFM_OK;
 }
 

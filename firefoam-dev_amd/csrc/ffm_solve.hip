@@ -508,13 +508,13 @@ static inline bool check_convergence(ffm_perf *p, const Controls &k)
 }
 
 // normFactor + initial residual: wA = A psi already computed, rA = source - wA already formed
+// tmp holds sumA on entry (ffm_k_spmv_sumA at the top of every solver)
 static int norm_and_initial(ffm_ldu *A, const double *psi, const double *source, const double *Apsi, double *tmp,
                             const double *rA, ffm_perf *perf)
 {
     ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned;
     FFM_TRY(ffm_k_sum(c, psi, N, S_TMP0));
     FFM_TRY(finish_dot(c, OP_XREF, 1, (double)A->globalCells));
-    FFM_TRY(ffm_k_sumA(A, tmp));
     const int g = sgrid(N);
     hipLaunchKernelGGL(k_normf, dim3(g), dim3(256), 0, s, N, Apsi, source, tmp, c->scal_d, c->partials_d);
     FFM_TRY(partial_sum_to(c, g, S_TMP0));
@@ -535,7 +535,7 @@ static int pcg(ffm_ldu *A, int precond, const Controls &k, double *psi, const do
     double *pA, *wA, *rA;
     FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &wA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
     FFM_TRY(scalar_op(c, OP_RESET));
-    FFM_TRY(ffm_k_spmv(A, psi, wA, false));
+    FFM_TRY(ffm_k_spmv_sumA(A, psi, wA, pA));
     hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, rA, source, wA);
     FFM_TRY(norm_and_initial(A, psi, source, wA, pA, rA, perf));
     if (k.minIter > 0 || !check_convergence(perf, k)) {
@@ -565,7 +565,7 @@ static int pbicgstab(ffm_ldu *A, int precond, const Controls &k, double *psi, co
     double *yA, *rA, *pA, *AyA, *sA, *zA, *tA, *rA0;
     FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &yA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
     FFM_TRY(scalar_op(c, OP_RESET));
-    FFM_TRY(ffm_k_spmv(A, psi, yA, false));
+    FFM_TRY(ffm_k_spmv_sumA(A, psi, yA, pA));
     hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, rA, source, yA);
     FFM_TRY(norm_and_initial(A, psi, source, yA, pA, rA, perf));
     if (k.minIter > 0 || !check_convergence(perf, k)) {
@@ -615,7 +615,7 @@ static int pbicg(ffm_ldu *A, int precond, const Controls &k, double *psi, const 
     FFM_TRY(ffm_ldu_work(A, 1, &pA)); FFM_TRY(ffm_ldu_work(A, 2, &wA)); FFM_TRY(ffm_ldu_work(A, 3, &rA));
     FFM_TRY(ffm_ldu_work(A, 4, &pT)); FFM_TRY(ffm_ldu_work(A, 5, &wT)); FFM_TRY(ffm_ldu_work(A, 6, &rT));
     FFM_TRY(scalar_op(c, OP_RESET));
-    FFM_TRY(ffm_k_spmv(A, psi, wA, false));
+    FFM_TRY(ffm_k_spmv_sumA(A, psi, wA, pA));
     FFM_TRY(ffm_k_spmv(A, psi, wT, true));
     hipLaunchKernelGGL(k_sub2, dim3(g), dim3(256), 0, s, N, rA, rT, source, wA, wT);
     FFM_TRY(norm_and_initial(A, psi, source, wA, pA, rA, perf));
@@ -654,7 +654,7 @@ static int smooth(ffm_ldu *A, int smoother, const Controls &k, double *psi, cons
     double *Apsi, *tmp, *res;
     FFM_TRY(ffm_ldu_work(A, 1, &Apsi)); FFM_TRY(ffm_ldu_work(A, 2, &tmp)); FFM_TRY(ffm_ldu_work(A, 3, &res));
     FFM_TRY(scalar_op(c, OP_RESET));
-    FFM_TRY(ffm_k_spmv(A, psi, Apsi, false));
+    FFM_TRY(ffm_k_spmv_sumA(A, psi, Apsi, tmp));
     hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, res, source, Apsi);
     FFM_TRY(norm_and_initial(A, psi, source, Apsi, tmp, res, perf));
     if (k.minIter > 0 || !check_convergence(perf, k)) {

@@ -12,11 +12,12 @@
  * function below names the upstream file whose published algorithm it
  * restates, and the reference call site / dictionary that selects it.
  *
- * PARITY PIN: operator-level results are unpinned by the reference's own tests
- * (it has none).  The only golden data is the steckler log
- * cases/steckler/original/linux64/log.fireFoam; see oracle/README.md for which
- * oracle functions are pinned by it (tests/test_golden_log.py) and which are
- * "parity unpinned".
+ * PARITY PIN: the reference has no unit tests; its only golden data is the
+ * steckler log cases/steckler/original/linux64/log.fireFoam, whose five
+ * hydrostatic DICPCG solves (lines 92-101) this library reproduces digit for
+ * digit (tests/test_golden_log_cpu.py): that pins Amul, sumA/normFactor, DIC
+ * and PCG.  DILU, PBiCGStab, PBiCG, Gauss-Seidel and the smooth solver are
+ * "parity unpinned" by reference data (oracle/README.md).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The product (firefoam-dev_amd/) never links it.

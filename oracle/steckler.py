@@ -14,8 +14,15 @@ Case data used (all reference file:line):
   T 298.15, Y O2 0.23301 / N2 0.76699, W from cases/steckler/constant/thermo.compressibleGas
   PCG + DIC, tolerance 1e-6, relTol 0.01      cases/steckler/system/fvSolution:29-46
   nHydrostaticCorrectors 5                    cases/steckler/system/fvSolution:91-92
-The doorway box touches face centres at z = +-0.5 exactly; with those faces taken as inside the box
-(boundBox::contains is inclusive) the first two solves reproduce the golden iteration counts.
+  boundary mixture: the inert specie's file gives N2 `calculated; value uniform 0` on top, sides, base, burner and floor
+  (cases/steckler/0/N2:24-51), and nothing evaluates that boundary before the hydrostatic initialisation, so the patch-face
+  mixture there is O2 alone (0.23301 of it): W_b = W_O2, psi_b = W_O2/(RR T) -- 10.9 % above the interior's.  On the
+  baffle patches T = 300 K and O2/N2 = 0.232/0.768 (cases/steckler/0/T:51-82, 0/include/wallBafflePatches).  On
+  fixedFluxPressure patches the boundary density cancels between the Laplacian's boundary source and div(phig); on `top`
+  (fixedValue) it is the coefficient rhof_b*|Sf|*deltaCoeffs of the top cell layer.
+The doorway box touches face centres at z = +-0.5 exactly; those faces are inside the box (boundBox::contains is inclusive).
+With both, the five solves reproduce the golden log DIGIT FOR DIGIT (all 8 printed digits of every residual and of every
+gMax-gMin, and every iteration count): tests/test_golden_log_cpu.py.
 """
 import numpy as np
 
@@ -52,11 +59,14 @@ def hydrostatic_initialisation(solve, nCorr=5, mesh=None):
     ghb = [p.Cf @ g - ghRef for p in m.patches]
     W = 1.0 / (0.23301 / 31.9988 + 0.76699 / 28.0134)
     psi = 1.0 / ((RR / W) * 298.15)
+    # patch-face mixtures (see the header): O2 alone where the N2 file leaves the boundary value 0, the wall values on the baffles
+    Wbaffle = 1.0 / (0.232 / 31.9988 + 0.768 / 28.0134)
+    psib = [1.0 / ((RR / Wbaffle) * 300.0) if pp.name.startswith("baffle") else 1.0 / ((RR / 31.9988) * 298.15) for pp in m.patches]
     rho = np.full(m.nCells, psi * 101325.0)
-    rhob = [np.full(p.size, psi * 101325.0) for p in m.patches]
+    rhob = [np.full(p.size, q * 101325.0) for p, q in zip(m.patches, psib)]
     ph = np.zeros(m.nCells); phb = [np.zeros(p.size) for p in m.patches]
     p = ph + rho * gh + pRef; pb = [a + r * gg + pRef for a, r, gg in zip(phb, rhob, ghb)]
-    rho = psi * p; rhob = [psi * x for x in pb]
+    rho = psi * p; rhob = [q * x for q, x in zip(psib, pb)]
     recs = []
     for _ in range(nCorr):
         rhof, rhofb = fv.interpolate(m, rho, rhob)
@@ -73,7 +83,7 @@ def hydrostatic_initialisation(solve, nCorr=5, mesh=None):
         phb = [np.zeros(pp.size) if bcs[q][0] == "fixedValue" else ph[pp.faceCells] + bcs[q][1] / pp.deltaCoeffs
                for q, pp in enumerate(m.patches)]
         p = ph + rho * gh + pRef; pb = [a + r * gg + pRef for a, r, gg in zip(phb, rhob, ghb)]
-        rho = psi * p; rhob = [psi * x for x in pb]
+        rho = psi * p; rhob = [q * x for q, x in zip(psib, pb)]
         recs.append(dict(perf, variation=float(ph.max() - ph.min())))
     return recs, ph
 

@@ -1,0 +1,25 @@
+"""Per-kernel totals of the LAST time step in a rocprofv3 kernel trace (the --stats table mixes in the start-up).
+usage: step_breakdown.py <..._kernel_trace.csv> [marker-substring]
+The step is taken to start at the last kernel whose name contains the marker (default: the first lambda of ffm_plume_step)."""
+import csv, sys, collections
+path = sys.argv[1]
+marker = sys.argv[2] if len(sys.argv) > 2 else "ffm_plume_step::{lambda(long)#1}"
+rows = []
+with open(path) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+starts = [i for i, r in enumerate(rows) if marker in r[2]]
+if not starts:
+    sys.exit("marker not found")
+i0 = starts[-1]
+step = rows[i0:]
+wall = step[-1][1] - step[0][0]
+busy = 0; tot = collections.Counter(); cnt = collections.Counter(); last_end = step[0][0]; gap = 0
+for s, e, n in step:
+    tot[n] += e - s; cnt[n] += 1; busy += e - s
+    if s > last_end: gap += s - last_end
+    last_end = max(last_end, e)
+print("last step: %d kernels, wall %.2f ms, kernel time %.2f ms, idle gaps %.2f ms" % (len(step), wall / 1e6, busy / 1e6, gap / 1e6))
+for n, t in tot.most_common(45):
+    print("%8.2f ms %6d x %8.1f us  %s" % (t / 1e6, cnt[n], t / cnt[n] / 1e3, n[:110]))

@@ -103,6 +103,25 @@ def test_foam_layer_demo_builds_and_loads():
     assert hasattr(lib, "b1_demo")
 
 
+def test_pimple_control_sequence():
+    """pimpleControl of include/ffmFoam.H walks the loops of solver/fireFoam.C:102-119 / solver/pEqn.H:24-44
+    as upstream does: PIMPLE 1/2/0 (cases/steckler/system/fvSolution:84-89) gives two correctors, p_rghFinal on the second."""
+    import ctypes, os
+    from ffm_import import ffm
+    import torch  # noqa: F401
+    ffm.lib()
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    out = (ctypes.c_int * 64)()
+
+    def seq(a, b, c):
+        n = lib.b1_pimple_sequence(None, None, None, a, b, c, out, 64)
+        return list(out[:n])
+    assert seq(1, 2, 0) == [10100, 10201, -1]
+    assert seq(1, 1, 0) == [10101, -1]
+    assert seq(2, 2, 1) == [10100, 10110, 10200, 10210, -2, 20100, 20110, 20200, 20211, -1]
+    assert seq(1, 2, 0) == [10100, 10201, -1]          # counters reset after the loop ended
+
+
 def _levels(N, l, u):
     lev = np.zeros(N, np.int64)
     for a, b in zip(l, u):

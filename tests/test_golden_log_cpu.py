@@ -2,14 +2,18 @@
 DICPCG solves of the hydrostatic initialisation in the steckler golden log
 (reference cases/steckler/original/linux64/log.fireFoam:92-101).
 
-What is pinned, honestly: the oracle reproduces the golden iteration counts of solves 1, 2, 4 and 5
-exactly (29, 32, 0, 0), solve 3 within one iteration (8 vs 7), every residual within 15 %, the
-initial residual of exactly 1, and the converged hydrostatic variation to 2e-6 relative.  The
-residuals are NOT reproduced digit for digit (first final residual 0.00836 vs 0.00804); the cause
-was not found (candidates: face-centre rounding in the doorway selection, an un-shipped
-difference between the golden build d773a7a and the current dictionaries).  PCG control flow,
-normFactor, DIC ordering, Laplacian and boundary-coefficient assembly are therefore pinned by
-iteration counts, not bitwise; every other oracle function is 'parity unpinned'."""
+What is pinned: the oracle reproduces the golden log DIGIT FOR DIGIT -- every iteration count (29, 32, 7, 0, 0), all 8
+printed digits of every initial and final residual and of every `gMax-gMin` (asserted to 1e-7 relative: the one visible
+difference is 9.6500999e-07 against the printed 9.6501e-07, i.e. 1e-8).  That pins, through the reference's own output:
+PCG control flow and stopping rule, normFactor, DIC (calcReciprocalD + precondition) in face order, fvm::laplacian and its
+boundary coefficients (fixedValue, fixedGradient via constrainPressure), fvc::interpolate, fvc::snGrad, fvc::div /
+surfaceIntegrate, the baffle/doorway mesh surgery and the LDU addressing.  Operators the hydrostatic initialisation does not
+touch (convection schemes and limiters, ddt, DILU/PBiCGStab/GaussSeidel, H/A/flux, relax) remain 'parity unpinned' by
+reference data: they are checked against dense algebra, hand-computed stencils and identities instead.
+
+Two case details carry the match (found by reading the case files, see oracle/steckler.py): the doorway box is inclusive of
+the face centres at z = +-0.5, and the boundary mixture on `top` is O2 alone because cases/steckler/0/N2 leaves N2 = 0 on
+that patch until the first YEEqn (its density, +10.9 %, is the fixedValue coefficient of the top cell layer)."""
 import json
 import os
 
@@ -22,15 +26,31 @@ def test_hydrostatic_initialisation_against_golden_log(O):
     from oracle import steckler
     recs, ph = steckler.hydrostatic_initialisation(steckler.oracle_solve)
     gold = GOLD["solves"]
-    assert [r["nIterations"] for r in recs][:2] == [29, 32]
-    assert abs(recs[2]["nIterations"] - gold[2]["nIterations"]) <= 1
-    assert [r["nIterations"] for r in recs][3:] == [0, 0]
+    assert [r["nIterations"] for r in recs] == [g["nIterations"] for g in gold] == [29, 32, 7, 0, 0]
     assert recs[0]["initialResidual"] == 1.0
     for r, g in zip(recs, gold):
-        assert abs(r["finalResidual"] - g["finalResidual"]) <= 0.15 * g["finalResidual"]
-        assert abs(r["initialResidual"] - g["initialResidual"]) <= 0.15 * g["initialResidual"]
-        assert abs(r["variation"] - g["variation"]) <= 5e-4 * g["variation"]
-    assert abs(recs[-1]["variation"] - gold[-1]["variation"]) <= 5e-6 * gold[-1]["variation"]
+        for key in ("initialResidual", "finalResidual", "variation"):
+            assert abs(r[key] - g[key]) <= 1e-7 * g[key], (key, r[key], g[key])
+        # and as the log prints them (8 significant digits); the third final residual is the 1e-8 case named above
+        assert "%.8g" % r["initialResidual"] == "%.8g" % g["initialResidual"]
+        assert "%.8g" % r["variation"] == "%.8g" % g["variation"]
+
+
+def test_boundary_mixture_of_the_top_patch_is_what_matches(O, monkeypatch):
+    """with the interior's mixture on `top` (N2 boundary value taken as 0.76699 instead of the file's 0) the first final
+    residual is 0.00836, not the golden 0.0080439052"""
+    from oracle import steckler
+    real = steckler.fv.interpolate
+    recs, _ = steckler.hydrostatic_initialisation(steckler.oracle_solve, nCorr=1)
+    assert "%.8g" % recs[0]["finalResidual"] == "0.0080439052"
+    W = 1.0 / (0.23301 / 31.9988 + 0.76699 / 28.0134)
+
+    def interior_mixture_on_top(m, rho, rhob):
+        rhob = [b * (W / 31.9988) if p.name == "top" else b for p, b in zip(m.patches, rhob)]
+        return real(m, rho, rhob)
+    monkeypatch.setattr(steckler.fv, "interpolate", interior_mixture_on_top)
+    recs, _ = steckler.hydrostatic_initialisation(steckler.oracle_solve, nCorr=1)
+    assert recs[0]["nIterations"] == 29 and abs(recs[0]["finalResidual"] - 0.00836) < 5e-5
 
 
 def test_doorway_borderline_choice_is_the_one_that_matches(O):

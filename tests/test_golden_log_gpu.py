@@ -1,8 +1,9 @@
 """The same golden-log check with the HIP solver in the loop: the five hydrostatic-initialisation
 DICPCG solves of the steckler case (reference cases/steckler/original/linux64/log.fireFoam:92-101)
-solved by libffm through the C ABI must follow the oracle's (and hence the golden log's) iteration
-counts; the assembled matrices come from the oracle's FV operators (assembly kernels have their own
-parity tests)."""
+solved by libffm through the C ABI must reproduce the golden log itself -- every iteration count and every printed
+residual / gMax-gMin to 1e-6 relative (the oracle matches the log digit for digit, tests/test_golden_log_cpu.py; the HIP
+solver sums its dot products in a different order, which moves the 8th digit); the assembled matrices come from the
+oracle's FV operators (assembly kernels have their own parity tests)."""
 import json
 import os
 
@@ -38,8 +39,10 @@ def test_steckler_hydrostatic_solves_on_gpu(O, ffm, ctx, tiled):
     recs, ph = steckler.hydrostatic_initialisation(gpu_solve, mesh=m)
     ref, phRef = steckler.hydrostatic_initialisation(steckler.oracle_solve, mesh=m)
     assert [r["nIterations"] for r in recs] == [r["nIterations"] for r in ref]
-    assert [r["nIterations"] for r in recs][:2] == [g["nIterations"] for g in GOLD["solves"]][:2] == [29, 32]
-    for r, o in zip(recs, ref):
+    assert [r["nIterations"] for r in recs] == [g["nIterations"] for g in GOLD["solves"]] == [29, 32, 7, 0, 0]
+    for r, o, g in zip(recs, ref, GOLD["solves"]):
         assert abs(r["finalResidual"] - o["finalResidual"]) <= 1e-6 * o["finalResidual"]
+        for key in ("initialResidual", "finalResidual", "variation"):
+            assert abs(r[key] - g[key]) <= 1e-6 * g[key], (key, r[key], g[key])
     assert np.linalg.norm(ph - phRef) / np.linalg.norm(phRef) < 1e-8
     A.close()

@@ -1,6 +1,6 @@
 """CPU tests of the oracle itself (no GPU): dense cross-checks, solver identities and the
-in-process multi-domain runner.  Operator-level parity of the oracle against OpenFOAM is
-unpinned by the reference (it has no unit tests); the golden-log pin is tests/test_golden_log.py."""
+in-process multi-domain runner.  The reference has no unit tests; its one golden log pins PCG/DIC/laplacian/snGrad/
+interpolate digit for digit (tests/test_golden_log_cpu.py), the remaining operators are checked here against dense algebra."""
 import numpy as np
 import pytest
 
