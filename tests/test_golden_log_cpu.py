@@ -62,3 +62,14 @@ def test_doorway_borderline_choice_is_the_one_that_matches(O):
         recs, _ = steckler.hydrostatic_initialisation(steckler.oracle_solve, nCorr=1, mesh=steckler.build_mesh(dk))
         counts[dk] = recs[0]["nIterations"]
     assert counts[(7, 12)] == 29 and all(v != 29 for k, v in counts.items() if k != (7, 12))
+
+
+def test_fvdom_ray_solid_angles_against_golden_log(O):
+    """the 32 solid angles the reference prints at start-up (log.fireFoam:125-156), digit for digit: pins the ray set of the
+    fvDOM stand-in (oracle/plume.py ray_set; theta outer / phi inner, omega = 2 sin(theta) sin(dTheta/2) dPhi)"""
+    from oracle import plume
+    rays = plume.ray_set(2, 4)
+    gold = GOLD["fvDOM_ray_omega"]["omega"]
+    assert len(rays) == len(gold) == 32
+    for (_, omega), g in zip(rays, gold):
+        assert "%.8g" % omega == "%.8g" % g
