@@ -16,7 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-_SO = os.path.join(_HERE, "lib", "libffm.so")
+_SO = os.environ.get("FFM_LIB") or os.path.join(_HERE, "lib", "libffm.so")      # FFM_LIB: kernel experiments only
 _HDR = os.path.join(_ROOT, "include", "ffm.h")
 
 SOLVERS = {"PCG": 0, "PBiCGStab": 1, "PBiCG": 2, "diagonal": 3, "smoothSolver": 4}

@@ -31,7 +31,10 @@ constexpr int T_RING = 4096;        // doubles (power of two)
 constexpr int T_ENT = 256;          // max cells per entry = workgroup size
 constexpr int T_THREADS = 256;
 constexpr int T_W = 3;              // neighbour slots per cell and direction (hexahedra: 3)
-constexpr int T_PF = 8;             // entries fetched ahead of the one being computed
+#ifndef FFM_T_PF
+#define FFM_T_PF 8
+#endif
+constexpr int T_PF = FFM_T_PF;      // entries fetched ahead of the one being computed
 constexpr int T_PM = 3;             // mailbox values are loaded this many entries ahead (2 <= T_PM < T_PF)
 constexpr int T_XMAX = 64;          // max external references per entry (one lane of the mail wave each; power of two)
 constexpr int T_RINGD = T_RING - 2 * T_ENT;     // largest cell distance served by the ring
@@ -990,4 +993,14 @@ extern "C" int ffm_debug_tile_trace(ffm_ldu *A, unsigned long long *out, int nWo
     }
     if (out && nWords > 0) FFM_HIP(hipMemcpy(out, T->trace, sizeof(unsigned long long) * std::min(nWords, 4 * T->G), hipMemcpyDeviceToHost));
     return T->G;
+}
+
+// Diagnostics: resident workgroups per CU the runtime predicts for the forward / backward sweep kernels and the tiled Amul
+extern "C" int ffm_debug_tile_occupancy(int *out3)
+{
+    if (!out3) return FFM_ERR_ARG;
+    FFM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[0], k_tile<TM_FWD, false, false>, T_THREADS + 64, 0));
+    FFM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[1], k_tile<TM_BWD, false, false>, T_THREADS + 64, 0));
+    FFM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out3[2], k_tile_amul<true>, T_THREADS + 64, 0));
+    return FFM_OK;
 }

@@ -21,6 +21,9 @@ A.reciprocalD("DIC")
 r = ctx.to_device(s["source"][cOrd])
 w = ctx.empty(blk.nCells)
 L = ffm.lib()
+occ = (C.c_int * 3)()
+if hasattr(L, "ffm_debug_tile_occupancy") and L.ffm_debug_tile_occupancy(occ) == 0:
+    print("runtime occupancy estimate (workgroups per CU): fwd %d bwd %d amul %d" % tuple(occ))
 def apply():
     rc = L.ffm_precond_apply(A.h, 1, 0, C.c_void_p(r.data_ptr()), C.c_void_p(w.data_ptr()))
     assert rc == 0, L.ffm_last_error()
@@ -47,6 +50,11 @@ if os.environ.get("FFM_TRACE"):
                   " run time (end-first entry) min/median/max %.1f/%.1f/%.1f us; re-loads total %d (max per group %d)"
                   % (which, G, en.max(), st.min(), np.median(st), st.max(), np.median(fe - st), (fe - st).max(),
                      (en - fe).min(), np.median(en - fe), (en - fe).max(), int(sp.sum()), int(sp.max())))
+            ev = sorted([(t, 1) for t in st] + [(t, -1) for t in en])
+            cur = peak = 0
+            for _, d in ev:
+                cur += d; peak = max(peak, cur)
+            print("  resident groups: %d started within 5 us, peak concurrently running %d" % (int((st < 5).sum()), peak))
             order = np.argsort(st)
             for q in (0, G // 4, G // 2, 3 * G // 4, G - 1):
                 g = order[q]
