@@ -129,6 +129,7 @@ def lib():
         "ffm_mesh_destroy": ([vp], C.c_int),
         "ffm_mesh_set_face_centres": ([vp, hp], C.c_int),
         "ffm_fv_lust_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fv_linear_upwind_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fvm_relax": ([vp, C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_mesh_nboundary": ([vp], C.c_int),
         "ffm_mesh_nnative": ([vp], C.c_int),

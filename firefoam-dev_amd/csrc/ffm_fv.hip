@@ -261,7 +261,7 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
             const double flux = phi[e];
             const double p0 = flux >= 0 ? 1.0 : 0.0;
             double wgt;
-            if (scheme == 0) wgt = p0;
+            if (scheme == 0 || scheme == 5) wgt = p0;                       // upwind; linearUpwind<Type>::weights = upwind's
             else if (scheme == 1) wgt = q.w[e];
             else if (scheme == 4) wgt = 0.75 * q.w[e] + 0.25 * p0;          // LUST<Type>::weights
             else {
@@ -291,14 +291,14 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
 __global__ void k_lust_correction(MeshView q, const double *__restrict__ phi, const double *__restrict__ gx, const double *__restrict__ gy,
                                   const double *__restrict__ gz, const double *__restrict__ Cx, const double *__restrict__ Cy,
                                   const double *__restrict__ Cz, const double *__restrict__ Cfx, const double *__restrict__ Cfy,
-                                  const double *__restrict__ Cfz, double *__restrict__ out)
+                                  const double *__restrict__ Cfz, double factor, double *__restrict__ out)
 {
     CELL_SCHED(ci, q) {
         const int c = (int)ci;
         FOR_OWN_FACES(q, c, e, nb) {
             const int up = phi[e] > 0 ? c : nb;
             const double dx = Cfx[e] - Cx[up], dy = Cfy[e] - Cy[up], dz = Cfz[e] - Cz[up];
-            out[e] = 0.25 * ((dx * gx[up] + dy * gy[up]) + dz * gz[up]);
+            out[e] = factor * ((dx * gx[up] + dy * gy[up]) + dz * gz[up]);       // factor 1: linearUpwind itself (1.0*x == x)
         }
     }
 }
@@ -603,7 +603,7 @@ extern "C" int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double 
                                       const double *vf, const double *gx, const double *gy, const double *gz, double *out_w)
 {
     CHECK_M(m);
-    if (scheme < 0 || scheme > 4 || !phi_f || !out_w || ((scheme == 2 || scheme == 3) && (!vf || !gx || !gy || !gz))) return FFM_ERR_ARG;
+    if (scheme < 0 || scheme > 5 || !phi_f || !out_w || ((scheme == 2 || scheme == 3) && (!vf || !gx || !gy || !gz))) return FFM_ERR_ARG;
     LAUNCH_CELLS(k_limited_weights, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], out_w);
     DONE();
 }
@@ -624,7 +624,15 @@ extern "C" int ffm_fv_lust_correction(ffm_mesh *m, const double *phi_f, const do
     CHECK_M(m);
     if (!phi_f || !gx || !gy || !gz || !out_f) return FFM_ERR_ARG;
     if (!m->Cf[0]) { ffm_set_error("ffm_fv_lust_correction: face centres not set (ffm_mesh_set_face_centres)"); return FFM_ERR_ARG; }
-    LAUNCH_CELLS(k_lust_correction, mview(m), phi_f, gx, gy, gz, m->C[0], m->C[1], m->C[2], m->Cf[0], m->Cf[1], m->Cf[2], out_f);
+    LAUNCH_CELLS(k_lust_correction, mview(m), phi_f, gx, gy, gz, m->C[0], m->C[1], m->C[2], m->Cf[0], m->Cf[1], m->Cf[2], 0.25, out_f);
+    DONE();
+}
+extern "C" int ffm_fv_linear_upwind_correction(ffm_mesh *m, const double *phi_f, const double *gx, const double *gy, const double *gz, double *out_f)
+{
+    CHECK_M(m);
+    if (!phi_f || !gx || !gy || !gz || !out_f) return FFM_ERR_ARG;
+    if (!m->Cf[0]) { ffm_set_error("ffm_fv_linear_upwind_correction: face centres not set (ffm_mesh_set_face_centres)"); return FFM_ERR_ARG; }
+    LAUNCH_CELLS(k_lust_correction, mview(m), phi_f, gx, gy, gz, m->C[0], m->C[1], m->C[2], m->Cf[0], m->Cf[1], m->Cf[2], 1.0, out_f);
     DONE();
 }
 extern "C" int ffm_fvm_relax(ffm_mesh *m, double alpha, int nc, const double *upper, const double *lower, const double *ic0,

@@ -246,7 +246,8 @@ int ffm_fvc_grad(ffm_mesh *m, const double *vf, const double *vb, double *gx, do
 int ffm_fvc_reconstruct(ffm_mesh *m, const double *ssf_f, const double *ssf_b, double *ox, double *oy, double *oz);
 /* limitedSurfaceInterpolationScheme weights: scheme 0 upwind, 1 linear,
  * 2 limitedLinear k, 3 limitedLinear01 k with bounds [lo,hi], 4 LUST (0.75 linear +
- * 0.25 upwind; vf and gradients unused)  (cases/steckler/system/fvSchemes:28-54) */
+ * 0.25 upwind; vf and gradients unused), 5 linearUpwind (upwind weights; its explicit correction is
+ * ffm_fv_linear_upwind_correction)  (cases/steckler/system/fvSchemes:28-54) */
 int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double hi,
                            const double *phi_f, const double *vf, const double *gx,
                            const double *gy, const double *gz, double *out_w_f);
@@ -256,6 +257,10 @@ int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double 
  * then adds fvc::surfaceIntegrate(phi*correction) to the matrix: source -= V * ffm_fvc_surface_integrate(phi_f*corr_f, 0). */
 int ffm_fv_lust_correction(ffm_mesh *m, const double *phi_f, const double *gx, const double *gy,
                            const double *gz, double *out_f);
+/* linearUpwind<Type>::correction(vf): (Cf - C_c) & grad(vf)_c with c the upwind cell, no factor
+ * (`div(Ji,Ii_h) Gauss linearUpwind grad(Ii_h)`, cases/wallFireSpread2D/system/fvSchemes:58); used like the LUST one. */
+int ffm_fv_linear_upwind_correction(ffm_mesh *m, const double *phi_f, const double *gx, const double *gy,
+                                    const double *gz, double *out_f);
 
 /* ------------------------------------------------------- fvm:: (implicit)    */
 /* [fvm::ddt(rho,.)] + [fvm::div(phi,.)] (+/-) [fvm::laplacian(gamma,.)] in one

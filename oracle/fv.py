@@ -278,6 +278,16 @@ def lust_correction(mesh, phi, gradvf):
     return 0.25 * ((d[:, 0] * g[:, 0] + d[:, 1] * g[:, 1]) + d[:, 2] * g[:, 2])
 
 
+def linear_upwind_correction(mesh, phi, gradvf):
+    """linearUpwind<Type>::correction (OpenFOAM-dev .../schemes/linearUpwind/linearUpwind.C): (Cf - C_c) & grad(vf)_c, c the upwind
+    cell, zero on non-coupled patches; its weights are upwind's.  Reference selection: `div(Ji,Ii_h) Gauss linearUpwind
+    grad(Ii_h)`, cases/wallFireSpread2D/system/fvSchemes:58."""
+    cell = np.where(phi > 0, mesh.l, mesh.u)
+    d = mesh.Cf - mesh.C[cell]
+    g = gradvf[cell]
+    return (d[:, 0] * g[:, 0] + d[:, 1] * g[:, 1]) + d[:, 2] * g[:, 2]
+
+
 class Matrix:
     """fvMatrix<Type> with nc components sharing diag/upper/lower (Type = scalar: nc=1, vector: nc=3)."""
 

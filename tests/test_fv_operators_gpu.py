@@ -176,6 +176,11 @@ def test_lust_weights_and_correction(setup, O, ctx):
     corr = ctx.zeros(mesh.nNative)
     mesh.call("fv_lust_correction", facef(s, phi), *g, corr)
     assert np.array_equal(back_face(s, corr), fv.lust_correction(m, phi, gref))
+    # linearUpwind (cases/wallFireSpread2D/system/fvSchemes:58): upwind weights, the same correction without the factor 0.25
+    mesh.call("fv_limited_weights", 5, 1.0, 0.0, 1.0, facef(s, phi), None, None, None, None, w)
+    assert np.array_equal(back_face(s, w), fv.pos0(phi))
+    mesh.call("fv_linear_upwind_correction", facef(s, phi), *g, corr)
+    assert np.array_equal(back_face(s, corr), fv.linear_upwind_correction(m, phi, gref))
 
 
 @pytest.mark.parametrize("nc", [1, 3])
