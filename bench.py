@@ -180,6 +180,36 @@ def main():
         cpu = {"value": round(cell_steps / N, 6), "unit": "outer-iterations/s", "cores": 1, "kind": "port",
                "sample": "oracle/plume.py (numpy assembly + C solvers, 1 core): %d^3 cells, %d steps, %.2f s/step = %.3g cell-steps/s, "
                          "scaled by cell count to %d cells" % (cn, nst, cdt, cell_steps, N)}
+        # the linear-algebra kernels of the path on the host: Amul GB/s on one core, and the synthetic p_rgh PCG
+        # solve on one core against P block subdomains on P threads (block-Jacobi DIC, oracle/ffo_multi.c)
+        try:
+            import numpy as np
+            from oracle import oracle as OO, multi
+            H = ffm.hexmesh
+            sn = 160
+            blk = H.HexBlock((sn, sn, sn)); sy = H.synth_p_rgh(blk)
+            Ao = OO.Ldu(blk.nCells, blk.l, blk.u).set_coeffs(sy["diag"], sy["upper"])
+            xs = H.hash_u(0xF4, np.arange(blk.nCells))
+            Ao.amul(xs)
+            t1 = time.perf_counter(); reps = 5
+            for _ in range(reps):
+                Ao.amul(xs)
+            tsp = (time.perf_counter() - t1) / reps
+            cpu["spmv_GBps_1core"] = round((24 * blk.nCells + 16 * len(blk.l)) / tsp / 1e9, 2)
+            t1 = time.perf_counter()
+            _, pf1 = Ao.solve(OO.PCG, OO.DIC, np.zeros(blk.nCells), sy["source"], tolerance=1e-6, relTol=0.0)      # p_rghFinal controls
+            t1core = time.perf_counter() - t1
+            P = 8 if (os.cpu_count() or 1) >= 8 else (4 if (os.cpu_count() or 1) >= 4 else 2)
+            grid_c = {8: (2, 2, 2), 4: (2, 2, 1), 2: (2, 1, 1)}[P]
+            blocks, nbrRank, nbrPatch, ldus, srcs = multi.decomposed_case(H, (sn, sn, sn), grid_c)
+            t1 = time.perf_counter()
+            _, pfP = OO.solve_multi(ldus, nbrRank, nbrPatch, OO.PCG, OO.DIC, [np.zeros(b.nCells) for b in blocks], srcs, tolerance=1e-6, relTol=0.0)
+            tP = time.perf_counter() - t1
+            cpu["pcg_p_rgh_%d3" % sn] = {"one_core_s": round(t1core, 3), "iterations": pf1["nIterations"], "threads": P,
+                                         "threads_s": round(tP, 3), "threads_iterations": pfP[0]["nIterations"],
+                                         "speedup": round(t1core / tP, 2), "host_cores": os.cpu_count()}
+        except Exception as e:                            # the extra figures are informative; the contract fields above stand
+            cpu["extra_error"] = repr(e)
 
     if rank == 0:
         out = {

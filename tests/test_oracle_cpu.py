@@ -108,27 +108,9 @@ def test_renumbered_mesh_gives_same_dic_pcg(O, ffm):
     assert rel_l2(psi1, psi0[cOrd]) < 1e-13
 
 
-def _decomposed_case(O, ffm, glob, grid, asym=False):
-    H = ffm.hexmesh
-    blocks, nbrRank = H.decompose(glob, grid)
-    ldus, srcs = [], []
-    nbrPatch = []
-    for r, blk in enumerate(blocks):
-        s = H.synth_p_rgh(blk)
-        A = O.Ldu(blk.nCells, blk.l, blk.u).set_coeffs(s["diag"], s["upper"])
-        A.set_interfaces([i["faceCells"] for i in s["interfaces"]], s["bouCoeffs"])
-        ldus.append(A); srcs.append(s["source"])
-    for r, blk in enumerate(blocks):
-        pp = []
-        for q, itf in enumerate(blk.interfaces()):
-            other = blocks[nbrRank[r][q]].interfaces()
-            match = [k for k, o in enumerate(other) if o["dir"] == itf["dir"] and o["side"] != itf["side"]
-                     and nbrRank[nbrRank[r][q]][k] == r]
-            assert len(match) == 1
-            assert np.array_equal(other[match[0]]["gface"], itf["gface"])
-            pp.append(match[0])
-        nbrPatch.append(pp)
-    return blocks, nbrRank, nbrPatch, ldus, srcs
+def _decomposed_case(O, ffm, glob, grid):
+    from oracle import multi
+    return multi.decomposed_case(ffm.hexmesh, glob, grid)
 
 
 @pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
