@@ -1,0 +1,46 @@
+"""the reference's own equation files compile UNCHANGED against the Foam layer.
+
+examples/fireFoam_snippets.C is this repository's counterpart of solver/createFields.H + the loop of solver/fireFoam.C:97-119;
+inside that loop it `#include`s rhoEqn.H, UEqn.H, YEEqn.H and pEqn.H, and the build passes -I/root/reference/solver so that
+the files are the reference's, read where they lie (nothing is copied; the test is skipped where the reference is not mounted,
+e.g. on the GPU box, which receives the built library instead)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/solver"
+SNIPPETS = ["rhoEqn.H", "UEqn.H", "YEEqn.H", "pEqn.H"]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "UEqn.H")), reason="reference not mounted")
+
+
+def test_the_four_equation_files_are_the_references_and_compile_unchanged(tmp_path):
+    src = os.path.join(ROOT, "examples", "fireFoam_snippets.C")
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-H", "-I", os.path.join(ROOT, "include"), "-I", REF, src]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "error" not in r.stderr
+    included = [ln.strip(". \n") for ln in r.stderr.splitlines() if ln.startswith(".")]
+    for name in SNIPPETS:                                   # -H lists every file the translation unit pulled in
+        assert os.path.join(REF, name) in included, name
+    # pEqn.H includes rhoEqn.H again (solver/pEqn.H:48) and the OpenFOAM header compressibleContinuityErrs.H, which is ours
+    assert included.count(os.path.join(REF, "rhoEqn.H")) == 2
+    assert any(p.endswith("include/compressibleContinuityErrs.H") for p in included)
+    # nothing of the repository shadows or copies the reference's files
+    for name in SNIPPETS:
+        for base, _, files in os.walk(ROOT):
+            if ".git" in base or "gpurun_out" in base:
+                continue
+            assert name not in files, os.path.join(base, name)
+
+
+def test_the_library_built_from_them_exports_the_step():
+    import ctypes
+    import torch  # noqa: F401
+    from ffm_import import ffm
+    ffm.lib()
+    so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
+    assert os.path.exists(so), "run firefoam-dev_amd/csrc/Makefile (or __graft_entry__.build())"
+    assert hasattr(ctypes.CDLL(so), "firefoam_snippets_step")
