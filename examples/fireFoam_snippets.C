@@ -31,10 +31,10 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     // boundary conditions: value fraction f (-1 = inletOutlet: 1 - pos0(phi_b)), refValue; U: 3 components
     const double* fU; const double* refU; const double* fixesU;
     const double* fY; const double* const* refY; const double* fH; const double* refH;
-    const double* fluxMaskP; const double* totalMaskP; const double* ph_rgh_b;
+    const double* fluxMaskP; const double* totalMaskP; const double* ph_rgh_b; const double* p_rghB;
     // results
     double* rhoOut; double* UOut; double* pOut; double* p_rghOut; double* hOut; double* const* YOut; double* TOut; double* KOut;
-    double* dpdtOut; double* phiOutF; double* phiOutB; int* nIterOut; int nIterCap;
+    double* dpdtOut; double* phiOutF; double* phiOutB; double* p_rghBOut; int* nIterOut; int nIterCap;
 };
 
 extern "C" int firefoam_snippets_step(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, const snippetCase* cs)
@@ -85,8 +85,12 @@ extern "C" int firefoam_snippets_step(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh,
     U.fixesValue = std::make_shared<dField>(ctx, B); U.fixesValue->assignHost(cs->fixesU);
     surfaceScalarField phi(mesh);
     FFM_FOAM_CHK(ffm_faces_to_native(msh, cs->phiF, phi.v.data())); phi.b.assignHost(cs->phiB);
-    volScalarField p_rgh("p_rgh", mesh); p_rgh.v.assignHost(cs->p_rgh);
-    p_rgh.bc = zeroGradient();
+    // p_rgh: fixedFluxPressure where fluxMaskP = 1 (gradient from constrainPressure), prghTotalHydrostaticPressure where
+    // totalMaskP = 1 (value ph_rgh - 0.5*rho*(1 - pos0(phi))*|U|^2); boundary values as the last evaluate() left them
+    volScalarField p_rgh("p_rgh", mesh); p_rgh.v.assignHost(cs->p_rgh); p_rgh.b.assignHost(cs->p_rghB);
+    p_rgh.bc = std::make_shared<mixedBC>(ctx, B, cs->totalMaskP, zeroBh.data(), zeroBh.data());
+    p_rgh.bc->totalMask = std::make_shared<dField>(ctx, B); p_rgh.bc->totalMask->assignHost(cs->totalMaskP);
+    p_rgh.bc->ph_rgh_b = std::make_shared<dField>(ctx, B); p_rgh.bc->ph_rgh_b->assignHost(cs->ph_rgh_b);
     p_rgh.fixedFluxMask = std::make_shared<dField>(ctx, B); p_rgh.fixedFluxMask->assignHost(cs->fluxMaskP);
     volScalarField gh("gh", mesh); gh.v.assignHost(cs->gh);
     surfaceScalarField ghf(mesh);
@@ -112,12 +116,15 @@ extern "C" int firefoam_snippets_step(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh,
     const bool constD = false;
     scalar cumulativeContErr = 0;
 
+    // objects boundary conditions look up by name (inletOutlet: phi; prghTotalHydrostaticPressure: rho, U, phi)
+    mesh.store("phi", phi); mesh.store("rho", rho); mesh.store("U", U);
     thermo.correct();                                           // T, psi of the start state
+    U.correctBoundaryConditions(); thermo.he().correctBoundaryConditions();
+    forAll(Y, i) { Y[i].correctBoundaryConditions(); }
     // ---- runTime++: old-time levels
     rho.storeOldTime(); U.storeOldTime(); thermo.he().storeOldTime(); K.storeOldTime(); p.storeOldTime(); p_rgh.storeOldTime();
-    thermoObj.psi_.storeOldTime();
-    forAll(Y, i) { Y[i].correctBoundaryConditions(); Y[i].storeOldTime(); }
-    const surfaceScalarField phiOld("phi_0", phi);
+    thermoObj.psi_.storeOldTime(); phi.storeOldTime();
+    forAll(Y, i) { Y[i].storeOldTime(); }
 
     // ---- solver/fireFoam.C:97-119 -----------------------------------------------------------------------------------------
     #include "rhoEqn.H"
@@ -147,10 +154,10 @@ extern "C" int firefoam_snippets_step(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh,
     K.v.toHost(cs->KOut); dpdt.v.toHost(cs->dpdtOut);
     for (int d = 0; d < 3; d++) U.v[d].toHost(cs->UOut + (size_t)d*N);
     forAll(Y, i) { Y[i].v.toHost(cs->YOut[i]); }
-    FFM_FOAM_CHK(ffm_faces_from_native(msh, phi.v.data(), cs->phiOutF)); phi.b.toHost(cs->phiOutB);
+    FFM_FOAM_CHK(ffm_faces_from_native(msh, phi.v.data(), cs->phiOutF)); phi.b.toHost(cs->phiOutB); p_rgh.b.toHost(cs->p_rghBOut);
     FFM_FOAM_CHK(ffm_ctx_sync(ctx));
     int n = 0;
-    for (const solverPerformance& sp : mesh.log) if (n < cs->nIterCap) cs->nIterOut[n++] = sp.nIterations;
-    (void)psi; (void)phiOld; (void)inertIndex;
+    for (const solverPerformance& sp : mesh.log) if (sp.fieldName != "rho" && n < cs->nIterCap) cs->nIterOut[n++] = sp.nIterations;   // (diagonal solves left out)
+    (void)psi; (void)inertIndex;
     return n;
 }

@@ -188,6 +188,7 @@ extern "C" int ffm_field_binary(ffm_ctx *c, int op, long n, const double *a, con
     case FFM_OP_DIV: return field_launch(c, n, [=] __device__(long i) { return a[i] / b[i]; }, out);
     case FFM_OP_MAX: return field_launch(c, n, [=] __device__(long i) { return fmax(a[i], b[i]); }, out);
     case FFM_OP_MIN: return field_launch(c, n, [=] __device__(long i) { return fmin(a[i], b[i]); }, out);
+    case FFM_OP_NEGSEL: return field_launch(c, n, [=] __device__(long i) { return a[i] < 0.0 ? b[i] : a[i]; }, out);
     }
     return FFM_ERR_ARG;
 }
@@ -212,6 +213,7 @@ extern "C" int ffm_field_unary(ffm_ctx *c, int op, long n, const double *a, doub
     case FFM_UN_SQR: return field_launch(c, n, [=] __device__(long i) { return a[i] * a[i]; }, out);
     case FFM_UN_MAG: return field_launch(c, n, [=] __device__(long i) { return fabs(a[i]); }, out);
     case FFM_UN_SQRT: return field_launch(c, n, [=] __device__(long i) { return sqrt(a[i]); }, out);
+    case FFM_UN_POS0: return field_launch(c, n, [=] __device__(long i) { return a[i] >= 0.0 ? 1.0 : 0.0; }, out);
     }
     return FFM_ERR_ARG;
 }

@@ -80,8 +80,9 @@ int ffm_memset(ffm_ctx *ctx, void *dst_d, int value, size_t bytes);
 
 /* element-wise field algebra (Field<scalar> operators of the Foam layer): one pass per operator, like
  * OpenFOAM's own tmp-field evaluation, so an expression rounds the way the reference's does                        */
-enum { FFM_OP_ADD = 0, FFM_OP_SUB = 1, FFM_OP_MUL = 2, FFM_OP_DIV = 3, FFM_OP_MAX = 4, FFM_OP_MIN = 5 };
-enum { FFM_UN_NEG = 0, FFM_UN_SQR = 1, FFM_UN_MAG = 2, FFM_UN_SQRT = 3 };
+enum { FFM_OP_ADD = 0, FFM_OP_SUB = 1, FFM_OP_MUL = 2, FFM_OP_DIV = 3, FFM_OP_MAX = 4, FFM_OP_MIN = 5,
+       FFM_OP_NEGSEL = 6 /* a < 0 ? b : a  (a marker value selects the other operand) */ };
+enum { FFM_UN_NEG = 0, FFM_UN_SQR = 1, FFM_UN_MAG = 2, FFM_UN_SQRT = 3, FFM_UN_POS0 = 4 /* pos0(x) = x >= 0 ? 1 : 0 */ };
 int ffm_field_binary(ffm_ctx *ctx, int op, long n, const double *a_d, const double *b_d, double *out_d);
 /* out = a op s, or s op a when scalarFirst != 0 */
 int ffm_field_scalar(ffm_ctx *ctx, int op, long n, const double *a_d, double s, int scalarFirst, double *out_d);

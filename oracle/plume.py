@@ -223,6 +223,10 @@ class Plume:
         self.ph_rgh = ph
         self.ph_rgh_b = fv.MixedBC(m, f=bc.f).values(m, ph)
         self.p_rgh = ph.copy()
+        # stored_bc: p_rgh keeps the boundary values of its last evaluate() (GeometricField semantics, what the reference's
+        # snippets see through include/ffmFoam.H) instead of re-evaluating its conditions with a zero gradient in UEqn
+        self.stored_bc = False
+        self.p_rgh_b = [b.copy() for b in self.ph_rgh_b]
 
     # ---- one time step (solver/fireFoam.C:76-121) -----------------------------------------
     def rho_eqn(self):
@@ -256,7 +260,7 @@ class Plume:
         rhob = self.zg(self.rho)
         sgr, _ = fv.snGrad(m, self.rho, rhob)
         bcp = self.bc_p_rgh([np.zeros(p.size) for p in m.patches])
-        sgp, sgpb = fv.snGrad(m, self.p_rgh, bcp.values(m, self.p_rgh))
+        sgp, sgpb = fv.snGrad(m, self.p_rgh, self.p_rgh_b if self.stored_bc else bcp.values(m, self.p_rgh))
         rec = fv.reconstruct(m, (-self.ghf * sgr - sgp) * m.magSf, [-s * p.magSf for s, p in zip(sgpb, m.patches)])
         for c in range(3):
             d, s = UEqn.solve_system(c)
@@ -366,6 +370,7 @@ class Plume:
         E -= fv.fvm_laplacian(m, rhorAUf, rhorAUfb, [bcp])
         d, s = E.solve_system()
         self.p_rgh = self.sol.solve("p_rghFinal" if final else "p_rgh", "p_rgh", m, d, E.upper, E.lower, s, self.p_rgh)
+        self.p_rgh_b = bcp.values(m, self.p_rgh)
         fl, flb = E.flux(self.p_rgh)
         self.phi = phiHbyA + fl
         self.phib = [a + b for a, b in zip(phiHbyAb, flb)]

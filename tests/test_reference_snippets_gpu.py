@@ -1,0 +1,125 @@
+"""The reference's own solver/rhoEqn.H, UEqn.H, YEEqn.H and pEqn.H, compiled unchanged against include/ffmFoam.H +
+include/fireFoamHandles.H (examples/fireFoam_snippets.C, built where the reference is mounted; the library travels to the GPU
+box), run one time step of the synthetic plume case on the device and are compared with the oracle's time step
+(oracle/plume.py with GeometricField boundary-value semantics for p_rgh: stored_bc).  Two consecutive steps: the second starts
+from the first's results (non-zero flow, both correctors' flux updates, dynamic inletOutlet / total-pressure conditions).
+Bars: 1e-8 rel-L2 per field with identical iteration counts, as for the compiled plume driver (tests/test_plume_gpu.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from common import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+class SnippetCase(C.Structure):
+    dp, dpp = C.POINTER(C.c_double), C.POINTER(C.POINTER(C.c_double))
+    _fields_ = ([("deltaT", C.c_double)] + [(k, C.c_double) for k in ("RR", "Cp", "Tref", "pRef", "mu", "Pr", "sO2", "HC", "tau")]
+                + [(k, C.c_int) for k in ("nSpecies", "inertIndex", "fuelIndex", "o2Index")]
+                + [("W", dp), ("nu", dp)]
+                + [("rho", dp), ("U", dp), ("p", dp), ("p_rgh", dp), ("h", dp), ("Y", dpp)]
+                + [("K", dp), ("dpdt", dp), ("phiF", dp), ("phiB", dp)]
+                + [("gh", dp), ("ghfF", dp), ("ghfB", dp)]
+                + [("fU", dp), ("refU", dp), ("fixesU", dp)]
+                + [("fY", dp), ("refY", dpp), ("fH", dp), ("refH", dp)]
+                + [("fluxMaskP", dp), ("totalMaskP", dp), ("ph_rgh_b", dp), ("p_rghB", dp)]
+                + [("rhoOut", dp), ("UOut", dp), ("pOut", dp), ("p_rghOut", dp), ("hOut", dp), ("YOut", dpp), ("TOut", dp), ("KOut", dp)]
+                + [("dpdtOut", dp), ("phiOutF", dp), ("phiOutB", dp), ("p_rghBOut", dp), ("nIterOut", C.POINTER(C.c_int)), ("nIterCap", C.c_int)])
+
+
+def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
+    from oracle import plume
+    so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
+    if not os.path.exists(so):
+        pytest.skip("libffm_refsnippets.so not built (needs /root/reference at build time)")
+    lib = C.CDLL(so)
+    lib.firefoam_snippets_step.restype = C.c_int
+    lib.firefoam_snippets_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SnippetCase)]
+
+    ref = plume.Plume((10, 12, 9))
+    ref.stored_bc = True
+    m = ref.m
+    N, F = m.nCells, m.nFaces
+    B = sum(p.size for p in m.patches)
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    mesh.set_face_centres(m.Cf[fOrd].T.copy())
+
+    dp = C.POINTER(C.c_double)
+    h = lambda a: np.ascontiguousarray(a, np.float64)
+    keep = []
+
+    def P(a):
+        a = h(a); keep.append(a)
+        return a.ctypes.data_as(dp)
+
+    def PP(arrs):
+        arrs = [h(a) for a in arrs]; keep.append(arrs)
+        arr = (dp * len(arrs))(*[a.ctypes.data_as(dp) for a in arrs]); keep.append(arr)
+        return arr
+    cell = lambda a: np.asarray(a)[..., cOrd]
+    face = lambda a: np.asarray(a)[fOrd]
+    bnd = lambda lst: np.concatenate(lst)
+    per = lambda fn: bnd([fn(p) for p in m.patches])
+    is_open = lambda p: p.name not in ("inlet", "floor")
+    # boundary conditions in mixed form; f = -1: value fraction 1 - pos0(phi_b) (inletOutlet, tangential pressureInletOutletVelocity)
+    fU = np.concatenate([per(lambda p, d=d: np.where(np.abs(p.Sf[:, d]) > 0, 0.0, -1.0) if is_open(p) else np.ones(p.size)) for d in range(3)])
+    refU = np.concatenate([per(lambda p, d=d: np.full(p.size, plume.U_IN if (p.name == "inlet" and d == 1) else 0.0)) for d in range(3)])
+    fixesU = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0))
+    fY = per(lambda p: np.full(p.size, 1.0 if p.name == "inlet" else (0.0 if p.name == "floor" else -1.0)))
+    refY = [per(lambda p, i=i: np.full(p.size, plume.Y_IN[i] if p.name == "inlet" else (plume.Y_AMB[i] if is_open(p) else 0.0))) for i in range(5)]
+    fH = per(lambda p: np.full(p.size, -1.0 if is_open(p) else 1.0))
+    refH = per(lambda p: np.full(p.size, plume.CP * (plume.T_IN - plume.TREF) if p.name == "inlet" else 0.0))
+    fluxMask = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0))
+    totalMask = per(lambda p: np.full(p.size, 1.0 if is_open(p) else 0.0))
+    ghfb = bnd([p.Cf @ plume.G - ref.ghRef for p in m.patches])
+
+    for step in range(2):
+        out = dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), Y=[np.empty(N) for _ in range(5)],
+                   T=np.empty(N), K=np.empty(N), dpdt=np.empty(N), phi=np.empty(F), phib=np.empty(B), p_rghB=np.empty(B))
+        nit = (C.c_int * 32)()
+        cs = SnippetCase(
+            deltaT=ref.dt, RR=plume.RR, Cp=plume.CP, Tref=plume.TREF, pRef=plume.PREF, mu=plume.MU, Pr=plume.PR, sO2=plume.S_O2, HC=plume.HC,
+            tau=plume.TAU, nSpecies=5, inertIndex=plume.INERT, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
+            rho=P(cell(ref.rho)), U=P(cell(ref.U)), p=P(cell(ref.p)), p_rgh=P(cell(ref.p_rgh)), h=P(cell(ref.h)), Y=PP([cell(ref.Y[i]) for i in range(5)]),
+            K=P(cell(ref.K)), dpdt=P(cell(ref.dpdt)), phiF=P(face(ref.phi)), phiB=P(bnd(ref.phib)),
+            gh=P(cell(ref.gh)), ghfF=P(face(ref.ghf)), ghfB=P(ghfb),
+            fU=P(fU), refU=P(refU), fixesU=P(fixesU), fY=P(fY), refY=PP(refY), fH=P(fH), refH=P(refH),
+            fluxMaskP=P(fluxMask), totalMaskP=P(totalMask), ph_rgh_b=P(bnd(ref.ph_rgh_b)), p_rghB=P(bnd(ref.p_rgh_b)),
+            rhoOut=out["rho"].ctypes.data_as(dp), UOut=out["U"].ctypes.data_as(dp), pOut=out["p"].ctypes.data_as(dp),
+            p_rghOut=out["p_rgh"].ctypes.data_as(dp), hOut=out["h"].ctypes.data_as(dp),
+            TOut=out["T"].ctypes.data_as(dp), KOut=out["K"].ctypes.data_as(dp), dpdtOut=out["dpdt"].ctypes.data_as(dp),
+            phiOutF=out["phi"].ctypes.data_as(dp), phiOutB=out["phib"].ctypes.data_as(dp), p_rghBOut=out["p_rghB"].ctypes.data_as(dp),
+            nIterOut=nit, nIterCap=32)
+        yout = (dp * 5)(*[a.ctypes.data_as(dp) for a in out["Y"]]); keep.append(yout)
+        cs.YOut = yout
+        os.environ["FFM_FOAM_QUIET"] = "1"
+        n = lib.firefoam_snippets_step(ctx.h, A.h, mesh.h, C.byref(cs))
+        ref.step()
+        its_ref = [pf["nIterations"] for _, pf in ref.sol.log]
+        assert list(nit[:n]) == its_ref, (step, list(nit[:n]), its_ref)
+        inv = np.empty(N, np.int64); inv[cOrd] = np.arange(N)            # library order -> natural order
+        finv = np.empty(F, np.int64); finv[fOrd] = np.arange(F)
+        f = ref.fields()
+        got = {"rho": out["rho"], "p": out["p"], "T": out["T"], "h": out["h"], "K": out["K"], "Ux": out["U"][0], "Uy": out["U"][1], "Uz": out["U"][2]}
+        for i, sname in enumerate(plume.SPECIES):
+            got[sname] = out["Y"][i]
+        errs = {}
+        for name, a in got.items():
+            a, b = a[inv], f[name]
+            errs[name] = np.abs(a).max() if np.linalg.norm(b) < 1e-30 else rel_l2(a, b)
+        errs["p_rgh"] = np.linalg.norm(out["p_rgh"][inv] - f["p_rgh"]) / max(np.linalg.norm(f["p_rgh"] - f["p_rgh"].mean()), 1e-30)
+        errs["phi"] = np.linalg.norm(out["phi"][finv] - ref.phi) / max(np.linalg.norm(ref.phi), 1e-30)
+        errs["dpdt"] = np.linalg.norm(out["dpdt"][inv] - ref.dpdt) / max(np.linalg.norm(ref.dpdt), 1e-30)
+        errs["p_rgh_b"] = np.abs(out["p_rghB"] - bnd(ref.p_rgh_b)).max() / max(np.abs(bnd(ref.p_rgh_b)).max(), 1e-30)
+        tol = {"p_rgh": 1e-5, "dpdt": 1e-5, "phi": 1e-7, "p_rgh_b": 1e-5}
+        bad = {k: v for k, v in errs.items() if not v < tol.get(k, 1e-8)}
+        print("SNIPERRS", step, {k: float("%.3g" % v) for k, v in errs.items()})
+        assert not bad, (step, bad)
+    A.close()
