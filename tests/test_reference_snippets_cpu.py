@@ -1,7 +1,7 @@
 """the reference's own equation files compile UNCHANGED against the Foam layer.
 
 examples/fireFoam_snippets.C is this repository's counterpart of solver/createFields.H + the loop of solver/fireFoam.C:97-119;
-inside that loop it `#include`s rhoEqn.H, UEqn.H, YEEqn.H and pEqn.H, and the build passes -I/root/reference/solver so that
+inside that loop it `#include`s rhoEqn.H, UEqn.H, YEEqn.H and pEqn.H (and, in the start-up function, phrghEqn.H), and the build passes -I/root/reference/solver so that
 the files are the reference's, read where they lie (nothing is copied; the test is skipped where the reference is not mounted,
 e.g. on the GPU box, which receives the built library instead)."""
 import os
@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/solver"
-SNIPPETS = ["rhoEqn.H", "UEqn.H", "YEEqn.H", "pEqn.H"]
+SNIPPETS = ["rhoEqn.H", "UEqn.H", "YEEqn.H", "pEqn.H", "phrghEqn.H"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "UEqn.H")), reason="reference not mounted")
 
@@ -43,4 +43,5 @@ def test_the_library_built_from_them_exports_the_step():
     ffm.lib()
     so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
     assert os.path.exists(so), "run firefoam-dev_amd/csrc/Makefile (or __graft_entry__.build())"
-    assert hasattr(ctypes.CDLL(so), "firefoam_snippets_step")
+    lib = ctypes.CDLL(so)
+    assert hasattr(lib, "firefoam_snippets_step") and hasattr(lib, "firefoam_snippets_hydrostatic")

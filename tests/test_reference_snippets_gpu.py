@@ -80,6 +80,33 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
     totalMask = per(lambda p: np.full(p.size, 1.0 if is_open(p) else 0.0))
     ghfb = bnd([p.Cf @ plume.G - ref.ghRef for p in m.patches])
 
+    # ---- start-up: solver/phrghEqn.H (included unchanged) against the oracle's hydrostatic initialisation
+    lib.firefoam_snippets_hydrostatic.restype = C.c_int
+    lib.firefoam_snippets_hydrostatic.argtypes = lib.firefoam_snippets_step.argtypes
+    Yamb = [np.full(N, plume.Y_AMB[i]) for i in range(5)]
+    psi0 = 1.0 / (plume.RR * plume.TREF * sum(plume.Y_AMB[i] / plume.WMOL[i] for i in range(5)))
+    o = dict(rho=np.empty(N), p=np.empty(N), p_rgh=np.empty(N), p_rghB=np.empty(B))
+    dummyN, dummy3, dummyF, dummyB = np.zeros(N), np.zeros((3, N)), np.zeros(F), np.zeros(B)
+    nit = (C.c_int * 32)()
+    topMask = per(lambda p: np.full(p.size, 1.0 if p.name == "top" else 0.0))
+    cs = SnippetCase(
+        deltaT=ref.dt, RR=plume.RR, Cp=plume.CP, Tref=plume.TREF, pRef=plume.PREF, mu=plume.MU, Pr=plume.PR, sO2=plume.S_O2, HC=plume.HC,
+        tau=plume.TAU, nSpecies=5, inertIndex=plume.INERT, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
+        rho=P(np.full(N, psi0 * plume.PREF)), U=P(dummy3), p=P(np.full(N, plume.PREF)), p_rgh=P(dummyN), h=P(dummyN), Y=PP(Yamb),
+        K=P(dummyN), dpdt=P(dummyN), phiF=P(dummyF), phiB=P(dummyB), gh=P(cell(ref.gh)), ghfF=P(face(ref.ghf)), ghfB=P(ghfb),
+        fU=P(fU), refU=P(refU), fixesU=P(fixesU), fY=P(fY), refY=PP(refY), fH=P(fH), refH=P(refH),
+        fluxMaskP=P(1.0 - topMask), totalMaskP=P(topMask), ph_rgh_b=P(dummyB), p_rghB=P(dummyB),
+        rhoOut=o["rho"].ctypes.data_as(dp), pOut=o["p"].ctypes.data_as(dp), p_rghOut=o["p_rgh"].ctypes.data_as(dp),
+        p_rghBOut=o["p_rghB"].ctypes.data_as(dp), nIterOut=nit, nIterCap=32)
+    os.environ["FFM_FOAM_QUIET"] = "1"
+    n = lib.firefoam_snippets_hydrostatic(ctx.h, A.h, mesh.h, C.byref(cs))
+    init = plume.Plume((10, 12, 9))
+    its0 = [pf["nIterations"] for _, pf in init.sol.log]
+    inv0 = np.empty(N, np.int64); inv0[cOrd] = np.arange(N)
+    assert list(nit[:n]) == its0 and n == 5, (list(nit[:n]), its0)
+    assert rel_l2(o["p_rgh"][inv0], init.ph_rgh) < 1e-8 and rel_l2(o["p"][inv0], init.p) < 1e-13 and rel_l2(o["rho"][inv0], init.rho) < 1e-13
+    assert np.abs(o["p_rghB"] - bnd(init.ph_rgh_b)).max() <= 1e-8 * np.abs(bnd(init.ph_rgh_b)).max() + 1e-14
+
     for step in range(2):
         out = dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), Y=[np.empty(N) for _ in range(5)],
                    T=np.empty(N), K=np.empty(N), dpdt=np.empty(N), phi=np.empty(F), phib=np.empty(B), p_rghB=np.empty(B))
