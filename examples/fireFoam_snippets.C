@@ -37,159 +37,204 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     double* dpdtOut; double* phiOutF; double* phiOutB; double* p_rghBOut; int* nIterOut; int nIterCap;
 };
 
-// ---- what solver/createFields.H declares: fvSolution / fvSchemes of the synthetic case (cf. cases/steckler/system/fvSolution:19-101,
-// fvSchemes:28-61), thermo / composition / Y, the fields, the physics handles; objects boundary conditions look up by name are
-// registered with mesh.store() (inletOutlet: phi; prghTotalHydrostaticPressure: rho, U, phi)
-#define FIREFOAM_CREATE_FIELDS(cs)                                                                                            \
-    fvMesh mesh(ctx, ldu, msh, cs->deltaT); \
-    const label N = mesh.nCells, B = mesh.nBoundary; \
-    mesh.solvers["rho"] = mesh.solvers["rhoFinal"] = {FFM_DIAGONAL, FFM_NONE, 1e-6, 0, 0, 1000, 1}; \
-    mesh.solvers["U"] = mesh.solvers["UFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-6, 0, 0, 1000, 1}; \
-    mesh.solvers["Yi"] = mesh.solvers["YiFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-8, 0, 0, 1000, 1}; \
-    mesh.solvers["h"] = mesh.solvers["hFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-8, 0, 0, 1000, 1}; \
-    mesh.solvers["p_rgh"] = {FFM_PCG, FFM_DIC, 1e-6, 0.01, 0, 1000, 1}; \
-    mesh.solvers["p_rghFinal"] = {FFM_PCG, FFM_DIC, 1e-6, 0, 0, 1000, 1}; \
-    if (std::getenv("FFM_PLUME_TIGHT")) for (auto& kv : mesh.solvers) if (kv.second.solver != FFM_DIAGONAL) { kv.second.tolerance = 1e-13; kv.second.relTol = 0; } \
-    mesh.divSchemes["div(phi,U)"] = {4, 1, 0, 1}; \
-    mesh.divSchemes["div(phi,K)"] = {2, 1, 0, 1}; \
-    mesh.divSchemes["div(phiv,p)"] = {2, 1, 0, 1}; \
-    mesh.multivariateSelection["div(phi,Yi_h)"]["h"] = {2, 1, 0, 1}; \
-    pimpleDict pd; pd.nOuterCorrectors = 1; pd.nCorrectors = 2; pd.nNonOrthogonalCorrectors = 0; pd.hydrostaticInitialization = true; pd.nHydrostaticCorrectors = 5; \
-    pimpleControl pimple(mesh, pd); \
- \
-    std::vector<double> zeroBh(B, 0.0), oneBh(B, 1.0); \
-    auto zeroGradient = [&]() { return std::make_shared<mixedBC>(ctx, B, zeroBh.data(), zeroBh.data(), zeroBh.data()); }; \
-    perfectGasConstCpThermo thermoObj(mesh, cs->RR, cs->Cp, cs->Tref); \
-    psiReactionThermo& thermo = thermoObj; \
-    basicMultiComponentMixture& composition = thermo.composition(); \
-    PtrList<volScalarField>& Y = composition.Y(); \
-    static const char* specieNames[] = {"O2", "H2O", "C3H8", "CO2", "N2"}; \
-    for (label i = 0; i < cs->nSpecies; i++) { \
-        composition.species_.push_back(specieNames[i]); composition.active_.push_back(true); \
-        thermoObj.W_.push_back(cs->W[i]); \
-        Y.append(new volScalarField(specieNames[i], mesh)); \
-        Y[i].v.assignHost(cs->Y[i]); \
-        Y[i].bc = std::make_shared<mixedBC>(ctx, B, cs->fY, cs->refY[i], zeroBh.data()); \
-        mesh.multivariateSelection["div(phi,Yi_h)"][specieNames[i]] = {3, 1, 0, 1}; \
-    } \
-    const label inertIndex = cs->inertIndex; \
-    volScalarField& p = thermo.p(); p.v.assignHost(cs->p); p.b = mesh.patchInternal(p.v); \
-    volScalarField& T = thermo.T(); \
-    const volScalarField& psi = thermo.psi(); \
-    thermo.he().v.assignHost(cs->h); \
-    thermo.he().bc = std::make_shared<mixedBC>(ctx, B, cs->fH, cs->refH, zeroBh.data()); \
- \
-    volScalarField rho("rho", mesh); rho.v.assignHost(cs->rho); rho.bc = zeroGradient(); rho.correctBoundaryConditions(); \
-    volVectorField U("U", mesh); \
-    for (int d = 0; d < 3; d++) { U.v[d].assignHost(cs->U + (size_t)d*N); U.bc[d] = std::make_shared<mixedBC>(ctx, B, cs->fU + (size_t)d*B, cs->refU + (size_t)d*B, zeroBh.data()); } \
-    U.fixesValue = std::make_shared<dField>(ctx, B); U.fixesValue->assignHost(cs->fixesU); \
-    surfaceScalarField phi(mesh); \
-    FFM_FOAM_CHK(ffm_faces_to_native(msh, cs->phiF, phi.v.data())); phi.b.assignHost(cs->phiB); \
-    volScalarField p_rgh("p_rgh", mesh); p_rgh.v.assignHost(cs->p_rgh); p_rgh.b.assignHost(cs->p_rghB); \
-    p_rgh.bc = std::make_shared<mixedBC>(ctx, B, cs->totalMaskP, zeroBh.data(), zeroBh.data()); \
-    p_rgh.bc->totalMask = std::make_shared<dField>(ctx, B); p_rgh.bc->totalMask->assignHost(cs->totalMaskP); \
-    p_rgh.bc->ph_rgh_b = std::make_shared<dField>(ctx, B); p_rgh.bc->ph_rgh_b->assignHost(cs->ph_rgh_b); \
-    p_rgh.fixedFluxMask = std::make_shared<dField>(ctx, B); p_rgh.fixedFluxMask->assignHost(cs->fluxMaskP); \
-    volScalarField gh("gh", mesh); gh.v.assignHost(cs->gh); \
-    surfaceScalarField ghf(mesh); \
-    FFM_FOAM_CHK(ffm_faces_to_native(msh, cs->ghfF, ghf.v.data())); ghf.b.assignHost(cs->ghfB); \
-    const dimensionedScalar pRef("pRef", cs->pRef); \
-    volScalarField K("K", mesh); K.v.assignHost(cs->K); \
-    volScalarField dpdt("dpdt", mesh); dpdt.v.assignHost(cs->dpdt); \
-    volScalarField Qdot("Qdot", mesh); \
-    multivariateSurfaceInterpolationScheme<scalar>::fieldTable fields; \
-    forAll(Y, i) { fields.add(Y[i]); } \
-    fields.add(thermo.he()); \
- \
-    autoPtr<compressible::turbulenceModel> turbulence(new constantViscosity(mesh, cs->mu, cs->Pr)); \
-    std::vector<scalar> nu(cs->nu, cs->nu + cs->nSpecies); \
-    autoPtr<combustionModels::psiCombustionModel> combustion(new singleStepEDC(thermo, rho, cs->fuelIndex, cs->o2Index, cs->sO2, cs->tau, cs->HC, nu)); \
-    autoPtr<radiation::radiationModel> radiation(new noRadiation()); \
-    noParcels parcels(mesh); \
-    noSurfaceFilm surfaceFilm(mesh); \
-    noFvOptions fvOptions; \
-    noMRF MRF; \
-    const scalar lewisNo = 1; \
-    dimensionedScalar DM("DM", 0.0); \
-    const bool constD = false; \
-    scalar cumulativeContErr = 0; \
- \
-    mesh.store("phi", phi); mesh.store("rho", rho); mesh.store("U", U); \
-    (void)0
+// ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
+// step to the next: fvSolution / fvSchemes of the synthetic case (cf. cases/steckler/system/fvSolution:19-101, fvSchemes:28-61),
+// thermo / composition / Y, the fields, the physics handles.  Objects boundary conditions look up by name are registered with
+// mesh.store() (inletOutlet: phi; prghTotalHydrostaticPressure: rho, U, phi).  The member functions are the reference's loop:
+// inside them the members are in scope under the names the equation files use.
+struct snippetSolver
+{
+    ffm_ctx* ctx; ffm_mesh* msh;
+    fvMesh mesh;
+    const label N, B;
+    std::vector<double> zeroBh;
+    pimpleControl pimple;
+    perfectGasConstCpThermo thermoObj;
+    psiReactionThermo& thermo;
+    basicMultiComponentMixture& composition;
+    PtrList<volScalarField>& Y;
+    const label inertIndex;
+    volScalarField& p;
+    volScalarField& T;
+    const volScalarField& psi;
+    volScalarField rho;
+    volVectorField U;
+    surfaceScalarField phi;
+    volScalarField p_rgh, gh;
+    surfaceScalarField ghf;
+    const dimensionedScalar pRef;
+    volScalarField K, dpdt, Qdot;
+    multivariateSurfaceInterpolationScheme<scalar>::fieldTable fields;
+    autoPtr<compressible::turbulenceModel> turbulence;
+    autoPtr<combustionModels::psiCombustionModel> combustion;
+    autoPtr<radiation::radiationModel> radiation;
+    noParcels parcels;
+    noSurfaceFilm surfaceFilm;
+    noFvOptions fvOptions;
+    noMRF MRF;
+    const scalar lewisNo = 1;                                   // solver/readAdditionalThermo.H:32
+    dimensionedScalar DM;
+    const bool constD = false;
+    scalar cumulativeContErr = 0;
+    Time runTime;
 
+    static pimpleDict pimpleOf()
+    {
+        pimpleDict pd; pd.nOuterCorrectors = 1; pd.nCorrectors = 2; pd.nNonOrthogonalCorrectors = 0;      // fvSolution:84-92
+        pd.hydrostaticInitialization = true; pd.nHydrostaticCorrectors = 5;
+        return pd;
+    }
+    std::shared_ptr<mixedBC> zeroGradient() { return std::make_shared<mixedBC>(ctx, B, zeroBh.data(), zeroBh.data(), zeroBh.data()); }
+
+    snippetSolver(ffm_ctx* c, ffm_ldu* ldu, ffm_mesh* m, const snippetCase* cs)
+    : ctx(c), msh(m), mesh(c, ldu, m, cs->deltaT), N(mesh.nCells), B(mesh.nBoundary), zeroBh(B, 0.0), pimple(mesh, pimpleOf()),
+      thermoObj(mesh, cs->RR, cs->Cp, cs->Tref), thermo(thermoObj), composition(thermo.composition()), Y(composition.Y()),
+      inertIndex(cs->inertIndex), p(thermo.p()), T(thermo.T()), psi(thermo.psi()), rho("rho", mesh), U("U", mesh), phi(mesh),
+      p_rgh("p_rgh", mesh), gh("gh", mesh), ghf(mesh), pRef("pRef", cs->pRef), K("K", mesh), dpdt("dpdt", mesh), Qdot("Qdot", mesh),
+      parcels(mesh), surfaceFilm(mesh), DM("DM", 0.0), runTime(0)
+    {
+        mesh.solvers["rho"] = mesh.solvers["rhoFinal"] = {FFM_DIAGONAL, FFM_NONE, 1e-6, 0, 0, 1000, 1};
+        mesh.solvers["U"] = mesh.solvers["UFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-6, 0, 0, 1000, 1};
+        mesh.solvers["Yi"] = mesh.solvers["YiFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-8, 0, 0, 1000, 1};
+        mesh.solvers["h"] = mesh.solvers["hFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-8, 0, 0, 1000, 1};
+        mesh.solvers["p_rgh"] = mesh.solvers["ph_rgh"] = {FFM_PCG, FFM_DIC, 1e-6, 0.01, 0, 1000, 1};     // fvSolution:29-46
+        mesh.solvers["p_rghFinal"] = {FFM_PCG, FFM_DIC, 1e-6, 0, 0, 1000, 1};
+        if (std::getenv("FFM_PLUME_TIGHT")) for (auto& kv : mesh.solvers) if (kv.second.solver != FFM_DIAGONAL) { kv.second.tolerance = 1e-13; kv.second.relTol = 0; }
+        mesh.divSchemes["div(phi,U)"] = {4, 1, 0, 1};                                   // Gauss LUST grad(U)
+        mesh.divSchemes["div(phi,K)"] = {2, 1, 0, 1};                                   // Gauss limitedLinear 1
+        mesh.divSchemes["div(phiv,p)"] = {2, 1, 0, 1};
+        mesh.multivariateSelection["div(phi,Yi_h)"]["h"] = {2, 1, 0, 1};                // h limitedLinear 1
+        static const char* specieNames[] = {"O2", "H2O", "C3H8", "CO2", "N2"};
+        for (label i = 0; i < cs->nSpecies; i++) {
+            composition.species_.push_back(specieNames[i]); composition.active_.push_back(true);
+            thermoObj.W_.push_back(cs->W[i]);
+            Y.append(new volScalarField(specieNames[i], mesh));
+            Y[i].v.assignHost(cs->Y[i]);
+            Y[i].bc = std::make_shared<mixedBC>(ctx, B, cs->fY, cs->refY[i], zeroBh.data());
+            mesh.multivariateSelection["div(phi,Yi_h)"][specieNames[i]] = {3, 1, 0, 1};  // Yi limitedLinear01 1
+        }
+        p.v.assignHost(cs->p); p.b = mesh.patchInternal(p.v);
+        thermo.he().v.assignHost(cs->h);
+        thermo.he().bc = std::make_shared<mixedBC>(ctx, B, cs->fH, cs->refH, zeroBh.data());
+        rho.v.assignHost(cs->rho); rho.bc = zeroGradient(); rho.correctBoundaryConditions();
+        for (int d = 0; d < 3; d++) { U.v[d].assignHost(cs->U + (size_t)d*N); U.bc[d] = std::make_shared<mixedBC>(ctx, B, cs->fU + (size_t)d*B, cs->refU + (size_t)d*B, zeroBh.data()); }
+        U.fixesValue = std::make_shared<dField>(ctx, B); U.fixesValue->assignHost(cs->fixesU);
+        FFM_FOAM_CHK(ffm_faces_to_native(msh, cs->phiF, phi.v.data())); phi.b.assignHost(cs->phiB);
+        // p_rgh: fixedFluxPressure where fluxMaskP = 1 (gradient from constrainPressure), prghTotalHydrostaticPressure where
+        // totalMaskP = 1 (value ph_rgh - 0.5*rho*(1 - pos0(phi))*|U|^2); boundary values as the last evaluate() left them
+        p_rgh.v.assignHost(cs->p_rgh); p_rgh.b.assignHost(cs->p_rghB);
+        p_rgh.bc = std::make_shared<mixedBC>(ctx, B, cs->totalMaskP, zeroBh.data(), zeroBh.data());
+        p_rgh.bc->totalMask = std::make_shared<dField>(ctx, B); p_rgh.bc->totalMask->assignHost(cs->totalMaskP);
+        p_rgh.bc->ph_rgh_b = std::make_shared<dField>(ctx, B); p_rgh.bc->ph_rgh_b->assignHost(cs->ph_rgh_b);
+        p_rgh.fixedFluxMask = std::make_shared<dField>(ctx, B); p_rgh.fixedFluxMask->assignHost(cs->fluxMaskP);
+        gh.v.assignHost(cs->gh);
+        FFM_FOAM_CHK(ffm_faces_to_native(msh, cs->ghfF, ghf.v.data())); ghf.b.assignHost(cs->ghfB);
+        K.v.assignHost(cs->K); dpdt.v.assignHost(cs->dpdt);
+        forAll(Y, i) { fields.add(Y[i]); }
+        fields.add(thermo.he());
+        turbulence = autoPtr<compressible::turbulenceModel>(new constantViscosity(mesh, cs->mu, cs->Pr));
+        std::vector<scalar> nu(cs->nu, cs->nu + cs->nSpecies);
+        combustion = autoPtr<combustionModels::psiCombustionModel>(new singleStepEDC(thermo, rho, cs->fuelIndex, cs->o2Index, cs->sO2, cs->tau, cs->HC, nu));
+        radiation = autoPtr<radiation::radiationModel>(new noRadiation());
+        mesh.store("phi", phi); mesh.store("rho", rho); mesh.store("U", U);
+        thermo.correct();                                           // T, psi of the start state
+        U.correctBoundaryConditions(); thermo.he().correctBoundaryConditions();
+        forAll(Y, i) { Y[i].correctBoundaryConditions(); }
+    }
+
+    // one time step: solver/fireFoam.C:84,97-119 with the reference's equation files
+    void step()
+    {
+        mesh.log.clear();
+        // runTime++: old-time levels
+        rho.storeOldTime(); U.storeOldTime(); thermo.he().storeOldTime(); K.storeOldTime(); p.storeOldTime(); p_rgh.storeOldTime();
+        thermoObj.psi_.storeOldTime(); phi.storeOldTime();
+        forAll(Y, i) { Y[i].storeOldTime(); }
+
+        #include "rhoEqn.H"
+
+        // --- PIMPLE loop
+        while (pimple.loop())
+        {
+            #include "UEqn.H"
+            #include "YEEqn.H"
+
+            // --- Pressure corrector loop
+            while (pimple.correct())
+            {
+                #include "pEqn.H"
+            }
+
+            if (pimple.turbCorr())
+            {
+                turbulence->correct();
+            }
+        }
+
+        rho = thermo.rho();
+        FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    }
+
+    // solver/createFields.H:100-104 -> solver/phrghEqn.H: hydrostatic initialisation (nHydrostaticCorrectors solves of
+    // fvm::laplacian(rhof, ph_rgh) == fvc::div(phig)); the case's 0/ph_rgh: fixedValue 0 where topMask = 1, fixedFluxPressure elsewhere
+    void hydrostatic(const double* topMask, const double* fluxMask)
+    {
+        mesh.log.clear();
+        {
+            std::shared_ptr<volScalarField> f(new volScalarField("ph_rgh", mesh));
+            f->bc = std::make_shared<mixedBC>(ctx, B, topMask, zeroBh.data(), zeroBh.data());
+            f->fixedFluxMask = std::make_shared<dField>(ctx, B); f->fixedFluxMask->assignHost(fluxMask);
+            mesh.fieldFiles["ph_rgh"] = f;
+        }
+        thermo.correct();
+        rho = thermo.rho();
+
+        #include "phrghEqn.H"
+
+        FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    }
+
+    void download(const snippetCase* cs, bool all)
+    {
+        rho.v.toHost(cs->rhoOut); p.v.toHost(cs->pOut); p_rgh.v.toHost(cs->p_rghOut); p_rgh.b.toHost(cs->p_rghBOut);
+        if (!all) return;
+        thermo.he().v.toHost(cs->hOut); T.v.toHost(cs->TOut); K.v.toHost(cs->KOut); dpdt.v.toHost(cs->dpdtOut);
+        for (int d = 0; d < 3; d++) U.v[d].toHost(cs->UOut + (size_t)d*N);
+        forAll(Y, i) { Y[i].v.toHost(cs->YOut[i]); }
+        FFM_FOAM_CHK(ffm_faces_from_native(msh, phi.v.data(), cs->phiOutF)); phi.b.toHost(cs->phiOutB);
+    }
+    int iterations(const snippetCase* cs, bool skipRho)
+    {
+        int n = 0;
+        for (const solverPerformance& sp : mesh.log) if (!(skipRho && sp.fieldName == "rho") && n < cs->nIterCap) cs->nIterOut[n++] = sp.nIterations;
+        return n;
+    }
+};
+
+// ---- C entry points -------------------------------------------------------------------------------------------------------
+extern "C" snippetSolver* firefoam_snippets_create(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, const snippetCase* cs) { return new snippetSolver(ctx, ldu, msh, cs); }
+extern "C" void firefoam_snippets_destroy(snippetSolver* s) { delete s; }
+// one time step on the device-resident state; returns the number of linear solves (iteration counts in cs->nIterOut, diagonal
+// solves left out); results are downloaded only if download != 0
+extern "C" int firefoam_snippets_advance(snippetSolver* s, const snippetCase* cs, int download)
+{
+    s->step();
+    if (download) s->download(cs, true);
+    return s->iterations(cs, true);
+}
 extern "C" int firefoam_snippets_step(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, const snippetCase* cs)
 {
-    FIREFOAM_CREATE_FIELDS(cs);
-    thermo.correct();                                           // T, psi of the start state
-    U.correctBoundaryConditions(); thermo.he().correctBoundaryConditions();
-    forAll(Y, i) { Y[i].correctBoundaryConditions(); }
-    // ---- runTime++: old-time levels
-    rho.storeOldTime(); U.storeOldTime(); thermo.he().storeOldTime(); K.storeOldTime(); p.storeOldTime(); p_rgh.storeOldTime();
-    thermoObj.psi_.storeOldTime(); phi.storeOldTime();
-    forAll(Y, i) { Y[i].storeOldTime(); }
-
-    // ---- solver/fireFoam.C:97-119 -----------------------------------------------------------------------------------------
-    #include "rhoEqn.H"
-
-    // --- PIMPLE loop
-    while (pimple.loop())
-    {
-        #include "UEqn.H"
-        #include "YEEqn.H"
-
-        // --- Pressure corrector loop
-        while (pimple.correct())
-        {
-            #include "pEqn.H"
-        }
-
-        if (pimple.turbCorr())
-        {
-            turbulence->correct();
-        }
-    }
-
-    rho = thermo.rho();
-
-    // ---- results
-    rho.v.toHost(cs->rhoOut); p.v.toHost(cs->pOut); p_rgh.v.toHost(cs->p_rghOut); thermo.he().v.toHost(cs->hOut); T.v.toHost(cs->TOut);
-    K.v.toHost(cs->KOut); dpdt.v.toHost(cs->dpdtOut);
-    for (int d = 0; d < 3; d++) U.v[d].toHost(cs->UOut + (size_t)d*N);
-    forAll(Y, i) { Y[i].v.toHost(cs->YOut[i]); }
-    FFM_FOAM_CHK(ffm_faces_from_native(msh, phi.v.data(), cs->phiOutF)); phi.b.toHost(cs->phiOutB); p_rgh.b.toHost(cs->p_rghBOut);
-    FFM_FOAM_CHK(ffm_ctx_sync(ctx));
-    int n = 0;
-    for (const solverPerformance& sp : mesh.log) if (sp.fieldName != "rho" && n < cs->nIterCap) cs->nIterOut[n++] = sp.nIterations;   // (diagonal solves left out)
-    (void)psi; (void)inertIndex;
-    return n;
+    snippetSolver s(ctx, ldu, msh, cs);
+    s.step();
+    s.download(cs, true);
+    return s.iterations(cs, true);
 }
-
-
-// solver/createFields.H:100-104 -> solver/phrghEqn.H, the reference's file included unchanged: hydrostatic initialisation
-// (nHydrostaticCorrectors solves of fvm::laplacian(rhof, ph_rgh) == fvc::div(phig)).  Inputs: p (uniform pRef), h, Y, U = 0;
-// ph_rgh "file": fixedValue 0 where totalMaskP = 1 (the top), fixedFluxPressure where fluxMaskP = 1.
-// Results: p_rghOut (= ph_rgh), pOut, rhoOut, p_rghBOut (boundary values of ph_rgh).
+// inputs: p (uniform pRef), h, Y, U = 0; totalMaskP = the fixedValue-0 patch of ph_rgh (the top), fluxMaskP = its fixedFluxPressure
+// patches.  Results: p_rghOut (= ph_rgh), pOut, rhoOut, p_rghBOut (boundary values of ph_rgh)
 extern "C" int firefoam_snippets_hydrostatic(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, const snippetCase* cs)
 {
-    FIREFOAM_CREATE_FIELDS(cs);
-    mesh.solvers["ph_rgh"] = {FFM_PCG, FFM_DIC, 1e-6, 0.01, 0, 1000, 1};           // cases/steckler/system/fvSolution:43-46
-    if (std::getenv("FFM_PLUME_TIGHT")) { mesh.solvers["ph_rgh"].tolerance = 1e-13; mesh.solvers["ph_rgh"].relTol = 0; }
-    Time runTime(0);
-    {
-        std::shared_ptr<volScalarField> f(new volScalarField("ph_rgh", mesh));
-        f->bc = std::make_shared<mixedBC>(ctx, B, cs->totalMaskP, zeroBh.data(), zeroBh.data());
-        f->fixedFluxMask = std::make_shared<dField>(ctx, B); f->fixedFluxMask->assignHost(cs->fluxMaskP);
-        mesh.fieldFiles["ph_rgh"] = f;                                              // the case's 0/ph_rgh
-    }
-    thermo.correct();
-    rho = thermo.rho();
-
-    #include "phrghEqn.H"
-
-    rho.v.toHost(cs->rhoOut); p.v.toHost(cs->pOut); p_rgh.v.toHost(cs->p_rghOut); p_rgh.b.toHost(cs->p_rghBOut);
-    FFM_FOAM_CHK(ffm_ctx_sync(ctx));
-    int n = 0;
-    for (const solverPerformance& sp : mesh.log) if (n < cs->nIterCap) cs->nIterOut[n++] = sp.nIterations;
-    (void)psi; (void)inertIndex; (void)T; (void)N; (void)lewisNo; (void)constD; (void)cumulativeContErr; (void)fvOptions; (void)MRF;
-    return n;
+    snippetSolver s(ctx, ldu, msh, cs);
+    s.hydrostatic(cs->totalMaskP, cs->fluxMaskP);
+    s.download(cs, false);
+    return s.iterations(cs, false);
 }

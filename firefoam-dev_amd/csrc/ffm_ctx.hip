@@ -47,6 +47,7 @@ extern "C" int ffm_ctx_destroy(ffm_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     ffm_comm_finalize_i(c);
+    ffm_ctx_trim(c);
     hipFree(c->scal_d); hipFree(c->partials_d); hipHostFree(c->scal_h);
     if (c->ownStream) hipStreamDestroy(c->stream);
     delete c;
@@ -56,10 +57,48 @@ extern "C" int ffm_ctx_destroy(ffm_ctx *c)
 extern "C" int ffm_ctx_sync(ffm_ctx *c) { FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK; }
 extern "C" void *ffm_ctx_stream(ffm_ctx *c) { return (void *)c->stream; }
 
+static inline size_t pool_class(size_t bytes) { return bytes <= 256 ? 256 : ((bytes + 4095) & ~(size_t)4095); }
+extern "C" int ffm_ctx_trim(ffm_ctx *c)
+{
+    if (!c) return FFM_ERR_ARG;
+    FFM_HIP(hipSetDevice(c->device));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    for (auto &kv : c->poolFree) for (void *q : kv.second) { c->poolSize.erase(q); hipFree(q); }
+    c->poolFree.clear(); c->poolCachedBytes = 0;
+    return FFM_OK;
+}
 extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p)
-{ FFM_HIP(hipSetDevice(c->device)); FFM_HIP(hipMalloc(p, bytes ? bytes : 8)); return FFM_OK; }
+{
+    if (!c || !p) return FFM_ERR_ARG;
+    const size_t cls = pool_class(bytes);
+    auto it = c->poolFree.find(cls);
+    if (it != c->poolFree.end() && !it->second.empty()) {
+        *p = it->second.back(); it->second.pop_back(); c->poolCachedBytes -= cls;
+        FFM_HIP(hipMemsetAsync(*p, 0, cls, c->stream));          // as fresh memory: the padding slots of face arrays must read 0
+        return FFM_OK;
+    }
+    FFM_HIP(hipSetDevice(c->device));
+    if (hipMalloc(p, cls) != hipSuccess) {                       // out of memory: give the cached blocks back and try once more
+        (void)hipGetLastError();
+        FFM_TRY(ffm_ctx_trim(c));
+        FFM_HIP(hipMalloc(p, cls));
+    }
+    c->poolSize[*p] = cls;
+    FFM_HIP(hipMemsetAsync(*p, 0, cls, c->stream));
+    return FFM_OK;
+}
 extern "C" int ffm_free(ffm_ctx *c, void *p)
-{ FFM_HIP(hipStreamSynchronize(c->stream)); FFM_HIP(hipFree(p)); return FFM_OK; }
+{
+    if (!c) return FFM_ERR_ARG;
+    if (!p) return FFM_OK;
+    auto it = c->poolSize.find(p);
+    if (it == c->poolSize.end()) { FFM_HIP(hipStreamSynchronize(c->stream)); FFM_HIP(hipFree(p)); return FFM_OK; }   // not ours
+    if (c->poolCachedBytes + it->second > c->poolCapBytes) {
+        FFM_HIP(hipStreamSynchronize(c->stream)); FFM_HIP(hipFree(p)); c->poolSize.erase(it); return FFM_OK;
+    }
+    c->poolFree[it->second].push_back(p); c->poolCachedBytes += it->second;
+    return FFM_OK;
+}
 extern "C" int ffm_memcpy_h2d(ffm_ctx *c, void *d, const void *s, size_t n)
 { FFM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK; }
 extern "C" int ffm_memcpy_d2h(ffm_ctx *c, void *d, const void *s, size_t n)

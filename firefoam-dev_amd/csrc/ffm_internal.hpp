@@ -8,6 +8,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <unordered_map>
 
 #include "../../include/ffm.h"
 
@@ -64,6 +65,13 @@ struct ffm_ctx {
     ffm_host_exchange_fn hostExchange = nullptr;
     ffm_host_exchange2_fn hostExchange2 = nullptr;
     int cuCount = 256;
+    // stream-ordered caching allocator behind ffm_malloc / ffm_free (the Foam layer makes one temporary per operator):
+    // a freed block goes to the free list of its size class without synchronising -- every consumer runs on `stream`, so a
+    // later owner's kernels are ordered after the previous owner's -- and is handed out again by the next ffm_malloc of that
+    // class; ffm_ctx_trim / ffm_ctx_destroy return the cached blocks to the runtime
+    std::unordered_map<size_t, std::vector<void *>> poolFree;
+    std::unordered_map<void *, size_t> poolSize;
+    size_t poolCachedBytes = 0, poolCapBytes = (size_t)96 << 30;
 };
 
 struct SweepGraphKey {

@@ -73,6 +73,10 @@ const char *ffm_version(void);
  * OpenFOAM shim) can hold fields on the GPU                                  */
 int ffm_malloc(ffm_ctx *ctx, size_t bytes, void **ptr_d);
 int ffm_free(ffm_ctx *ctx, void *ptr_d);
+/* ffm_malloc / ffm_free go through a stream-ordered caching allocator (freed blocks are reused by later allocations of the same
+ * size class on the context stream, without synchronising; every block is handed out zero-filled); ffm_ctx_trim returns the cached
+ * blocks to the runtime */
+int ffm_ctx_trim(ffm_ctx *ctx);
 int ffm_memcpy_h2d(ffm_ctx *ctx, void *dst_d, const void *src, size_t bytes);
 int ffm_memcpy_d2h(ffm_ctx *ctx, void *dst, const void *src_d, size_t bytes);
 int ffm_memcpy_d2d(ffm_ctx *ctx, void *dst_d, const void *src_d, size_t bytes);

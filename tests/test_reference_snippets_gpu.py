@@ -94,7 +94,7 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
         tau=plume.TAU, nSpecies=5, inertIndex=plume.INERT, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
         rho=P(np.full(N, psi0 * plume.PREF)), U=P(dummy3), p=P(np.full(N, plume.PREF)), p_rgh=P(dummyN), h=P(dummyN), Y=PP(Yamb),
         K=P(dummyN), dpdt=P(dummyN), phiF=P(dummyF), phiB=P(dummyB), gh=P(cell(ref.gh)), ghfF=P(face(ref.ghf)), ghfB=P(ghfb),
-        fU=P(fU), refU=P(refU), fixesU=P(fixesU), fY=P(fY), refY=PP(refY), fH=P(fH), refH=P(refH),
+        fU=P(fU), refU=P(np.zeros_like(refU)), fixesU=P(fixesU), fY=P(fY), refY=PP(refY), fH=P(fH), refH=P(refH),      # U_b = 0 at t = 0
         fluxMaskP=P(1.0 - topMask), totalMaskP=P(topMask), ph_rgh_b=P(dummyB), p_rghB=P(dummyB),
         rhoOut=o["rho"].ctypes.data_as(dp), pOut=o["p"].ctypes.data_as(dp), p_rghOut=o["p_rgh"].ctypes.data_as(dp),
         p_rghBOut=o["p_rghB"].ctypes.data_as(dp), nIterOut=nit, nIterCap=32)
@@ -107,10 +107,11 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
     assert rel_l2(o["p_rgh"][inv0], init.ph_rgh) < 1e-8 and rel_l2(o["p"][inv0], init.p) < 1e-13 and rel_l2(o["rho"][inv0], init.rho) < 1e-13
     assert np.abs(o["p_rghB"] - bnd(init.ph_rgh_b)).max() <= 1e-8 * np.abs(bnd(init.ph_rgh_b)).max() + 1e-14
 
-    for step in range(2):
-        out = dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), Y=[np.empty(N) for _ in range(5)],
-                   T=np.empty(N), K=np.empty(N), dpdt=np.empty(N), phi=np.empty(F), phib=np.empty(B), p_rghB=np.empty(B))
-        nit = (C.c_int * 32)()
+    def new_out():
+        return dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), Y=[np.empty(N) for _ in range(5)],
+                    T=np.empty(N), K=np.empty(N), dpdt=np.empty(N), phi=np.empty(F), phib=np.empty(B), p_rghB=np.empty(B))
+
+    def case_of(ref, out, nit):
         cs = SnippetCase(
             deltaT=ref.dt, RR=plume.RR, Cp=plume.CP, Tref=plume.TREF, pRef=plume.PREF, mu=plume.MU, Pr=plume.PR, sO2=plume.S_O2, HC=plume.HC,
             tau=plume.TAU, nSpecies=5, inertIndex=plume.INERT, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
@@ -126,6 +127,31 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
             nIterOut=nit, nIterCap=32)
         yout = (dp * 5)(*[a.ctypes.data_as(dp) for a in out["Y"]]); keep.append(yout)
         cs.YOut = yout
+        return cs
+
+    # ---- the state stays on the device: create once, advance three steps, download once
+    lib.firefoam_snippets_create.restype = C.c_void_p
+    lib.firefoam_snippets_create.argtypes = lib.firefoam_snippets_step.argtypes
+    lib.firefoam_snippets_advance.restype = C.c_int
+    lib.firefoam_snippets_advance.argtypes = [C.c_void_p, C.POINTER(SnippetCase), C.c_int]
+    lib.firefoam_snippets_destroy.argtypes = [C.c_void_p]
+    ref3 = plume.Plume((10, 12, 9)); ref3.stored_bc = True
+    out3, nit3 = new_out(), (C.c_int * 32)()
+    cs3 = case_of(ref3, out3, nit3)
+    solver = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(cs3))
+    for k in range(3):
+        n3 = lib.firefoam_snippets_advance(solver, C.byref(cs3), 1 if k == 2 else 0)
+        ref3.step()
+        assert list(nit3[:n3]) == [pf["nIterations"] for _, pf in ref3.sol.log], k
+    lib.firefoam_snippets_destroy(solver)
+    f3 = ref3.fields()
+    for name, a in (("rho", out3["rho"]), ("T", out3["T"]), ("Ux", out3["U"][0]), ("Uy", out3["U"][1]), ("Uz", out3["U"][2]), ("C3H8", out3["Y"][2])):
+        assert rel_l2(a[inv0], f3[name]) < 1e-8, (name, rel_l2(a[inv0], f3[name]))
+
+    for step in range(2):
+        out = new_out()
+        nit = (C.c_int * 32)()
+        cs = case_of(ref, out, nit)
         os.environ["FFM_FOAM_QUIET"] = "1"
         n = lib.firefoam_snippets_step(ctx.h, A.h, mesh.h, C.byref(cs))
         ref.step()
