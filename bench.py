@@ -53,6 +53,10 @@ def main():
     ndev = torch.cuda.device_count()
     dev = local % max(ndev, 1)
     torch.cuda.set_device(dev)
+    if world > 1 and args.transport == "rccl" and world > max(ndev, 1):
+        # more ranks than devices (a rehearsal on a smaller box): RCCL refuses two ranks on one device, use the host transport
+        sys.stderr.write("bench.py: %d ranks on %d device(s): falling back to --transport host\n" % (world, ndev))
+        args.transport = "host"
     if world > 1:
         if args.transport == "rccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
