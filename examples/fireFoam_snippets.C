@@ -35,6 +35,8 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     // results
     double* rhoOut; double* UOut; double* pOut; double* p_rghOut; double* hOut; double* const* YOut; double* TOut; double* KOut;
     double* dpdtOut; double* phiOutF; double* phiOutB; double* p_rghBOut; int* nIterOut; int nIterCap;
+    // fvDOM stand-in (0 = no radiation model): 32 rays, directions / solid angles optional (NULL: built from nPhi 2, nTheta 4)
+    int radiationFreq; double kAbs, sigmaSB; const double* dAve; const double* omega; double* GOut;
 };
 
 // ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
@@ -135,7 +137,12 @@ struct snippetSolver
         turbulence = autoPtr<compressible::turbulenceModel>(new constantViscosity(mesh, cs->mu, cs->Pr));
         std::vector<scalar> nu(cs->nu, cs->nu + cs->nSpecies);
         combustion = autoPtr<combustionModels::psiCombustionModel>(new singleStepEDC(thermo, rho, cs->fuelIndex, cs->o2Index, cs->sO2, cs->tau, cs->HC, nu));
-        radiation = autoPtr<radiation::radiationModel>(new noRadiation());
+        if (cs->radiationFreq > 0) {
+            mesh.divSchemes["div(Ji,Ii_h)"] = {0, 1, 0, 1};                                     // Gauss upwind (fvSchemes:60)
+            mesh.solvers["Ii"] = mesh.solvers["IiFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-4, 0, 0, 1000, 1};
+            radiation = autoPtr<radiation::radiationModel>(new fvDOMStandIn(mesh, T, 2, 4, cs->radiationFreq, cs->kAbs, cs->sigmaSB, cs->Tref, cs->dAve, cs->omega));
+        }
+        else radiation = autoPtr<radiation::radiationModel>(new noRadiation());
         mesh.store("phi", phi); mesh.store("rho", rho); mesh.store("U", U);
         thermo.correct();                                           // T, psi of the start state
         U.correctBoundaryConditions(); thermo.he().correctBoundaryConditions();
@@ -202,6 +209,7 @@ struct snippetSolver
         for (int d = 0; d < 3; d++) U.v[d].toHost(cs->UOut + (size_t)d*N);
         forAll(Y, i) { Y[i].v.toHost(cs->YOut[i]); }
         FFM_FOAM_CHK(ffm_faces_from_native(msh, phi.v.data(), cs->phiOutF)); phi.b.toHost(cs->phiOutB);
+        if (cs->radiationFreq > 0 && cs->GOut) static_cast<fvDOMStandIn&>(radiation()).G_.v.toHost(cs->GOut);
     }
     int iterations(const snippetCase* cs, bool skipRho)
     {

@@ -687,6 +687,7 @@ extern "C" const double *ffm_mesh_geometry_d(const ffm_mesh *m, int which)
     switch (which) {
     case 0: return m->V; case 1: return m->magSf; case 2: return m->delta; case 3: return m->w; case 4: return m->bMagSf; case 5: return m->bDelta;
     case 6: return m->bSf[0]; case 7: return m->bSf[1]; case 8: return m->bSf[2];
+    case 9: return m->Sf[0]; case 10: return m->Sf[1]; case 11: return m->Sf[2]; case 12: return m->C[0]; case 13: return m->C[1]; case 14: return m->C[2];
     }
     return nullptr;
 }

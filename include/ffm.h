@@ -232,7 +232,8 @@ int ffm_mesh_set_face_centres(ffm_mesh *mesh, const double *Cf);
 int ffm_mesh_destroy(ffm_mesh *mesh);
 int ffm_mesh_nboundary(const ffm_mesh *mesh);
 /* device geometry fields for the Foam layer: 0 V[N], 1 magSf[nNative], 2 deltaCoeffs[nNative], 3 weights[nNative],
- * 4 boundary magSf[B], 5 boundary deltaCoeffs[B], 6-8 boundary Sf x,y,z [B]                                 */
+ * 4 boundary magSf[B], 5 boundary deltaCoeffs[B], 6-8 boundary Sf x,y,z [B], 9-11 Sf x,y,z of the internal faces [nNative],
+ * 12-14 cell centres x,y,z [N]                                                                                 */
 const double *ffm_mesh_geometry_d(const ffm_mesh *mesh, int which);
 int ffm_mesh_nnative(const ffm_mesh *mesh);
 int ffm_faces_to_native(const ffm_mesh *mesh, const double *lduOrder, double *native_d);

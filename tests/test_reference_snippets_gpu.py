@@ -27,7 +27,8 @@ class SnippetCase(C.Structure):
                 + [("fY", dp), ("refY", dpp), ("fH", dp), ("refH", dp)]
                 + [("fluxMaskP", dp), ("totalMaskP", dp), ("ph_rgh_b", dp), ("p_rghB", dp)]
                 + [("rhoOut", dp), ("UOut", dp), ("pOut", dp), ("p_rghOut", dp), ("hOut", dp), ("YOut", dpp), ("TOut", dp), ("KOut", dp)]
-                + [("dpdtOut", dp), ("phiOutF", dp), ("phiOutB", dp), ("p_rghBOut", dp), ("nIterOut", C.POINTER(C.c_int)), ("nIterCap", C.c_int)])
+                + [("dpdtOut", dp), ("phiOutF", dp), ("phiOutB", dp), ("p_rghBOut", dp), ("nIterOut", C.POINTER(C.c_int)), ("nIterCap", C.c_int)]
+                + [("radiationFreq", C.c_int), ("kAbs", C.c_double), ("sigmaSB", C.c_double), ("dAve", dp), ("omega", dp), ("GOut", dp)])
 
 
 def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
@@ -147,6 +148,17 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
     f3 = ref3.fields()
     for name, a in (("rho", out3["rho"]), ("T", out3["T"]), ("Ux", out3["U"][0]), ("Uy", out3["U"][1]), ("Uz", out3["U"][2]), ("C3H8", out3["Y"][2])):
         assert rel_l2(a[inv0], f3[name]) < 1e-8, (name, rel_l2(a[inv0], f3[name]))
+
+    # ---- with the fvDOM stand-in as the radiation handle: radiation->correct() of solver/YEEqn.H:80 solves the 32 rays
+    refR = plume.Plume((10, 12, 9)); refR.stored_bc = True; refR.set_radiation(solverFreq=1)
+    outR, nitR, G = new_out(), (C.c_int * 64)(), np.empty(N)
+    csR = case_of(refR, outR, nitR)
+    csR.nIterCap = 64; csR.radiationFreq = 1; csR.kAbs = plume.K_ABS; csR.sigmaSB = plume.SIGMA_SB
+    csR.dAve = P(np.concatenate([d for d, _ in refR.rays])); csR.omega = P(np.array([o for _, o in refR.rays])); csR.GOut = G.ctypes.data_as(dp)
+    nR = lib.firefoam_snippets_step(ctx.h, A.h, mesh.h, C.byref(csR))
+    refR.step()
+    assert list(nitR[:nR]) == [pf["nIterations"] for _, pf in refR.sol.log] and nR == 10 + 32
+    assert rel_l2(G[inv0], refR.G) < 1e-10 and rel_l2(outR["T"][inv0], refR.T) < 1e-10
 
     for step in range(2):
         out = new_out()
