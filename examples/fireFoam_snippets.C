@@ -37,6 +37,9 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     double* dpdtOut; double* phiOutF; double* phiOutB; double* p_rghBOut; int* nIterOut; int nIterCap;
     // fvDOM stand-in (0 = no radiation model): 32 rays, directions / solid angles optional (NULL: built from nPhi 2, nTheta 4)
     int radiationFreq; double kAbs, sigmaSB; const double* dAve; const double* omega; double* GOut;
+    // psiB != NULL: compressibility on the boundary faces (patch-face mixtures differing from the cells', e.g. the steckler
+    // case's start state); the thermo object then keeps them and rho_b = psi_b*p_b.  resOut: {initial, final} residual per solve
+    const double* psiB; double* resOut;
 };
 
 // ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
@@ -116,6 +119,7 @@ struct snippetSolver
             mesh.multivariateSelection["div(phi,Yi_h)"][specieNames[i]] = {3, 1, 0, 1};  // Yi limitedLinear01 1
         }
         p.v.assignHost(cs->p); p.b = mesh.patchInternal(p.v);
+        if (cs->psiB) { thermoObj.zeroGradientBoundaries_ = false; thermoObj.psi_.b.assignHost(cs->psiB); }
         thermo.he().v.assignHost(cs->h);
         thermo.he().bc = std::make_shared<mixedBC>(ctx, B, cs->fH, cs->refH, zeroBh.data());
         rho.v.assignHost(cs->rho); rho.bc = zeroGradient(); rho.correctBoundaryConditions();
@@ -129,7 +133,7 @@ struct snippetSolver
         p_rgh.bc->totalMask = std::make_shared<dField>(ctx, B); p_rgh.bc->totalMask->assignHost(cs->totalMaskP);
         p_rgh.bc->ph_rgh_b = std::make_shared<dField>(ctx, B); p_rgh.bc->ph_rgh_b->assignHost(cs->ph_rgh_b);
         p_rgh.fixedFluxMask = std::make_shared<dField>(ctx, B); p_rgh.fixedFluxMask->assignHost(cs->fluxMaskP);
-        gh.v.assignHost(cs->gh);
+        gh.v.assignHost(cs->gh); gh.b.assignHost(cs->ghfB);
         FFM_FOAM_CHK(ffm_faces_to_native(msh, cs->ghfF, ghf.v.data())); ghf.b.assignHost(cs->ghfB);
         K.v.assignHost(cs->K); dpdt.v.assignHost(cs->dpdt);
         forAll(Y, i) { fields.add(Y[i]); }
@@ -214,7 +218,10 @@ struct snippetSolver
     int iterations(const snippetCase* cs, bool skipRho)
     {
         int n = 0;
-        for (const solverPerformance& sp : mesh.log) if (!(skipRho && sp.fieldName == "rho") && n < cs->nIterCap) cs->nIterOut[n++] = sp.nIterations;
+        for (const solverPerformance& sp : mesh.log) if (!(skipRho && sp.fieldName == "rho") && n < cs->nIterCap) {
+            if (cs->resOut) { cs->resOut[2*n] = sp.initialResidual; cs->resOut[2*n + 1] = sp.finalResidual; }
+            cs->nIterOut[n++] = sp.nIterations;
+        }
         return n;
     }
 };

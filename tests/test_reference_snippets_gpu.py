@@ -28,7 +28,8 @@ class SnippetCase(C.Structure):
                 + [("fluxMaskP", dp), ("totalMaskP", dp), ("ph_rgh_b", dp), ("p_rghB", dp)]
                 + [("rhoOut", dp), ("UOut", dp), ("pOut", dp), ("p_rghOut", dp), ("hOut", dp), ("YOut", dpp), ("TOut", dp), ("KOut", dp)]
                 + [("dpdtOut", dp), ("phiOutF", dp), ("phiOutB", dp), ("p_rghBOut", dp), ("nIterOut", C.POINTER(C.c_int)), ("nIterCap", C.c_int)]
-                + [("radiationFreq", C.c_int), ("kAbs", C.c_double), ("sigmaSB", C.c_double), ("dAve", dp), ("omega", dp), ("GOut", dp)])
+                + [("radiationFreq", C.c_int), ("kAbs", C.c_double), ("sigmaSB", C.c_double), ("dAve", dp), ("omega", dp), ("GOut", dp)]
+                + [("psiB", dp), ("resOut", dp)])
 
 
 def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
@@ -187,4 +188,72 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
         bad = {k: v for k, v in errs.items() if not v < tol.get(k, 1e-8)}
         print("SNIPERRS", step, {k: float("%.3g" % v) for k, v in errs.items()})
         assert not bad, (step, bad)
+    A.close()
+
+
+def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx):
+    """The reference's solver/phrghEqn.H, included unchanged, run on the reference's steckler case (30 x 15 x 20 cells, the
+    compartment baffles and doorway, ph_rgh fixedValue 0 on `top` and fixedFluxPressure elsewhere, the boundary mixtures of the
+    case files: oracle/steckler.py) through the Foam layer on the device: every operator of the file (fvc::interpolate, snGrad,
+    constrainPressure, fvm::laplacian, fvc::div, the DICPCG solve, thermo.rho()) is this repository's device code, and the five
+    solves reproduce the reference's golden log (cases/steckler/original/linux64/log.fireFoam:92-101): iteration counts
+    29, 32, 7, 0, 0 and every printed residual and gMax-gMin to 1e-6."""
+    import json
+    from oracle import plume, steckler
+    so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
+    if not os.path.exists(so):
+        pytest.skip("libffm_refsnippets.so not built (needs /root/reference at build time)")
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "steckler_ph_rgh.json")))["solves"]
+    lib = C.CDLL(so)
+    lib.firefoam_snippets_hydrostatic.restype = C.c_int
+    lib.firefoam_snippets_hydrostatic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SnippetCase)]
+    m = steckler.build_mesh()
+    N, F = m.nCells, m.nFaces
+    B = sum(p.size for p in m.patches)
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    dp = C.POINTER(C.c_double)
+    keep = []
+
+    def P(a):
+        a = np.ascontiguousarray(a, np.float64); keep.append(a)
+        return a.ctypes.data_as(dp)
+
+    def PP(arrs):
+        arrs = [np.ascontiguousarray(a, np.float64) for a in arrs]; keep.append(arrs)
+        arr = (dp * len(arrs))(*[a.ctypes.data_as(dp) for a in arrs]); keep.append(arr)
+        return arr
+    per = lambda fn: np.concatenate([fn(p) for p in m.patches])
+    # the case data of oracle/steckler.py (each item cites the reference's case file there)
+    g = np.array([0.0, -9.81, 0.0]); ghRef = -np.linalg.norm(g) * 3.0
+    gh, ghf, ghb = m.C @ g - ghRef, m.Cf @ g - ghRef, per(lambda p: p.Cf @ g - ghRef)
+    Wbaffle = 1.0 / (0.232 / 31.9988 + 0.768 / 28.0134)
+    psib = per(lambda p: np.full(p.size, 1.0 / ((steckler.RR / Wbaffle) * 300.0) if p.name.startswith("baffle") else 1.0 / ((steckler.RR / 31.9988) * 298.15)))
+    Wmix = 1.0 / (0.23301 / 31.9988 + 0.76699 / 28.0134)
+    psi = 1.0 / ((steckler.RR / Wmix) * 298.15)
+    Y = [np.full(N, v) for v in (0.23301, 0.0, 0.0, 0.0, 0.76699)]
+    topMask = per(lambda p: np.full(p.size, 1.0 if p.name == "top" else 0.0))
+    zN, z3, zF, zB = np.zeros(N), np.zeros((3, N)), np.zeros(F), np.zeros(B)
+    o = dict(rho=np.empty(N), p=np.empty(N), p_rgh=np.empty(N), p_rghB=np.empty(B))
+    nit, res = (C.c_int * 8)(), np.zeros(16)
+    cs = SnippetCase(
+        deltaT=1.0, RR=steckler.RR, Cp=plume.CP, Tref=298.15, pRef=101325.0, mu=plume.MU, Pr=plume.PR, sO2=plume.S_O2, HC=plume.HC, tau=plume.TAU,
+        nSpecies=5, inertIndex=4, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
+        rho=P(np.full(N, psi * 101325.0)), U=P(z3), p=P(np.full(N, 101325.0)), p_rgh=P(zN), h=P(zN), Y=PP(Y), K=P(zN), dpdt=P(zN), phiF=P(zF), phiB=P(zB),
+        gh=P(gh[cOrd]), ghfF=P(ghf[fOrd]), ghfB=P(ghb),
+        fU=P(np.ones(3 * B)), refU=P(np.zeros(3 * B)), fixesU=P(np.ones(B)), fY=P(zB), refY=PP([zB] * 5), fH=P(zB), refH=P(zB),
+        fluxMaskP=P(1.0 - topMask), totalMaskP=P(topMask), ph_rgh_b=P(zB), p_rghB=P(zB),
+        rhoOut=o["rho"].ctypes.data_as(dp), pOut=o["p"].ctypes.data_as(dp), p_rghOut=o["p_rgh"].ctypes.data_as(dp), p_rghBOut=o["p_rghB"].ctypes.data_as(dp),
+        nIterOut=nit, nIterCap=8, psiB=P(psib), resOut=res.ctypes.data_as(dp))
+    os.environ["FFM_FOAM_QUIET"] = "1"
+    n = lib.firefoam_snippets_hydrostatic(ctx.h, A.h, mesh.h, C.byref(cs))
+    assert n == 5 and list(nit[:5]) == [g_["nIterations"] for g_ in gold] == [29, 32, 7, 0, 0], list(nit[:n])
+    for k, g_ in enumerate(gold):
+        assert abs(res[2 * k] - g_["initialResidual"]) <= 1e-6 * g_["initialResidual"], (k, res[2 * k], g_["initialResidual"])
+        assert abs(res[2 * k + 1] - g_["finalResidual"]) <= 1e-6 * g_["finalResidual"], (k, res[2 * k + 1], g_["finalResidual"])
+    variation = o["p_rgh"].max() - o["p_rgh"].min()
+    assert abs(variation - gold[-1]["variation"]) <= 1e-6 * gold[-1]["variation"], variation
     A.close()
