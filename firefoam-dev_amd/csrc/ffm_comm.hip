@@ -49,7 +49,9 @@ extern "C" int ffm_comm_init(ffm_ctx *c, int rank, int nRanks, const void *uniqu
 {
     if (!c || rank < 0 || nRanks < 1 || rank >= nRanks) return FFM_ERR_ARG;
     c->rank = rank; c->nRanks = nRanks;
-    if (nRanks == 1) return FFM_OK;
+    // a single rank needs no communicator; FFM_FORCE_COMM=1 creates one anyway so that the RCCL calls of the halo exchange
+    // (send / receive to itself) and of the reductions run on a one-GPU box (tests/test_rccl_single_rank_gpu.py)
+    if (nRanks == 1 && !(uniqueId128 && getenv("FFM_FORCE_COMM"))) return FFM_OK;
     if (!uniqueId128) return FFM_ERR_ARG;
     FFM_HIP(hipSetDevice(c->device));
     ncclUniqueId id; memcpy(&id, uniqueId128, sizeof(id));
@@ -77,7 +79,7 @@ extern "C" int ffm_comm_size(const ffm_ctx *c) { return c ? c->nRanks : FFM_ERR_
 
 int ffm_allreduce_slots(ffm_ctx *c, int firstSlot, int n)
 {
-    if (c->nRanks <= 1) return FFM_OK;
+    if (c->nRanks <= 1 && !c->comm) return FFM_OK;
     if (c->comm) {
         FFM_NCCL(ncclAllReduce(c->scal_d + firstSlot, c->scal_d + firstSlot, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
         return FFM_OK;
@@ -93,7 +95,7 @@ int ffm_allreduce_slots(ffm_ctx *c, int firstSlot, int n)
 
 int ffm_allreduce_minmax(ffm_ctx *c, int slot, int isMax)
 {
-    if (c->nRanks <= 1) return FFM_OK;
+    if (c->nRanks <= 1 && !c->comm) return FFM_OK;
     if (c->comm) {
         FFM_NCCL(ncclAllReduce(c->scal_d + slot, c->scal_d + slot, 1, ncclDouble, isMax ? ncclMax : ncclMin, (ncclComm_t)c->comm, c->stream));
         return FFM_OK;

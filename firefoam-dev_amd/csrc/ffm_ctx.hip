@@ -186,7 +186,7 @@ static int reduce_public(ffm_ctx *c, const double *x, const double *y, long n, d
 {
     if (!c || !out || n < 0) return FFM_ERR_ARG;
     FFM_TRY(reduce_to_slot<OP>(c, x, y, n, S_TMP0));
-    if (c->nRanks > 1) {
+    if (c->nRanks > 1 || c->comm) {
         if (OP == R_MIN) FFM_TRY(ffm_allreduce_minmax(c, S_TMP0, 0));
         else if (OP == R_MAX) FFM_TRY(ffm_allreduce_minmax(c, S_TMP0, 1));
         else FFM_TRY(ffm_allreduce_slots(c, S_TMP0, 1));

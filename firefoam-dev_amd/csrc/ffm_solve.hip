@@ -84,7 +84,7 @@ static int scalar_op(ffm_ctx *c, int op, double arg = 0.0, int iter = 0)
 // local sum sits in S_TMP0(..S_TMP0+n-1): all-reduce over ranks, then derive
 static int finish_dot(ffm_ctx *c, int op, int nSlots = 1, double arg = 0.0, int iter = 0)
 {
-    if (c->nRanks > 1) FFM_TRY(ffm_allreduce_slots(c, S_TMP0, nSlots));
+    if (c->nRanks > 1 || c->comm) FFM_TRY(ffm_allreduce_slots(c, S_TMP0, nSlots));
     return scalar_op(c, op, arg, iter);
 }
 

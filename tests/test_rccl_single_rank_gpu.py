@@ -1,0 +1,65 @@
+"""The RCCL transport on real hardware, as far as a one-GPU box allows: a ONE-rank RCCL communicator (FFM_FORCE_COMM=1) under
+the ghost-cell exchange and the reductions.  The rank is its own neighbour on both ends of a 1-D chain, so ncclGroupStart /
+ncclSend / ncclRecv / ncclGroupEnd move real data (rank 0 -> rank 0) and ncclAllReduce runs inside every dot product of the
+solver.  What this checks is the call sequence, counts, types, stream and buffer offsets of csrc/ffm_comm.hip -- the multi-GPU
+runs themselves are the driver's."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ghost_exchange_and_allreduce_through_a_one_rank_rccl_communicator(O, ffm):
+    os.environ["FFM_FORCE_COMM"] = "1"
+    try:
+        ctx = ffm.Context(0)
+        ctx.comm_init_rccl(0, 1, ffm.Context.comm_unique_id())
+    finally:
+        del os.environ["FFM_FORCE_COMM"]
+    L = ffm.lib()
+    N = 300
+    # chain 0-1-...-(N-1) plus two ghost cells: N next to cell 0, N+1 next to cell N-1; faces in upper-triangular order
+    faces = sorted([(i, i + 1) for i in range(N - 1)] + [(0, N), (N - 1, N + 1)])
+    l = np.array([f[0] for f in faces], np.int32); u = np.array([f[1] for f in faces], np.int32)
+    h = C.c_void_p()
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    assert L.ffm_ldu_create_ext(ctx.h, N, 2, len(l), ip(l), ip(u), C.byref(h)) == 0, L.ffm_last_error()
+    A = ffm.lduMatrix.__new__(ffm.lduMatrix)
+    A.ctx, A.h, A.nCells, A.nFaces = ctx, h, N + 2, len(l)
+    assert A.native_order
+    # both neighbours are rank 0: message 1 = cell 0, message 2 = cell N-1; receives are matched in order, so ghost N gets
+    # cell 0 and ghost N+1 gets cell N-1
+    nbr = np.array([0, 0], np.int32); cnt = np.array([1, 1], np.int32); send = np.array([0, N - 1], np.int32)
+    assert L.ffm_ldu_set_ghost_exchange(h, 2, ip(nbr), ip(cnt), ip(send), ip(cnt)) == 0, L.ffm_last_error()
+    rng = lambda seed, n: O.hash_u(seed, np.arange(n))
+    upper = -(0.5 + rng(1, len(l)))
+    diag = np.zeros(N + 2)
+    np.add.at(diag, l, -upper); np.add.at(diag, u, -upper); diag[:N] += 0.3
+    A.set_coeffs(diag, upper)
+    # the operator the rank sees: ghost columns are copies of their source cells
+    src = np.arange(N + 2); src[N] = 0; src[N + 1] = N - 1
+    M = np.zeros((N, N))
+    M[np.arange(N), np.arange(N)] = diag[:N]
+    for f, (a, b) in enumerate(zip(l, u)):
+        M[a, src[b]] += upper[f]
+        if b < N:
+            M[b, a] += upper[f]
+    x = rng(2, N + 2); x[N:] = 1e300                        # ghosts hold rubbish until the exchange
+    y = A.Amul(ctx.to_device(x)).cpu().numpy()
+    assert np.abs(y[:N] - M @ x[:N]).max() <= 1e-13 * np.abs(M @ x[:N]).max()
+    b = np.zeros(N + 2); b[:N] = rng(3, N) - 0.5
+    psi = ctx.zeros(N + 2)
+    perf = A.solve(psi, ctx.to_device(b), solver="PCG", preconditioner="DIC", tolerance=1e-12, relTol=0.0)
+    assert perf["converged"]
+    ref = np.linalg.solve(M, b[:N])
+    assert np.linalg.norm(psi.cpu().numpy()[:N] - ref) <= 1e-9 * np.linalg.norm(ref)
+    # reductions through ncclAllReduce (sum over one rank = the local value)
+    out = C.c_double()
+    xd = ctx.to_device(x[:N].copy())
+    assert L.ffm_reduce_sum(ctx.h, C.c_void_p(xd.data_ptr()), N, C.byref(out)) == 0
+    assert abs(out.value - x[:N].sum()) <= 1e-12 * abs(x[:N].sum())
+    assert L.ffm_reduce_max(ctx.h, C.c_void_p(xd.data_ptr()), N, C.byref(out)) == 0 and out.value == x[:N].max()
+    A.close(); ctx.close()
