@@ -63,3 +63,23 @@ def test_ghost_exchange_and_allreduce_through_a_one_rank_rccl_communicator(O, ff
     assert abs(out.value - x[:N].sum()) <= 1e-12 * abs(x[:N].sum())
     assert L.ffm_reduce_max(ctx.h, C.c_void_p(xd.data_ptr()), N, C.byref(out)) == 0 and out.value == x[:N].max()
     A.close(); ctx.close()
+
+
+def test_plume_step_with_every_reduction_through_rccl(O, ffm):
+    """a whole time step of the plume case on a context whose reductions all go through ncclAllReduce (one rank): every solver's
+    dot products, normalisation factors and residual norms, multi-slot all-reduces included -- bitwise the same fields and the
+    same iteration counts as without a communicator"""
+    plain = ffm.Context(0)
+    os.environ["FFM_FORCE_COMM"] = "1"
+    try:
+        viaRccl = ffm.Context(0)
+        viaRccl.comm_init_rccl(0, 1, ffm.Context.comm_unique_id())
+    finally:
+        del os.environ["FFM_FORCE_COMM"]
+    a, b = ffm.Plume(plain, (10, 12, 9)), ffm.Plume(viaRccl, (10, 12, 9))
+    for _ in range(2):
+        a.step(); b.step()
+        assert [(n, p["nIterations"]) for n, p in a.solves()] == [(n, p["nIterations"]) for n, p in b.solves()]
+    for name in ("rho", "p", "p_rgh", "T", "Ux", "Uy", "Uz", "C3H8", "O2"):
+        assert np.array_equal(a.field(name), b.field(name)), name
+    a.close(); b.close(); plain.close(); viaRccl.close()
