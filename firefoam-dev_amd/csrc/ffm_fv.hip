@@ -161,12 +161,23 @@ extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, con
         }
         for (int k = 0; k < B; k++) { const double sv[3] = {bS[0][k], bS[1][k], bS[2][k]}; addT(bc[k], sv, bM[k]); }
         std::vector<double> inv((size_t)6 * N, 0.0);
+        // 2-D / 1-D meshes (empty patches): the tensor has no entries in the missing directions.  As OpenFOAM's inv(tensorField)
+        // does, the missing directions are found from the first cell (diagonal entry negligible against the tensor's magnitude),
+        // 1 is added on those diagonals before the inversion and taken off again afterwards
+        bool rm[3] = {false, false, false};
+        if (N > 0) {
+            const double t0[6] = {T[0], T[(size_t)N], T[(size_t)2 * N], T[(size_t)3 * N], T[(size_t)4 * N], T[(size_t)5 * N]};
+            const double scale = t0[0] * t0[0] + 2 * t0[1] * t0[1] + 2 * t0[2] * t0[2] + t0[3] * t0[3] + 2 * t0[4] * t0[4] + t0[5] * t0[5];
+            if (scale > 0) { rm[0] = t0[0] * t0[0] / scale < 1e-15; rm[1] = t0[3] * t0[3] / scale < 1e-15; rm[2] = t0[5] * t0[5] / scale < 1e-15; }
+        }
         for (int c = 0; c < N; c++) {
-            const double a = T[c], b = T[(size_t)N + c], cc = T[(size_t)2 * N + c], d = T[(size_t)3 * N + c], e = T[(size_t)4 * N + c], f = T[(size_t)5 * N + c];
+            const double a = T[c] + (rm[0] ? 1.0 : 0.0), b = T[(size_t)N + c], cc = T[(size_t)2 * N + c], d = T[(size_t)3 * N + c] + (rm[1] ? 1.0 : 0.0),
+                         e = T[(size_t)4 * N + c], f = T[(size_t)5 * N + c] + (rm[2] ? 1.0 : 0.0);
             const double det = a * (d * f - e * e) - b * (b * f - e * cc) + cc * (b * e - d * cc);
-            if (det == 0) continue;     // degenerate (2-D / 1-D column): reconstruct returns 0 in the missing directions
-            inv[c] = (d * f - e * e) / det; inv[(size_t)N + c] = (cc * e - b * f) / det; inv[(size_t)2 * N + c] = (b * e - cc * d) / det;
-            inv[(size_t)3 * N + c] = (a * f - cc * cc) / det; inv[(size_t)4 * N + c] = (b * cc - a * e) / det; inv[(size_t)5 * N + c] = (a * d - b * b) / det;
+            if (det == 0) continue;     // a cell without faces (ghost cells): reconstruct returns 0 there
+            inv[c] = (d * f - e * e) / det - (rm[0] ? 1.0 : 0.0); inv[(size_t)N + c] = (cc * e - b * f) / det; inv[(size_t)2 * N + c] = (b * e - cc * d) / det;
+            inv[(size_t)3 * N + c] = (a * f - cc * cc) / det - (rm[1] ? 1.0 : 0.0); inv[(size_t)4 * N + c] = (b * cc - a * e) / det;
+            inv[(size_t)5 * N + c] = (a * d - b * b) / det - (rm[2] ? 1.0 : 0.0);
         }
         if ((rc = up(m->ctx, &m->invT, inv))) return rc;
     }

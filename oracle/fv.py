@@ -234,7 +234,12 @@ def reconstruct(mesh, ssf, bssf):
         for b_ in range(3):
             T[:, a, b_] = surface_sum(mesh, mesh.Sf[:, a] * mesh.Sf[:, b_] / mesh.magSf,
                                       [p.Sf[:, a] * p.Sf[:, b_] / p.magSf for p in mesh.patches])
-    return np.einsum("nab,nb->na", np.linalg.inv(T), v)
+    # 2-D / 1-D meshes (empty patches): OpenFOAM's inv(tensorField) finds the missing directions from the first cell, adds 1 on
+    # those diagonals before inverting and takes it off afterwards (src/OpenFOAM/fields/Fields/symmTensorField/symmTensorField.C)
+    scale = (T[0] ** 2).sum()
+    rm = np.array([T[0, a, a] ** 2 / scale < 1e-15 for a in range(3)], dtype=float) if scale > 0 else np.zeros(3)
+    E = np.diag(rm)
+    return np.einsum("nab,nb->na", np.linalg.inv(T + E) - E, v)
 
 
 def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):

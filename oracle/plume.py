@@ -42,7 +42,9 @@ T_IN, U_IN = 600.0, 0.5
 G = np.array([0.0, -9.81, 0.0])
 
 
-def make_mesh(n, h=0.05):
+def make_mesh(n, h=0.05, empty=()):
+    """empty: boundary groups left out of every patch, i.e. OpenFOAM's `empty` patches of a 2-D case (their faces take part in
+    no operator; cases/wallFireSpread2D/system/blockMeshDict:41 is one cell thick in x)"""
     nx, ny, nz = n
     m = fv.HexMesh(n, (0, 0, 0), (nx * h, ny * h, nz * h))
     # split ymin into inlet (central patch, 1 m^2 or the central quarter on small boxes) and floor
@@ -54,7 +56,7 @@ def make_mesh(n, h=0.05):
     for name, sel in (("inlet_part", isin), ("floor_part", ~isin)):
         m._bdefs[name] = fv.Patch(name, ymin.faceCells[sel], ymin.Sf[sel], ymin.Cf[sel], ymin.deltaCoeffs[sel])
     m.set_patches([("inlet", ["inlet_part"]), ("floor", ["floor_part"]), ("top", ["ymax"]),
-                   ("sides", ["xmin", "xmax", "zmin", "zmax"])])
+                   ("sides", [g for g in ("xmin", "xmax", "zmin", "zmax") if g not in empty])])
     return m
 
 
@@ -115,8 +117,8 @@ def ray_set(nPhi=2, nTheta=4):
 
 
 class Plume:
-    def __init__(self, n, h=0.05, dt=1e-3, solvers=None):
-        self.m = m = make_mesh(n, h)
+    def __init__(self, n, h=0.05, dt=1e-3, solvers=None, mesh=None):
+        self.m = m = mesh if mesh is not None else make_mesh(n, h)
         self.dt, self.rDeltaT = dt, 1.0 / dt
         self.sol = solvers or Solvers()
         N = m.nCells

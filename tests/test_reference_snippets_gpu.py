@@ -32,8 +32,11 @@ class SnippetCase(C.Structure):
                 + [("psiB", dp), ("resOut", dp)])
 
 
-def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
+@pytest.mark.parametrize("shape,empty", [((10, 12, 9), ()), ((1, 24, 20), ("xmin", "xmax"))])
+def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
+    """second case: a 2-D mesh, one cell thick with `empty` x-patches (the shape of cases/wallFireSpread2D, BASELINE config 5)"""
     from oracle import plume
+    newPlume = lambda: plume.Plume(shape, mesh=plume.make_mesh(shape, empty=empty))
     so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
     if not os.path.exists(so):
         pytest.skip("libffm_refsnippets.so not built (needs /root/reference at build time)")
@@ -41,7 +44,7 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
     lib.firefoam_snippets_step.restype = C.c_int
     lib.firefoam_snippets_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SnippetCase)]
 
-    ref = plume.Plume((10, 12, 9))
+    ref = newPlume()
     ref.stored_bc = True
     m = ref.m
     N, F = m.nCells, m.nFaces
@@ -102,7 +105,7 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
         p_rghBOut=o["p_rghB"].ctypes.data_as(dp), nIterOut=nit, nIterCap=32)
     os.environ["FFM_FOAM_QUIET"] = "1"
     n = lib.firefoam_snippets_hydrostatic(ctx.h, A.h, mesh.h, C.byref(cs))
-    init = plume.Plume((10, 12, 9))
+    init = newPlume()
     its0 = [pf["nIterations"] for _, pf in init.sol.log]
     inv0 = np.empty(N, np.int64); inv0[cOrd] = np.arange(N)
     assert list(nit[:n]) == its0 and n == 5, (list(nit[:n]), its0)
@@ -137,7 +140,7 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
     lib.firefoam_snippets_advance.restype = C.c_int
     lib.firefoam_snippets_advance.argtypes = [C.c_void_p, C.POINTER(SnippetCase), C.c_int]
     lib.firefoam_snippets_destroy.argtypes = [C.c_void_p]
-    ref3 = plume.Plume((10, 12, 9)); ref3.stored_bc = True
+    ref3 = newPlume(); ref3.stored_bc = True
     out3, nit3 = new_out(), (C.c_int * 32)()
     cs3 = case_of(ref3, out3, nit3)
     solver = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(cs3))
@@ -148,10 +151,10 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx):
     lib.firefoam_snippets_destroy(solver)
     f3 = ref3.fields()
     for name, a in (("rho", out3["rho"]), ("T", out3["T"]), ("Ux", out3["U"][0]), ("Uy", out3["U"][1]), ("Uz", out3["U"][2]), ("C3H8", out3["Y"][2])):
-        assert rel_l2(a[inv0], f3[name]) < 1e-8, (name, rel_l2(a[inv0], f3[name]))
+        assert rel_l2(a[inv0], f3[name]) < 1e-7, (name, rel_l2(a[inv0], f3[name]))      # three steps of 1e-8-tolerance solves
 
     # ---- with the fvDOM stand-in as the radiation handle: radiation->correct() of solver/YEEqn.H:80 solves the 32 rays
-    refR = plume.Plume((10, 12, 9)); refR.stored_bc = True; refR.set_radiation(solverFreq=1)
+    refR = newPlume(); refR.stored_bc = True; refR.set_radiation(solverFreq=1)
     outR, nitR, G = new_out(), (C.c_int * 64)(), np.empty(N)
     csR = case_of(refR, outR, nitR)
     csR.nIterCap = 64; csR.radiationFreq = 1; csR.kAbs = plume.K_ABS; csR.sigmaSB = plume.SIGMA_SB
