@@ -2,7 +2,8 @@
   fireFoam_snippets.C -- one time step of the reference's solver loop (solver/fireFoam.C:97-119) in which the four equation
   files are the REFERENCE'S OWN, included unchanged from where they lie under /root/reference/solver:
 
-      #include "rhoEqn.H"   #include "UEqn.H"   #include "YEEqn.H"   #include "pEqn.H"      (and #include "phrghEqn.H", start-up)
+      #include "rhoEqn.H"   #include "UEqn.H"   #include "YEEqn.H"   #include "pEqn.H"      (and #include "phrghEqn.H", start-up;
+      #include "solidRegionDiffusionNo.H"   #include "setMultiRegionDeltaT.H", time-step control)
 
   compiled against include/ffmFoam.H (the fvMesh / fvMatrix / fvm:: / fvc:: layer over the C ABI) and include/fireFoamHandles.H
   (the physics handles with the stand-ins of the synthetic plume case).  This file is what solver/createFields.H is to the
@@ -40,6 +41,8 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     // psiB != NULL: compressibility on the boundary faces (patch-face mixtures differing from the cells', e.g. the steckler
     // case's start state); the thermo object then keeps them and rho_b = psi_b*p_b.  resOut: {initial, final} residual per solve
     const double* psiB; double* resOut;
+    // time-step control (controlDict adjustTimeStep / maxCo / maxDeltaT) for firefoam_snippets_time_step; dtOut: the deltaT used
+    int adjustTimeStep; double maxCo, maxDeltaT; double* dtOut;
 };
 
 // ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
@@ -82,6 +85,10 @@ struct snippetSolver
     const bool constD = false;
     scalar cumulativeContErr = 0;
     Time runTime;
+    struct { bool adjustTimeStep; scalar maxCo, maxDeltaT; } timeControls;
+    noPyrolysis pyrolysis;
+    const scalar maxDi;                                         // solver/readPyrolysisTimeControls.H:32
+    const bool solvePyrolysisRegion = true, solvePrimaryRegion = true;      // solver/createFields.H:134-145
 
     static pimpleDict pimpleOf()
     {
@@ -96,8 +103,10 @@ struct snippetSolver
       thermoObj(mesh, cs->RR, cs->Cp, cs->Tref), thermo(thermoObj), composition(thermo.composition()), Y(composition.Y()),
       inertIndex(cs->inertIndex), p(thermo.p()), T(thermo.T()), psi(thermo.psi()), rho("rho", mesh), U("U", mesh), phi(mesh),
       p_rgh("p_rgh", mesh), gh("gh", mesh), ghf(mesh), pRef("pRef", cs->pRef), K("K", mesh), dpdt("dpdt", mesh), Qdot("Qdot", mesh),
-      parcels(mesh), surfaceFilm(mesh), DM("DM", 0.0), runTime(0)
+      parcels(mesh), surfaceFilm(mesh), DM("DM", 0.0), runTime(0, cs->deltaT),
+      timeControls{cs->adjustTimeStep != 0, cs->maxCo, cs->maxDeltaT}, maxDi(pyrolysis.maxDiff())
     {
+        runTime.link(mesh.deltaT);
         mesh.solvers["rho"] = mesh.solvers["rhoFinal"] = {FFM_DIAGONAL, FFM_NONE, 1e-6, 0, 0, 1000, 1};
         mesh.solvers["U"] = mesh.solvers["UFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-6, 0, 0, 1000, 1};
         mesh.solvers["Yi"] = mesh.solvers["YiFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-8, 0, 0, 1000, 1};
@@ -186,6 +195,34 @@ struct snippetSolver
         FFM_FOAM_CHK(ffm_ctx_sync(ctx));
     }
 
+    // the body of the time loop, solver/fireFoam.C:76-121: time-step control (the reference's solidRegionDiffusionNo.H and
+    // setMultiRegionDeltaT.H between this layer's versions of the OpenFOAM headers), then the step
+    void timeStep()
+    {
+        #include "readTimeControls.H"
+        #include "compressibleCourantNo.H"
+        #include "solidRegionDiffusionNo.H"
+        #include "setMultiRegionDeltaT.H"
+        #include "setDeltaT.H"
+
+        runTime++;
+
+        parcels.evolve();
+
+        surfaceFilm.evolve();
+
+        if(solvePyrolysisRegion)
+        {
+            pyrolysis.evolve();
+        }
+
+        if (solvePrimaryRegion)
+        {
+            step();
+        }
+        (void)meanCoNum;
+    }
+
     // solver/createFields.H:100-104 -> solver/phrghEqn.H: hydrostatic initialisation (nHydrostaticCorrectors solves of
     // fvm::laplacian(rhof, ph_rgh) == fvc::div(phig)); the case's 0/ph_rgh: fixedValue 0 where topMask = 1, fixedFluxPressure elsewhere
     void hydrostatic(const double* topMask, const double* fluxMask)
@@ -234,6 +271,14 @@ extern "C" void firefoam_snippets_destroy(snippetSolver* s) { delete s; }
 extern "C" int firefoam_snippets_advance(snippetSolver* s, const snippetCase* cs, int download)
 {
     s->step();
+    if (download) s->download(cs, true);
+    return s->iterations(cs, true);
+}
+// the same with the time-step control of the reference's loop in front (adjustTimeStep / maxCo / maxDeltaT of the case)
+extern "C" int firefoam_snippets_time_step(snippetSolver* s, const snippetCase* cs, int download)
+{
+    s->timeStep();
+    if (cs->dtOut) *cs->dtOut = s->runTime.deltaTValue();
     if (download) s->download(cs, true);
     return s->iterations(cs, true);
 }

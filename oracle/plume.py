@@ -230,6 +230,30 @@ class Plume:
         self.stored_bc = False
         self.p_rgh_b = [b.copy() for b in self.ph_rgh_b]
 
+    # ---- time-step control (solver/fireFoam.C:78-82) ----------------------------------------
+    def set_time_controls(self, maxCo, maxDeltaT):
+        """controlDict adjustTimeStep yes; maxCo; maxDeltaT (cases/steckler/system/controlDict:44-48)"""
+        self.adjust, self.maxCo, self.maxDeltaT = True, maxCo, maxDeltaT
+
+    def set_delta_t(self):
+        """compressibleCourantNo.H [upstream], then the reference's solver/setMultiRegionDeltaT.H:34-60 (no pyrolysis region, no
+        film: DiNum = -GREAT -> SMALL, maxDi = GREAT, film Courant number 0), then setDeltaT.H [upstream] -- both are included"""
+        m = self.m
+        GREAT, SMALL = 1.0e15, 1.0e-15
+        sumPhi = fv.surface_sum(m, np.abs(self.phi), [np.abs(b) for b in self.phib]) / self.rho
+        CoNum = 0.5 * (sumPhi / m.V).max() * self.dt
+        self.meanCoNum = 0.5 * (sumPhi.sum() / m.V.sum()) * self.dt
+        self.CoNum = CoNum
+        DiNum = SMALL                                            # == -GREAT -> SMALL
+        TFactorFluid = self.maxCo / (CoNum + SMALL)
+        TFactorSolid = GREAT / (DiNum + SMALL)
+        TFactorFilm = self.maxCo / (0.0 + SMALL)
+        dt = min(self.dt * min(min(TFactorFluid, min(TFactorFilm, TFactorSolid)), 1.2), self.maxDeltaT)
+        maxDeltaTFact = self.maxCo / (CoNum + SMALL)
+        deltaTFact = min(min(maxDeltaTFact, 1.0 + 0.1 * maxDeltaTFact), 1.2)
+        dt = min(deltaTFact * dt, self.maxDeltaT)
+        self.dt, self.rDeltaT = dt, 1.0 / dt
+
     # ---- one time step (solver/fireFoam.C:76-121) -----------------------------------------
     def rho_eqn(self):
         m = self.m
@@ -238,6 +262,8 @@ class Plume:
         self.rho = s / d            # diagonalSolver
 
     def step(self):
+        if getattr(self, "adjust", False):
+            self.set_delta_t()
         m, rdt = self.m, self.rDeltaT
         self.sol.log = []
         # oldTime fields

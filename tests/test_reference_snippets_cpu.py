@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/solver"
-SNIPPETS = ["rhoEqn.H", "UEqn.H", "YEEqn.H", "pEqn.H", "phrghEqn.H"]
+SNIPPETS = ["rhoEqn.H", "UEqn.H", "YEEqn.H", "pEqn.H", "phrghEqn.H", "solidRegionDiffusionNo.H", "setMultiRegionDeltaT.H"]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "UEqn.H")), reason="reference not mounted")
 
@@ -27,6 +27,8 @@ def test_the_four_equation_files_are_the_references_and_compile_unchanged(tmp_pa
         assert os.path.join(REF, name) in included, name
     # pEqn.H includes rhoEqn.H again (solver/pEqn.H:48) and the OpenFOAM header compressibleContinuityErrs.H, which is ours
     assert included.count(os.path.join(REF, "rhoEqn.H")) == 2
+    for ours in ("readTimeControls.H", "compressibleCourantNo.H", "setDeltaT.H"):          # OpenFOAM headers, restated in include/
+        assert any(p.endswith("include/" + ours) for p in included), ours
     assert any(p.endswith("include/compressibleContinuityErrs.H") for p in included)
     # nothing of the repository shadows or copies the reference's files
     for name in SNIPPETS:

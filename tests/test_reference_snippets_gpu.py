@@ -29,7 +29,8 @@ class SnippetCase(C.Structure):
                 + [("rhoOut", dp), ("UOut", dp), ("pOut", dp), ("p_rghOut", dp), ("hOut", dp), ("YOut", dpp), ("TOut", dp), ("KOut", dp)]
                 + [("dpdtOut", dp), ("phiOutF", dp), ("phiOutB", dp), ("p_rghBOut", dp), ("nIterOut", C.POINTER(C.c_int)), ("nIterCap", C.c_int)]
                 + [("radiationFreq", C.c_int), ("kAbs", C.c_double), ("sigmaSB", C.c_double), ("dAve", dp), ("omega", dp), ("GOut", dp)]
-                + [("psiB", dp), ("resOut", dp)])
+                + [("psiB", dp), ("resOut", dp)]
+                + [("adjustTimeStep", C.c_int), ("maxCo", C.c_double), ("maxDeltaT", C.c_double), ("dtOut", dp)])
 
 
 @pytest.mark.parametrize("shape,empty", [((10, 12, 9), ()), ((1, 24, 20), ("xmin", "xmax"))])
@@ -152,6 +153,29 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
     f3 = ref3.fields()
     for name, a in (("rho", out3["rho"]), ("T", out3["T"]), ("Ux", out3["U"][0]), ("Uy", out3["U"][1]), ("Uz", out3["U"][2]), ("C3H8", out3["Y"][2])):
         assert rel_l2(a[inv0], f3[name]) < 1e-7, (name, rel_l2(a[inv0], f3[name]))      # three steps of 1e-8-tolerance solves
+
+    # ---- the body of the reference's time loop with its time-step control: solidRegionDiffusionNo.H and setMultiRegionDeltaT.H
+    # (the reference's, unchanged) between this layer's compressibleCourantNo.H and setDeltaT.H; maxCo 0.3 lets deltaT grow by
+    # 1.2 x 1.2 per step from 1 ms until the Courant number of the plume limits it
+    lib.firefoam_snippets_time_step.restype = C.c_int
+    lib.firefoam_snippets_time_step.argtypes = [C.c_void_p, C.POINTER(SnippetCase), C.c_int]
+    refT = newPlume(); refT.stored_bc = True; refT.set_time_controls(0.3, 0.05)
+    outT, nitT, dtOut = new_out(), (C.c_int * 32)(), np.zeros(1)
+    csT = case_of(refT, outT, nitT)
+    csT.adjustTimeStep = 1; csT.maxCo = 0.3; csT.maxDeltaT = 0.05; csT.dtOut = dtOut.ctypes.data_as(dp)
+    solverT = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(csT))
+    dts = []
+    for k in range(5):
+        nT = lib.firefoam_snippets_time_step(solverT, C.byref(csT), 1 if k == 4 else 0)
+        refT.step()
+        dts.append(dtOut[0])
+        assert abs(dtOut[0] - refT.dt) <= 1e-9 * refT.dt, (k, dtOut[0], refT.dt)
+        assert list(nitT[:nT]) == [pf["nIterations"] for _, pf in refT.sol.log], k
+    lib.firefoam_snippets_destroy(solverT)
+    assert dts[0] > 1.43e-3 and max(dts) > dts[0] and any(abs(b / a - 1.44) > 1e-6 for a, b in zip(dts, dts[1:]))   # grew, then was limited
+    fT = refT.fields()
+    for name, a in (("rho", outT["rho"]), ("T", outT["T"]), ("Uy", outT["U"][1]), ("O2", outT["Y"][0])):
+        assert rel_l2(a[inv0], fT[name]) < 1e-7, (name, rel_l2(a[inv0], fT[name]))
 
     # ---- with the fvDOM stand-in as the radiation handle: radiation->correct() of solver/YEEqn.H:80 solves the 32 rays
     refR = newPlume(); refR.stored_bc = True; refR.set_radiation(solverFreq=1)
