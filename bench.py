@@ -163,7 +163,7 @@ def main():
         barrier()
         sweep_ms = max((time.perf_counter() - t1) * 1e3 - dt / args.steps * 1e3, 0.0)
         rays = [pf["nIterations"] for nm, pf in case.solves() if nm.startswith("I") and nm[1:].isdigit()]
-        radiation = {"model": "fvDOM stand-in: 32 rays (nPhi 2, nTheta 4), upwind, PBiCGStab+DILU to 1e-4, constant absorption, no coupling into h",
+        radiation = {"model": "fvDOM stand-in: 32 rays (nPhi 2, nTheta 4), upwind, PBiCGStab+DILU to 1e-4 in a direction-ordered cell numbering per ray (one block; iterative on decomposed blocks), constant absorption, no coupling into h",
                      "solverFreq": args.radiation_freq,
                      "timed_steps_containing_a_sweep": len([k for k in range(args.warmup, args.warmup + args.steps) if k % args.radiation_freq == 0]),
                      "sweep_ms": round(sweep_ms, 1), "amortised_ms_per_step": round(sweep_ms / args.radiation_freq, 2),

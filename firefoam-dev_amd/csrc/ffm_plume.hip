@@ -87,6 +87,13 @@ struct ffm_plume {
     // fvDOM stand-in: off unless ffm_plume_set_radiation() was called
     int stepNo = 0, radFreq = 0;
     std::vector<double> rayD, rayOmega;    // dAve[3] and omega per ray
+    // direction-ordered ray solves (single block): for the flip of axis a, radCm[a][c] = cell that takes c's place and
+    // radFm[a][e] = native face that takes e's place (bit-complemented where owner and neighbour change roles); the permuted
+    // system has the sparsity of A and is triangular for every ray whose minority-sign axis is a, so DILU solves it exactly
+    std::vector<int> hL2, hU2, hOldToNew; std::vector<signed char> hFd2;
+    int *radCm[3] = {nullptr, nullptr, nullptr}, *radFm[3] = {nullptr, nullptr, nullptr};
+    double *radDB = nullptr, *radSB = nullptr, *radPsiB = nullptr, *radUB = nullptr, *radLB = nullptr;
+    bool radOrdered = false;
     std::vector<double *> I; double *G = nullptr, *radJ = nullptr, *radW = nullptr, *radJb = nullptr, *radF = nullptr, *radRef = nullptr, *radSrc = nullptr;
     bool stecklerSolvers = false;          // transport equations with smoothSolver + symGaussSeidel, maxIter 10
                                            // (cases/steckler/system/fvSolution:49-62) instead of PBiCGStab + DILU
@@ -287,7 +294,29 @@ static int radiation_correct(ffm_plume *P)
         });
         FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, su, nullptr, P->dWork, P->sWork));
         char nm[16]; snprintf(nm, sizeof(nm), "I%d", i);
-        FFM_TRY(solve_named(P, nm, FFM_PBICGSTAB, FFM_DILU, 1e-4, 0.0, P->dWork, P->upper, P->lower, P->I[i], P->sWork, false, true));
+        // the axis whose direction component has the minority sign; none when all three agree (the cell order is then already
+        // an upwind or a downwind order of the ray and DILU is exact)
+        int flip = -1;
+        if (P->radOrdered) {
+            const int neg = (d0 < 0) + (d1 < 0) + (d2 < 0);
+            if (neg == 1) flip = d0 < 0 ? 0 : d1 < 0 ? 1 : 2;
+            else if (neg == 2) flip = d0 >= 0 ? 0 : d1 >= 0 ? 1 : 2;
+        }
+        if (flip < 0) {
+            FFM_TRY(solve_named(P, nm, FFM_PBICGSTAB, FFM_DILU, 1e-4, 0.0, P->dWork, P->upper, P->lower, P->I[i], P->sWork, false, true));
+        } else {
+            // the same system with the cells renamed by the flip of that axis: same sparsity, triangular
+            const int *cm = P->radCm[flip], *fm = P->radFm[flip];
+            const double *dW = P->dWork, *sW = P->sWork, *up = P->upper, *lo = P->lower; double *Ii = P->I[i];
+            double *dB = P->radDB, *sB = P->radSB, *pB = P->radPsiB, *uB = P->radUB, *lB = P->radLB;
+            forN(P, N, [=] __device__(long c) { const int s = cm[c]; dB[c] = dW[s]; sB[c] = sW[s]; pB[c] = Ii[s]; });
+            forN(P, nNat, [=] __device__(long e) {
+                const int t = fm[e];
+                if (t >= 0) { uB[e] = up[t]; lB[e] = lo[t]; } else { uB[e] = lo[~t]; lB[e] = up[~t]; }
+            });
+            FFM_TRY(solve_named(P, nm, FFM_PBICGSTAB, FFM_DILU, 1e-4, 0.0, dB, uB, lB, pB, sB, false, true));
+            forN(P, N, [=] __device__(long c) { Ii[cm[c]] = pB[c]; });
+        }
         FFM_TRY(HX(P, P->I[i]));
         const double *Ii = P->I[i];
         forN(P, N, [=] __device__(long c) { G[c] = G[c] + Ii[c] * omega; });
@@ -594,6 +623,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
         FFM_TRY(ffm_ldu_create_hint(ctx, (int)nOwn, (int)nGhost, F, l2.data(), u2.data(), hintNew.data(), &P->A));
     }
     if (!P->A->identity) { ffm_set_error("plume: renumbered mesh is not native"); return FFM_ERR_ADDR; }
+    if (nGhost == 0) { P->hL2 = l2; P->hU2 = u2; P->hOldToNew = oldToNew; P->hFd2 = fd2; }      // for the direction-ordered ray solves
     FFM_TRY(ffm_ldu_set_global_cells(P->A, (long)gx * gy * gz));
     P->nNat = P->A->upTotal;
     // ---- geometry (global coordinates)
@@ -722,6 +752,7 @@ extern "C" int ffm_plume_destroy(ffm_plume *P)
     if (!P) return FFM_OK;
     hipStreamSynchronize(P->ctx->stream);
     for (double *p : P->pool) hipFree(p);
+    for (int a = 0; a < 3; a++) { hipFree(P->radCm[a]); hipFree(P->radFm[a]); }
     ffm_mesh_destroy(P->mesh); ffm_ldu_destroy(P->A);
     delete P;
     return FFM_OK;
@@ -754,6 +785,38 @@ extern "C" int ffm_plume_set_radiation(ffm_plume *P, int solverFreq, int nPhi, i
         P->G = dalloc(P, P->N); P->radSrc = dalloc(P, P->N); P->radJ = dalloc(P, P->nNat); P->radW = dalloc(P, P->nNat);
         P->radJb = dalloc(P, P->B); P->radF = dalloc(P, P->B); P->radRef = dalloc(P, P->B);
         if (!P->G || !P->radSrc || !P->radJ || !P->radW || !P->radJb || !P->radF || !P->radRef) return FFM_ERR_HIP;
+    }
+    // ---- direction-ordered solves: one block without ghost layers (a decomposed block keeps the iterative solve: the
+    // exact sweep would have to cross rank boundaries)
+    if (!P->hL2.empty() && !P->radOrdered && !getenv("FFM_RAD_ITERATIVE")) {
+        const int N = P->N, F = P->F, nx = P->nx, ny = P->ny, nz = P->nz; const long nNat = P->nNat;
+        std::vector<int> ownerStart(N + 1, 0);
+        for (int f = 0; f < F; f++) ownerStart[P->hL2[f] + 1]++;
+        for (int c = 0; c < N; c++) ownerStart[c + 1] += ownerStart[c];            // faces are sorted by owner (upper-triangular order)
+        const std::vector<int> &c2n = P->A->h_callerToNative;
+        for (int a = 0; a < 3; a++) {
+            std::vector<int> cm(N), fm(std::max<long>(nNat, 1));
+            for (long e = 0; e < nNat; e++) fm[e] = (int)e;                        // padding entries map to themselves
+            for (int c = 0; c < N; c++) {
+                const int o = P->newToOld[c]; int i = o % nx, j = (o / nx) % ny, k = o / (nx * ny);
+                if (a == 0) i = nx - 1 - i; else if (a == 1) j = ny - 1 - j; else k = nz - 1 - k;
+                cm[c] = P->hOldToNew[i + nx * (j + ny * k)];
+            }
+            for (int f = 0; f < F; f++) {
+                int o = cm[P->hL2[f]], n = cm[P->hU2[f]]; bool swap = false;
+                if (o > n) { std::swap(o, n); swap = true; }
+                int fp = -1;
+                for (int g = ownerStart[o]; g < ownerStart[o + 1]; g++) if (P->hU2[g] == n) { fp = g; break; }
+                if (fp < 0) { ffm_set_error("plume radiation: the flipped image of a face is not a face"); return FFM_ERR_ADDR; }
+                fm[c2n[f]] = swap ? ~c2n[fp] : c2n[fp];
+            }
+            PL_HIP(hipMalloc((void **)&P->radCm[a], sizeof(int) * N)); PL_HIP(hipMalloc((void **)&P->radFm[a], sizeof(int) * std::max<long>(nNat, 1)));
+            PL_HIP(hipMemcpy(P->radCm[a], cm.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+            PL_HIP(hipMemcpy(P->radFm[a], fm.data(), sizeof(int) * std::max<long>(nNat, 1), hipMemcpyHostToDevice));
+        }
+        P->radDB = dalloc(P, N); P->radSB = dalloc(P, N); P->radPsiB = dalloc(P, N); P->radUB = dalloc(P, nNat); P->radLB = dalloc(P, nNat);
+        if (!P->radDB || !P->radSB || !P->radPsiB || !P->radUB || !P->radLB) return FFM_ERR_HIP;
+        P->radOrdered = true;
     }
     P->radFreq = solverFreq;
     return FFM_OK;

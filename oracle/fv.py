@@ -283,6 +283,31 @@ def lust_correction(mesh, phi, gradvf):
     return 0.25 * ((d[:, 0] * g[:, 0] + d[:, 1] * g[:, 1]) + d[:, 2] * g[:, 2])
 
 
+def flip_maps(mesh, axis):
+    """The mirror image of a hex box in one axis as a renaming of its cells and faces: cm[c] = the cell that takes c's place,
+    fm[f] = the face that takes f's place, swap[f] = owner and neighbour change roles there.  The renamed matrix
+    B[r, c] = A[cm[r], cm[c]] has the sparsity of A; an upwind matrix whose direction has one component of the other sign
+    becomes triangular in the cell order when that axis is flipped (direction-ordered ray solves of the fvDOM stand-in)."""
+    nx, ny, nz = mesh.n
+    i, j, k = (a.copy() for a in mesh.ijk)
+    if axis == 0:
+        i = nx - 1 - i
+    elif axis == 1:
+        j = ny - 1 - j
+    else:
+        k = nz - 1 - k
+    cm = i + nx * (j + ny * k)
+    o, n = cm[mesh.l], cm[mesh.u]
+    swap = o > n
+    o, n = np.minimum(o, n), np.maximum(o, n)
+    key = mesh.l.astype(np.int64) * mesh.nCells + mesh.u
+    order = np.argsort(key)
+    pos = np.searchsorted(key[order], o.astype(np.int64) * mesh.nCells + n)
+    fm = order[pos]
+    assert np.array_equal(mesh.l[fm], o) and np.array_equal(mesh.u[fm], n)
+    return cm, fm, swap
+
+
 def linear_upwind_correction(mesh, phi, gradvf):
     """linearUpwind<Type>::correction (OpenFOAM-dev .../schemes/linearUpwind/linearUpwind.C): (Cf - C_c) & grad(vf)_c, c the upwind
     cell, zero on non-coupled patches; its weights are upwind's.  Reference selection: `div(Ji,Ii_h) Gauss linearUpwind

@@ -178,7 +178,7 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
         assert rel_l2(a[inv0], fT[name]) < 1e-7, (name, rel_l2(a[inv0], fT[name]))
 
     # ---- with the fvDOM stand-in as the radiation handle: radiation->correct() of solver/YEEqn.H:80 solves the 32 rays
-    refR = newPlume(); refR.stored_bc = True; refR.set_radiation(solverFreq=1)
+    refR = newPlume(); refR.stored_bc = True; refR.set_radiation(solverFreq=1, ordered=False)      # the handle solves every ray iteratively
     outR, nitR, G = new_out(), (C.c_int * 64)(), np.empty(N)
     csR = case_of(refR, outR, nitR)
     csR.nIterCap = 64; csR.radiationFreq = 1; csR.kAbs = plume.K_ABS; csR.sigmaSB = plume.SIGMA_SB
