@@ -218,3 +218,22 @@ extern "C" int b1_pimple_sequence(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, int
     }
     return n;
 }
+
+// `Gauss linear corrected` through the Foam layer on a non-orthogonal mesh (the mesh handle carries nonOrthCorrectionVectors):
+// the source of fvm::laplacian(gamma, vf) -- which holds only the explicit non-orthogonal term, the boundary part of a mixed
+// condition going to boundaryCoeffs -- and fvc::snGrad(vf) of the internal faces (LDU face order).
+extern "C" int b1_corrected_schemes(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, const double* vfC, const double* vfB, const double* gammaC,
+                                    const double* const* bc, double* sourceOut, double* snGradOutF)
+{
+    fvMesh mesh(ctx, ldu, msh, 1.0);
+    mesh.snGradCorrected = true; mesh.laplacianCorrected = true;
+    volScalarField vf("vf", mesh); vf.v.assignHost(vfC); vf.b.assignHost(vfB);
+    vf.bc = makeBC(mesh, bc[0], bc[1], bc[2]);
+    volScalarField gamma("gamma", mesh); gamma.v.assignHost(gammaC); gamma.b = mesh.patchInternal(gamma.v);
+    fvScalarMatrix M(fvm::laplacian(gamma, vf));
+    M.source[0].toHost(sourceOut);
+    const surfaceScalarField sg(fvc::snGrad(vf));
+    FFM_FOAM_CHK(ffm_faces_from_native(mesh.msh, sg.v.data(), snGradOutF));
+    FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    return 0;
+}

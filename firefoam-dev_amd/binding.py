@@ -128,7 +128,9 @@ def lib():
         "ffm_mesh_create": ([vp, hp, hp, hp, hp, hp, hp, C.c_int, ip, C.POINTER(ip), C.POINTER(hp), C.POINTER(hp), C.POINTER(vp)], C.c_int),
         "ffm_mesh_destroy": ([vp], C.c_int),
         "ffm_mesh_set_face_centres": ([vp, hp], C.c_int),
+        "ffm_mesh_set_nonorth_correction": ([vp, hp], C.c_int),
         "ffm_fv_lust_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvc_snGrad_correction": ([vp, dp, dp, dp, dp], C.c_int),
         "ffm_fv_linear_upwind_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fvm_relax": ([vp, C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_mesh_nboundary": ([vp], C.c_int),
@@ -558,6 +560,11 @@ class fvMesh:
         if getattr(self, "h", None):
             lib().ffm_mesh_destroy(self.h)
             self.h = None
+
+    def set_nonorth_correction(self, corrVec):
+        """nonOrthCorrectionVectors[3][F] in LDU face order (the `corrected` snGrad / laplacian schemes)."""
+        c = np.ascontiguousarray(corrVec, np.float64)
+        _check(lib().ffm_mesh_set_nonorth_correction(self.h, _hp(c)), "ffm_mesh_set_nonorth_correction")
 
     def set_face_centres(self, Cf):
         """Cf[3][F] in LDU face order (mesh.Cf(), needed by the LUST correction)."""

@@ -31,6 +31,7 @@ struct ffm_mesh {
     double *V = nullptr, *C[3] = {nullptr, nullptr, nullptr};
     double *Sf[3] = {nullptr, nullptr, nullptr}, *magSf = nullptr, *delta = nullptr, *w = nullptr;  // [nNat]
     double *Cf[3] = {nullptr, nullptr, nullptr};     // [nNat] face centres (optional: ffm_mesh_set_face_centres, needed by LUST)
+    double *corr[3] = {nullptr, nullptr, nullptr};   // [nNat] nonOrthCorrectionVectors (optional: ffm_mesh_set_nonorth_correction)
     double *invT = nullptr;          // [6][N] inverse of surfaceSum(Sf (x) Sf / magSf), symmetric
     int *bCells = nullptr;           // [B] face cell of each boundary face
     double *bSf[3] = {nullptr, nullptr, nullptr}, *bMagSf = nullptr, *bDelta = nullptr;           // [B]
@@ -189,6 +190,7 @@ extern "C" int ffm_mesh_destroy(ffm_mesh *m)
 {
     if (!m) return FFM_OK;
     hipStreamSynchronize(m->ctx->stream);
+    for (int d_ = 0; d_ < 3; d_++) hipFree(m->corr[d_]);
     hipFree(m->V); hipFree(m->magSf); hipFree(m->delta); hipFree(m->w); hipFree(m->invT); hipFree(m->bCells);
     hipFree(m->bMagSf); hipFree(m->bDelta); hipFree(m->cellB); hipFree(m->bcStart); hipFree(m->bcItem);
     for (int d = 0; d < 3; d++) { hipFree(m->C[d]); hipFree(m->Sf[d]); hipFree(m->bSf[d]); hipFree(m->Cf[d]); }
@@ -239,6 +241,19 @@ __global__ void k_snGrad(MeshView q, const double *__restrict__ vf, double *__re
     CELL_SCHED(ci, q) {
         const int c = (int)ci; const double P = vf[c];
         FOR_OWN_FACES(q, c, e, nb) out[e] = q.delta[e] * (vf[nb] - P);
+    }
+}
+// correctedSnGrad<Type>::correction(vf) for one scalar component: nonOrthCorrectionVectors & linear-interpolate(grad(vf))
+__global__ void k_snGrad_correction(MeshView q, const double *__restrict__ cx, const double *__restrict__ cy, const double *__restrict__ cz,
+                                    const double *__restrict__ gx, const double *__restrict__ gy, const double *__restrict__ gz,
+                                    double *__restrict__ out)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci; const double Px = gx[c], Py = gy[c], Pz = gz[c];
+        FOR_OWN_FACES(q, c, e, nb) {
+            const double w = q.w[e];
+            out[e] = (cx[e] * (w * Px + (1.0 - w) * gx[nb]) + cy[e] * (w * Py + (1.0 - w) * gy[nb])) + cz[e] * (w * Pz + (1.0 - w) * gz[nb]);
+        }
     }
 }
 // fvc::flux(v) = linear-interpolate(v) & Sf for a vector field given as three component arrays
@@ -629,6 +644,31 @@ extern "C" int ffm_mesh_set_face_centres(ffm_mesh *m, const double *Cf)
         FFM_TRY(up(m->ctx, &m->Cf[d], v));
     }
     return FFM_OK;
+}
+// mesh.nonOrthCorrectionVectors() of the internal faces, host array [3][F] in LDU face order (zero on orthogonal meshes, where
+// this call is not needed; non-coupled boundary faces carry no correction upstream)
+extern "C" int ffm_mesh_set_nonorth_correction(ffm_mesh *m, const double *corrVec)
+{
+    CHECK_M(m);
+    if (!corrVec) return FFM_ERR_ARG;
+    for (int d = 0; d < 3; d++) {
+        std::vector<double> v(std::max(m->nNat, 1), 0.0);
+        for (int f = 0; f < m->F; f++) v[m->A->h_callerToNative[f]] = corrVec[(size_t)d * m->F + f];
+        hipFree(m->corr[d]); m->corr[d] = nullptr;
+        FFM_TRY(up(m->ctx, &m->corr[d], v));
+    }
+    return FFM_OK;
+}
+// correctedSnGrad::correction(vf): out_f = nonOrthCorrectionVectors & interpolate(grad(vf)); `Gauss linear corrected` adds
+//   fvc::snGrad:      snGrad = uncorrected + out_f
+//   fvm::laplacian:   source -= V * ffm_fvc_surface_integrate(gamma_f*magSf*out_f, 0)       (gaussLaplacianScheme::fvmLaplacian)
+extern "C" int ffm_fvc_snGrad_correction(ffm_mesh *m, const double *gx, const double *gy, const double *gz, double *out_f)
+{
+    CHECK_M(m);
+    if (!gx || !gy || !gz || !out_f) return FFM_ERR_ARG;
+    if (!m->corr[0]) { ffm_set_error("ffm_fvc_snGrad_correction: correction vectors not set (ffm_mesh_set_nonorth_correction)"); return FFM_ERR_ARG; }
+    LAUNCH_CELLS(k_snGrad_correction, mview(m), m->corr[0], m->corr[1], m->corr[2], gx, gy, gz, out_f);
+    DONE();
 }
 extern "C" int ffm_fv_lust_correction(ffm_mesh *m, const double *phi_f, const double *gx, const double *gy, const double *gz, double *out_f)
 {

@@ -229,6 +229,9 @@ int ffm_mesh_create(ffm_ldu *ldu, const double *V, const double *C,
                     const double *const *patchDeltaCoeffs, ffm_mesh **out);
 /* mesh.Cf() of the internal faces, host array Cf[3][F] in LDU face order (needed by the LUST correction only) */
 int ffm_mesh_set_face_centres(ffm_mesh *mesh, const double *Cf);
+/* mesh.nonOrthCorrectionVectors() of the internal faces, host array [3][F] in LDU face order; needed by the `corrected`
+ * snGrad / laplacian schemes on non-orthogonal meshes only (cases/wallFireSpread2D/system/fvSchemes: `Gauss linear corrected`) */
+int ffm_mesh_set_nonorth_correction(ffm_mesh *mesh, const double *corrVec);
 int ffm_mesh_destroy(ffm_mesh *mesh);
 int ffm_mesh_nboundary(const ffm_mesh *mesh);
 /* device geometry fields for the Foam layer: 0 V[N], 1 magSf[nNative], 2 deltaCoeffs[nNative], 3 weights[nNative],
@@ -250,6 +253,10 @@ int ffm_fvc_surface_integrate(ffm_mesh *m, const double *ssf_f, const double *ss
 int ffm_fvc_surface_sum(ffm_mesh *m, const double *ssf_f, const double *ssf_b, double *out);
 int ffm_fvc_grad(ffm_mesh *m, const double *vf, const double *vb, double *gx, double *gy, double *gz);
 int ffm_fvc_reconstruct(ffm_mesh *m, const double *ssf_f, const double *ssf_b, double *ox, double *oy, double *oz);
+/* correctedSnGrad::correction(vf) = nonOrthCorrectionVectors & interpolate(grad(vf)), internal faces (one scalar component).
+ * `corrected` snGrad = ffm_fvc_snGrad + this; `Gauss linear corrected` laplacian = the uncorrected matrix with
+ * source -= V*ffm_fvc_surface_integrate(gamma_f*magSf*this, 0) */
+int ffm_fvc_snGrad_correction(ffm_mesh *m, const double *gx, const double *gy, const double *gz, double *out_f);
 /* limitedSurfaceInterpolationScheme weights: scheme 0 upwind, 1 linear,
  * 2 limitedLinear k, 3 limitedLinear01 k with bounds [lo,hi], 4 LUST (0.75 linear +
  * 0.25 upwind; vf and gradients unused), 5 linearUpwind (upwind weights; its explicit correction is

@@ -96,6 +96,39 @@ class HexMesh:
         return next(p for p in self.patches if p.name == name)
 
 
+def shear(mesh, M):
+    """Map the geometry of a HexMesh (patches already set) by the affine map x -> M x: a non-orthogonal test mesh.  Addressing
+    is unchanged; centres map with M, area vectors with det(M) M^-T, volumes with det(M); weights, nonOrthDeltaCoeffs and
+    nonOrthCorrectionVectors follow surfaceInterpolation::makeWeights / makeNonOrthDeltaCoeffs / makeNonOrthCorrectionVectors
+    (OpenFOAM-dev src/finiteVolume/interpolation/surfaceInterpolation/surfaceInterpolation/surfaceInterpolation.C)."""
+    M = np.asarray(M, float); det = np.linalg.det(M); cof = det * np.linalg.inv(M).T
+    mesh.C = mesh.C @ M.T; mesh.Cf = mesh.Cf @ M.T; mesh.Sf = mesh.Sf @ cof.T; mesh.V = mesh.V * det
+    mesh.magSf = np.linalg.norm(mesh.Sf, axis=1)
+    own = np.abs(np.einsum("fd,fd->f", mesh.Sf, mesh.Cf - mesh.C[mesh.l]))
+    nei = np.abs(np.einsum("fd,fd->f", mesh.Sf, mesh.C[mesh.u] - mesh.Cf))
+    mesh.weights = nei / (own + nei)
+    d = mesh.C[mesh.u] - mesh.C[mesh.l]
+    nf = mesh.Sf / mesh.magSf[:, None]
+    mesh.deltaCoeffs = 1.0 / np.maximum(np.einsum("fd,fd->f", nf, d), 0.05 * np.linalg.norm(d, axis=1))     # nonOrthDeltaCoeffs
+    mesh.nonOrthCorrectionVectors = nf - d * mesh.deltaCoeffs[:, None]
+    for p in mesh.patches:
+        p.Cf = p.Cf @ M.T; p.Sf = p.Sf @ cof.T; p.magSf = np.linalg.norm(p.Sf, axis=1)
+        nfb = p.Sf / p.magSf[:, None]
+        p.deltaCoeffs = 1.0 / np.einsum("fd,fd->f", nfb, p.Cf - mesh.C[p.faceCells])
+    return mesh
+
+
+def snGrad_correction(mesh, gradvf):
+    """correctedSnGrad<Type>::correction(vf) = nonOrthCorrectionVectors & linear-interpolate(grad(vf)) on the internal faces; zero
+    on non-coupled boundary faces (OpenFOAM-dev .../snGradSchemes/correctedSnGrad/correctedSnGrad.C).  `corrected` snGrad =
+    snGrad(...) + this; `Gauss linear corrected` laplacian = fvm_laplacian(...) with source -= V*div(gamma_f*magSf*this)
+    (gaussLaplacianScheme::fvmLaplacian)."""
+    w = mesh.weights[:, None]
+    gf = w * gradvf[mesh.l] + (1.0 - w) * gradvf[mesh.u]
+    c = mesh.nonOrthCorrectionVectors
+    return (c[:, 0] * gf[:, 0] + c[:, 1] * gf[:, 1]) + c[:, 2] * gf[:, 2]
+
+
 # ------------------------------------------------------------------ fvc operators ---
 def interpolate(mesh, vf, bvals):
     """fvc::interpolate, linear: face = w*P + (1-w)*N; boundary faces take the patch value."""

@@ -209,3 +209,70 @@ def test_fvm_relax(setup, O, ctx, nc):
     assert np.array_equal(back_cell(s, dg), M.diag)
     for c in range(nc):
         assert np.array_equal(back_cell(s, src[c]), M.source[c])
+
+
+def test_nonorthogonal_correction_on_a_sheared_mesh(O, ffm, ctx):
+    """`Gauss linear corrected` / `corrected` snGrad (cases/wallFireSpread2D/system/fvSchemes; zero on the reference's own
+    orthogonal meshes): on a sheared hex box the explicit term nonOrthCorrectionVectors & interpolate(grad(vf)) against
+    oracle/fv.py, the Gauss gradient on the sheared geometry, and the property that makes the scheme second order: for a linear
+    field the corrected surface-normal gradient of an interior face is exact, nf & a."""
+    from oracle import fv, plume
+    m = plume.make_mesh((7, 6, 5), h=0.1)
+    fv.shear(m, [[1.0, 0.35, 0.1], [0.0, 1.0, 0.25], [0.0, 0.0, 1.0]])
+    assert np.abs(m.nonOrthCorrectionVectors).max() > 0.1
+    N, F = m.nCells, m.nFaces
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    mesh.set_nonorth_correction(m.nonOrthCorrectionVectors[fOrd].T.copy())
+    s = dict(mesh=mesh, cOrd=cOrd, fOrd=fOrd, N=N, F=F)
+    # hashed field: gradient and correction against the oracle
+    vf = 0.2 + O.hash_u(71, np.arange(N)); vb = [0.1 + O.hash_u(72 + q, np.arange(p.size)) for q, p in enumerate(m.patches)]
+    g = [ctx.zeros(N) for _ in range(3)]
+    mesh.call("fvc_grad", cellf(s, ctx, vf), bndf(ctx, vb), *g)
+    gref = fv.grad(m, vf, vb)
+    for d in range(3):
+        assert rel_l2(back_cell(s, g[d]), gref[:, d]) < 1e-14
+    corr = ctx.zeros(mesh.nNative)
+    mesh.call("fvc_snGrad_correction", *[cellf(s, ctx, gref[:, d]) for d in range(3)], corr)
+    cref = fv.snGrad_correction(m, gref)
+    assert np.abs(back_face(s, corr) - cref).max() <= 1e-14 * np.abs(cref).max()
+    # linear field with its exact boundary values: Gauss gradient exact, corrected snGrad exact on faces between interior cells
+    a = np.array([0.7, -1.3, 2.1])
+    lin = m.C @ a + 0.4; linb = [p.Cf @ a + 0.4 for p in m.patches]
+    glin = fv.grad(m, lin, linb)
+    assert np.abs(glin - a).max() < 1e-12
+    mesh.call("fvc_grad", cellf(s, ctx, lin), bndf(ctx, linb), *g)
+    mesh.call("fvc_snGrad_correction", *g, corr)
+    sg = ctx.zeros(mesh.nNative)
+    mesh.call("fvc_snGrad", cellf(s, ctx, lin), sg)
+    nf = m.Sf / m.magSf[:, None]
+    total = back_face(s, sg) + back_face(s, corr)
+    assert np.abs(total - nf @ a).max() < 1e-11
+    assert np.abs(back_face(s, sg) - nf @ a).max() > 1e-2            # (the uncorrected one is not)
+    # the same through the Foam layer (include/ffmFoam.H with mesh.snGradCorrected / laplacianCorrected): fvc::snGrad(vf) and the
+    # explicit source of fvm::laplacian(gamma, vf) = -V*div(gamma_f*magSf*correction)
+    import ctypes as C, os
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    dp = C.POINTER(C.c_double)
+    gam = 1.0 + O.hash_u(75, np.arange(N))
+    B = sum(p.size for p in m.patches)
+    vbv = np.concatenate(vb)                                # boundary values = fixedValue conditions
+    bcs = [np.ones(B), vbv.copy(), np.zeros(B)]
+    arr = (dp * 3)(*[a.ctypes.data_as(dp) for a in bcs])
+    src, sgF = np.empty(N), np.empty(F)
+    h = lambda a_: np.ascontiguousarray(a_, np.float64)
+    vfl, gaml = h(vf[cOrd]), h(gam[cOrd])
+    lib.b1_corrected_schemes.argtypes = [C.c_void_p] * 3 + [dp, dp, dp, C.POINTER(dp), dp, dp]
+    assert lib.b1_corrected_schemes(ctx.h, A.h, mesh.h, vfl.ctypes.data_as(dp), vbv.ctypes.data_as(dp), gaml.ctypes.data_as(dp), arr,
+                                    src.ctypes.data_as(dp), sgF.ctypes.data_as(dp)) == 0
+    gf, _ = fv.interpolate(m, gam, [gam[p.faceCells] for p in m.patches])
+    src_ref = -m.V * fv.surface_integrate(m, gf * m.magSf * cref, [np.zeros(p.size) for p in m.patches])
+    back = np.empty(N); back[cOrd] = src
+    assert np.abs(back - src_ref).max() <= 1e-13 * np.abs(src_ref).max()
+    sgo = np.empty(F); sgo[fOrd] = sgF
+    sg_ref = fv.snGrad(m, vf, vb)[0] + cref
+    assert np.abs(sgo - sg_ref).max() <= 1e-13 * np.abs(sg_ref).max()
+    mesh.close(); A.close()
