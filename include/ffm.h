@@ -379,6 +379,22 @@ int ffm_comm_size(const ffm_ctx *ctx);
  * re-loads}.  Not part of the reference interface. */
 int ffm_debug_tile_trace(ffm_ldu *A, unsigned long long *out, int nWords);
 
+/* ------------------------------------------------------- polyMesh (host)    */
+/* SURVEY 8(f) N4, first part: OpenFOAM's on-disk mesh (ascii constant/polyMesh/{points,faces,owner,neighbour,boundary}, as
+ * blockMesh / topoSet / createBaffles leave it: reference cases/steckler/mesh.sh:8-21) and the finite-volume geometry
+ * derived from it with OpenFOAM's algorithms (face fans, cell pyramids, weights, nonOrthDeltaCoeffs, correction vectors):
+ * the inputs of ffm_ldu_create / ffm_mesh_create / ffm_mesh_set_face_centres / ffm_mesh_set_nonorth_correction.  Host only. */
+typedef struct ffm_polymesh ffm_polymesh;
+int ffm_polymesh_read(const char *polyMeshDir, ffm_polymesh **out);
+int ffm_polymesh_destroy(ffm_polymesh *pm);
+int ffm_polymesh_sizes(const ffm_polymesh *pm, int *nPoints, int *nCells, int *nFaces, int *nInternalFaces, int *nPatches);
+int ffm_polymesh_addressing(const ffm_polymesh *pm, int *lowerAddr, int *upperAddr);
+/* cell arrays [N] / [3][N]; internal-face arrays [F] / [3][F]; NULL = not wanted */
+int ffm_polymesh_geometry(const ffm_polymesh *pm, double *V, double *C, double *Sf, double *Cf, double *magSf, double *weights,
+                          double *nonOrthDeltaCoeffs, double *nonOrthCorrectionVectors);
+int ffm_polymesh_patch(const ffm_polymesh *pm, int i, char *name64, char *type32, int *startFace, int *nFaces);
+int ffm_polymesh_patch_geometry(const ffm_polymesh *pm, int i, int *faceCells, double *Sf, double *Cf, double *deltaCoeffs);
+
 #ifdef __cplusplus
 }
 #endif
