@@ -218,7 +218,8 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
     A.close()
 
 
-def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx):
+@pytest.mark.parametrize("from_polymesh", [False, True])
+def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx, from_polymesh, tmp_path):
     """The reference's solver/phrghEqn.H, included unchanged, run on the reference's steckler case (30 x 15 x 20 cells, the
     compartment baffles and doorway, ph_rgh fixedValue 0 on `top` and fixedFluxPressure elsewhere, the boundary mixtures of the
     case files: oracle/steckler.py) through the Foam layer on the device: every operator of the file (fvc::interpolate, snGrad,
@@ -235,6 +236,41 @@ def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx)
     lib.firefoam_snippets_hydrostatic.restype = C.c_int
     lib.firefoam_snippets_hydrostatic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SnippetCase)]
     m = steckler.build_mesh()
+    if from_polymesh:
+        # the mesh goes through a case directory: written as constant/polyMesh (tests/polymesh_writer.py, the files blockMesh +
+        # createBaffles would leave), read back and turned into finite-volume geometry by the library's reader (ffm_polymesh_*);
+        # everything the run below uses -- addressing, V, C, Sf, Cf, weights, deltaCoeffs, patches -- comes from there
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from polymesh_writer import write_polymesh
+        from oracle import fv
+        d = str(tmp_path / "polyMesh")
+        write_polymesh(d, m, (-2.0, 0.0, -2.0), patch_types={"base": "wall", "baffle1DWall_master": "wall", "baffle1DWall_slave": "wall"})
+        L = ffm.lib()
+        pm = C.c_void_p()
+        assert L.ffm_polymesh_read(d.encode(), C.byref(pm)) == 0, L.ffm_last_error()
+        nC, nI, nPa = C.c_int(), C.c_int(), C.c_int()
+        L.ffm_polymesh_sizes(pm, None, C.byref(nC), None, C.byref(nI), C.byref(nPa))
+        ipp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)); dpp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+        class _M:
+            pass
+        r = _M(); r.nCells, r.nFaces = nC.value, nI.value
+        r.l, r.u = np.empty(r.nFaces, np.int32), np.empty(r.nFaces, np.int32)
+        L.ffm_polymesh_addressing(pm, ipp(r.l), ipp(r.u))
+        V, Cc, Sf, Cf = np.empty(r.nCells), np.empty((3, r.nCells)), np.empty((3, r.nFaces)), np.empty((3, r.nFaces))
+        mag, w, dl = np.empty(r.nFaces), np.empty(r.nFaces), np.empty(r.nFaces)
+        L.ffm_polymesh_geometry(pm, dpp(V), dpp(Cc), dpp(Sf), dpp(Cf), dpp(mag), dpp(w), dpp(dl), None)
+        r.V, r.C, r.Sf, r.Cf, r.magSf, r.weights, r.deltaCoeffs = V, Cc.T.copy(), Sf.T.copy(), Cf.T.copy(), mag, w, dl
+        r.patches = []
+        name, st, n = C.create_string_buffer(64), C.c_int(), C.c_int()
+        for q in range(nPa.value):
+            L.ffm_polymesh_patch(pm, q, name, None, C.byref(st), C.byref(n))
+            fc, pS, pC, pd = np.empty(n.value, np.int32), np.empty((3, n.value)), np.empty((3, n.value)), np.empty(n.value)
+            L.ffm_polymesh_patch_geometry(pm, q, ipp(fc), dpp(pS), dpp(pC), dpp(pd))
+            r.patches.append(fv.Patch(name.value.decode(), fc, pS.T.copy(), pC.T.copy(), pd))
+        L.ffm_polymesh_destroy(pm)
+        m = r
     N, F = m.nCells, m.nFaces
     B = sum(p.size for p in m.patches)
     cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
