@@ -237,3 +237,34 @@ extern "C" int b1_corrected_schemes(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, c
     FFM_FOAM_CHK(ffm_ctx_sync(ctx));
     return 0;
 }
+
+// ---- include/ffmDictionary.H on a case's system/fvSolution and system/fvSchemes (no device work): for every name in `fields`
+// (separated by blanks) 6 numbers {solver, preconditioner|smoother, tolerance, relTol, maxIter, nSweeps}; then the PIMPLE entries
+// {nOuter, nCorr, nNonOrth, momentumPredictor, hydrostaticInitialization, nHydrostaticCorrectors}; then for every name in
+// `schemes` {scheme, k}; then for every "entry:field" in `multivariate` {scheme, k}; then {laplacianCorrected, snGradCorrected}
+#include "ffmDictionary.H"
+#include <sstream>
+extern "C" int b1_read_case(const char* fvSolutionPath, const char* fvSchemesPath, const char* fields, const char* schemes,
+                            const char* multivariate, double* out, int cap)
+{
+    fvMesh mesh(nullptr, nullptr, nullptr, 1.0);
+    const fvSolutionFile sol(fvSolutionPath);
+    readFvSchemes(mesh, fvSchemesPath);
+    int n = 0;
+    auto put = [&](double v) { if (n < cap) out[n] = v; n++; };
+    std::istringstream fs(fields); word w;
+    while (fs >> w) { const solverControls c = sol.solver(w); put(c.solver); put(c.preconditioner); put(c.tolerance); put(c.relTol); put(c.maxIter); put(c.nSweeps); }
+    const pimpleDict p = sol.pimple();
+    put(p.nOuterCorrectors); put(p.nCorrectors); put(p.nNonOrthogonalCorrectors); put(p.momentumPredictor); put(p.hydrostaticInitialization); put(p.nHydrostaticCorrectors);
+    std::istringstream ss(schemes);
+    while (ss >> w) { const divScheme& d = mesh.divSchemeOf(w); put(d.scheme); put(d.k); }
+    std::istringstream ms(multivariate);
+    while (ms >> w) {
+        const size_t c = w.find(':');
+        const divScheme& d = mesh.multivariateSelection.at(w.substr(0, c)).at(w.substr(c + 1));
+        put(d.scheme); put(d.k);
+    }
+    put(mesh.laplacianCorrected); put(mesh.snGradCorrected);
+    put(sol.equationRelaxation("U"));
+    return n;
+}

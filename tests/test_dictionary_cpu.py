@@ -1,0 +1,70 @@
+"""include/ffmDictionary.H (the dictionary reader of the Foam layer) on the reference's own case files, read where they lie:
+cases/steckler/system/{fvSolution,fvSchemes} and cases/wallFireSpread2D/system/{fvSolution,fvSchemes} -- regular-expression
+keywords ("(Yi|h|k).*"), $macro expansion ($p_rgh; $U;), `Gauss multivariateSelection { ... }`, PIMPLE, relaxation factors.
+Skipped where the reference is not mounted."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/cases"
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "steckler", "system", "fvSolution")), reason="reference not mounted")
+# ids of include/ffm.h (solver; preconditioner / smoother)
+IDS = dict(PCG=0, PBICGSTAB=1, PBICG=2, DIAGONAL=3, SMOOTH=4, NONE=0, DIC=1, DILU=2, GS=3, SYMGS=4)
+
+
+def _lib():
+    import torch  # noqa: F401
+    from ffm_import import ffm
+    ffm.lib()
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    lib.b1_read_case.restype = C.c_int
+    lib.b1_read_case.argtypes = [C.c_char_p] * 5 + [C.POINTER(C.c_double), C.c_int]
+    return lib, ffm
+
+
+def _read(case, fields, schemes, multivariate):
+    lib, ffm = _lib()
+    out = np.zeros(256)
+    n = lib.b1_read_case(os.path.join(REF, case, "system", "fvSolution").encode(), os.path.join(REF, case, "system", "fvSchemes").encode(),
+                         " ".join(fields).encode(), " ".join(schemes).encode(), " ".join(multivariate).encode(),
+                         out.ctypes.data_as(C.POINTER(C.c_double)), 256)
+    assert 0 < n <= 256
+    return out[:n], ffm
+
+
+def test_steckler_dictionaries():
+    fields = ["rho", "rhoFinal", "p_rgh", "p_rghFinal", "ph_rgh", "U", "UFinal", "Yi", "h", "kFinal", "Ii", "G"]
+    schemes = ["div(phi,U)", "div(phi,K)", "div(Ji,Ii_h)", "div(phiU,p)", "div(((rho*nuEff)*dev2(T(grad(U)))))"]
+    mv = ["div(phi,Yi_h):O2", "div(phi,Yi_h):C3H8", "div(phi,Yi_h):h"]
+    out, ffm = _read("steckler", fields, schemes, mv)
+    rows = out[:6 * len(fields)].reshape(len(fields), 6)
+    r = dict(zip(fields, rows))
+    assert tuple(r["p_rgh"][:4]) == (IDS["PCG"], IDS["DIC"], 1e-6, 0.01)
+    assert tuple(r["p_rghFinal"][:4]) == (IDS["PCG"], IDS["DIC"], 1e-6, 0.0)          # $p_rgh; relTol 0.0;
+    assert tuple(r["ph_rgh"][:4]) == (IDS["PCG"], IDS["DIC"], 1e-6, 0.01)             # $p_rgh;
+    assert tuple(r["rhoFinal"][:4]) == (IDS["PCG"], IDS["DIC"], 1e-6, 0.0)            # "rho.*"
+    for name in ("U", "UFinal"):                                                        # "U.*": smoothSolver symGaussSeidel maxIter 10
+        assert tuple(r[name][:5]) == (IDS["SMOOTH"], IDS["SYMGS"], 1e-6, 0.0, 10)
+    for name in ("Yi", "h", "kFinal"):                                                  # "(Yi|h|k).*": $U; tolerance 1e-8;
+        assert tuple(r[name][:5]) == (IDS["SMOOTH"], IDS["SYMGS"], 1e-8, 0.0, 10)
+    assert r["Ii"][0] == -1 and r["Ii"][2] == 1e-4                                      # GAMG: read, not built
+    assert tuple(r["G"][:2]) == (IDS["PCG"], IDS["DIC"])
+    o = 6 * len(fields)
+    assert tuple(out[o:o + 6]) == (1, 2, 0, 1, 1, 5)                                     # PIMPLE 1/2/0, hydrostaticInitialization yes, 5
+    o += 6
+    sch = out[o:o + 2 * len(schemes)].reshape(-1, 2)
+    assert [tuple(x) for x in sch] == [(4, 1), (2, 1), (0, 1), (1, 1), (1, 1)]            # LUST, limitedLinear 1, upwind, linear, linear
+    o += 2 * len(schemes)
+    assert [tuple(x) for x in out[o:o + 6].reshape(-1, 2)] == [(3, 1), (3, 1), (2, 1)]   # O2, C3H8 limitedLinear01 1; h limitedLinear 1
+    o += 6
+    assert tuple(out[o:o + 3]) == (0, 0, -1)                                             # uncorrected, uncorrected, no equation factor
+
+
+def test_wallFireSpread2D_dictionaries():
+    out, _ = _read("wallFireSpread2D", ["p_rgh", "U", "Yi"], ["div(phi,U)"], [])
+    assert out[0] in (IDS["PCG"], -1)                     # PCG or GAMG depending on the case variant
+    assert out[6 * 3 + 6] == -1                           # div(phi,U) Gauss filteredLinear2V 0.2 0.05: known, not built
+    assert out[-3] == 1 and out[-2] == 1                  # Gauss linear corrected / corrected
+    assert abs(out[-1] - 0.9) < 1e-12 or out[-1] == 1 or out[-1] == -1      # relaxationFactors::equations (0.9 in this case)
