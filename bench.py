@@ -153,6 +153,16 @@ def main():
                 "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(ms.value, 5)}
 
+    # ---- the other half of a PCG iteration, for the record: one DIC application = forward + backward sweep over the same matrix
+    # (not the metric kernel; algorithmic bytes per sweep 16 F + 16 N as SURVEY 8d counts the unfused upstream loops, + w = rD*r 24 N)
+    ms2 = C.c_double()
+    rc = L.ffm_bench_precond(case.ldu_handle(), 1, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 10, C.byref(ms2))
+    sweeps = None
+    if rc == 0:
+        dic_bytes = 2 * (16 * Floc + 16 * Nloc) + 24 * Nloc
+        sweeps = {"kernel": "k_tile<FWD> + k_tile<BWD> (DICPreconditioner::precondition, exact dependency order)", "avg_ms_per_application": round(ms2.value, 4),
+                  "algorithmic_bytes_per_application": dic_bytes, "achieved": round(dic_bytes / (ms2.value * 1e-3) / 1e9, 1), "unit": "GB/s",
+                  "frac": round(dic_bytes / (ms2.value * 1e-3) / 1e9 / 8000.0, 4), "bound": "dependency levels x per-level latency below ~20 M cells, hbm above"}
     # ---- cost of one fvDOM sweep (it falls on steps 0, 100, 200, ...: with --warmup >= 1 outside the timed steps)
     radiation = "off"
     if args.radiation_freq > 0:
@@ -227,7 +237,7 @@ def main():
                                       + ("RCCL halo + all-reduce" if transport == "rccl" else "halo + all-reduce through the host (gloo)"),
                        "radiation": radiation, "p_rgh_iterations_last_step": pIters, "setup_s": round(setup_s, 1),
                        "transport_solvers": "PBiCGStab+DILU" if args.solvers == "krylov" else "smoothSolver+symGaussSeidel maxIter 10"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_dic_sweeps": sweeps, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     case.close()

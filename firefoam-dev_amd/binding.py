@@ -119,6 +119,7 @@ def lib():
         "ffm_solve": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, hp, hp,
                        C.POINTER(Perf)], C.c_int),
         "ffm_bench_spmv": ([vp, dp, dp, C.c_int, hp], C.c_int),
+        "ffm_bench_precond": ([vp, C.c_int, dp, dp, C.c_int, hp], C.c_int),
         "ffm_debug_tile_trace": ([vp, C.c_void_p, C.c_int], C.c_int),
         "ffm_reduce_sum": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_min": ([vp, dp, C.c_long, hp], C.c_int),

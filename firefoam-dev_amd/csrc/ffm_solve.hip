@@ -744,6 +744,27 @@ extern "C" int ffm_precond_setup(ffm_ldu *A, int precond, double *rD_out_d)
     return FFM_OK;
 }
 
+// timing helper for bench.py: `reps` preconditioner applications (DIC: a forward and a backward sweep each) on the matrix bound
+// to the LDU, bracketed by HIP events on the context stream; average time of ONE application in milliseconds
+extern "C" int ffm_bench_precond(ffm_ldu *A, int precond, const double *r_d, double *w_d, int reps, double *avg_ms)
+{
+    if (!A || !r_d || !w_d || reps < 1 || !avg_ms) return FFM_ERR_ARG;
+    if (!A->identity) { ffm_set_error("ffm_bench_precond needs an LDU in the library's cell order"); return FFM_ERR_UNSUPPORTED; }
+    FFM_TRY(ffm_precond_setup_i(A, precond));
+    FFM_TRY(ffm_precond_apply_i(A, precond, false, r_d, w_d));      // warm-up
+    hipEvent_t e0, e1;
+    FFM_HIP(hipEventCreate(&e0)); FFM_HIP(hipEventCreate(&e1));
+    FFM_HIP(hipEventRecord(e0, A->ctx->stream));
+    for (int i = 0; i < reps; i++) FFM_TRY(ffm_precond_apply_i(A, precond, false, r_d, w_d));
+    FFM_HIP(hipEventRecord(e1, A->ctx->stream));
+    FFM_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FFM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *avg_ms = (double)ms / reps;
+    return FFM_OK;
+}
+
 extern "C" int ffm_precond_apply(ffm_ldu *A, int precond, int transpose, const double *r_d, double *w_d)
 {
     if (!A || !r_d || !w_d) return FFM_ERR_ARG;

@@ -211,6 +211,8 @@ int ffm_solve(ffm_ldu *ldu, int solver, int precond, double tolerance,
  * events on that stream; returns the average kernel time in milliseconds.    */
 int ffm_bench_spmv(ffm_ldu *ldu, const double *x_d, double *y_d, int reps,
                    double *avg_ms);
+/* the same for one preconditioner application (DIC: forward + backward sweep) on the bound matrix */
+int ffm_bench_precond(ffm_ldu *ldu, int precond, const double *r_d, double *w_d, int reps, double *avg_ms);
 
 /* ------------------------------------------------------- finite-volume mesh */
 /* fvMesh geometry on the device (mesh.V(), Sf(), magSf(), weights(), deltaCoeffs(),
