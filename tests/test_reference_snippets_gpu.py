@@ -213,8 +213,7 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
         errs["p_rgh_b"] = np.abs(out["p_rghB"] - bnd(ref.p_rgh_b)).max() / max(np.abs(bnd(ref.p_rgh_b)).max(), 1e-30)
         tol = {"p_rgh": 1e-5, "dpdt": 1e-5, "phi": 1e-7, "p_rgh_b": 1e-5}
         bad = {k: v for k, v in errs.items() if not v < tol.get(k, 1e-8)}
-        print("SNIPERRS", step, {k: float("%.3g" % v) for k, v in errs.items()})
-        assert not bad, (step, bad)
+        assert not bad, (step, bad, {k: float("%.3g" % v) for k, v in errs.items()})
     A.close()
 
 
