@@ -268,3 +268,25 @@ extern "C" int b1_read_case(const char* fvSolutionPath, const char* fvSchemesPat
     put(sol.equationRelaxation("U"));
     return n;
 }
+
+// a field file through include/ffmDictionary.H: for every patch name in `patches` {known-type flag, value fraction, refValue,
+// refGradient, first number of `value` (NaN if absent)}; before them the first number of internalField.  Patch types are
+// returned, blank-separated, in typesOut.
+#include <cmath>
+extern "C" int b1_read_field(const char* path, const char* patches, double* out, int cap, char* typesOut, int typesCap)
+{
+    const fieldFile ff(path);
+    int n = 0;
+    auto put = [&](double v) { if (n < cap) out[n] = v; n++; };
+    put(ff.internalField()[0]);
+    std::istringstream ps(patches); word w; std::string types;
+    while (ps >> w) {
+        scalar f, ref, grad;
+        const bool ok = ff.mixedForm(w, f, ref, grad);
+        put(ok); put(f); put(ref); put(grad);
+        put(ff.patch(w).found("value") ? ff.patchValue(w)[0] : std::nan(""));
+        types += ff.patchType(w) + " ";
+    }
+    std::strncpy(typesOut, types.c_str(), typesCap - 1); typesOut[typesCap - 1] = 0;
+    return n;
+}

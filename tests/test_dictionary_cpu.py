@@ -68,3 +68,38 @@ def test_wallFireSpread2D_dictionaries():
     assert out[6 * 3 + 6] == -1                           # div(phi,U) Gauss filteredLinear2V 0.2 0.05: known, not built
     assert out[-3] == 1 and out[-2] == 1                  # Gauss linear corrected / corrected
     assert abs(out[-1] - 0.9) < 1e-12 or out[-1] == 1 or out[-1] == -1      # relaxationFactors::equations (0.9 in this case)
+
+
+def _field(case, name, patches):
+    lib, _ = _lib()
+    lib.b1_read_field.restype = C.c_int
+    lib.b1_read_field.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_char_p, C.c_int]
+    out = np.zeros(1 + 5 * len(patches)); types = C.create_string_buffer(1024)
+    n = lib.b1_read_field(os.path.join(REF, case, "0", name).encode(), " ".join(patches).encode(), out.ctypes.data_as(C.POINTER(C.c_double)), len(out), types, 1024)
+    assert n == len(out)
+    rows = out[1:].reshape(len(patches), 5)
+    return out[0], dict(zip(patches, rows)), dict(zip(patches, types.value.decode().split()))
+
+
+def test_steckler_field_files_hold_what_the_golden_log_match_rests_on():
+    """The case data behind oracle/steckler.py, read from the reference's own 0/ files by include/ffmDictionary.H::fieldFile:
+    ph_rgh is fixedValue 0 on `top` and fixedFluxPressure everywhere else; T = 298.15 K, O2 = 0.23301, N2 = 0.76699 inside;
+    N2 is `calculated; value uniform 0` on top / sides / base / floor (the boundary mixture there is O2 alone until the first
+    YEEqn -- the detail that makes the first final residual 0.0080439052); the baffle patches carry T = 300, O2 = 0.232,
+    N2 = 0.768; the burner's velocity is (0 0 0) at t = 0."""
+    P = ["top", "sides", "base", "burner", "floor", "baffle1DWall_master", "baffle1DWall_slave"]
+    i, r, t = _field("steckler", "ph_rgh.orig", P)
+    assert i == 0.0 and t["top"] == "fixedValue" and tuple(r["top"][:3]) == (1, 1, 0)          # known, f = 1, ref = 0
+    assert all(t[p] == "fixedFluxPressure" and tuple(r[p][:4]) == (1, 0, 0, 0) for p in P[1:])
+    i, r, t = _field("steckler", "T", P)
+    assert i == 298.15 and r["baffle1DWall_master"][4] == 300 and r["baffle1DWall_slave"][4] == 300
+    assert t["top"] == "inletOutlet" and tuple(r["top"][1:3]) == (-1, 298.15)                   # 1 - pos0(phi), inletValue
+    i, r, t = _field("steckler", "O2", P)
+    assert i == 0.23301 and t["baffle1DWall_master"] == "fixedValue" and r["baffle1DWall_master"][2] == 0.232
+    i, r, t = _field("steckler", "N2", P)
+    assert i == 0.76699 and r["baffle1DWall_slave"][2] == 0.768
+    for p in ("top", "sides", "base", "floor"):
+        assert t[p] == "calculated" and r[p][0] == 0 and r[p][4] == 0.0                          # no mixed form; value uniform 0
+    i, r, t = _field("steckler", "U", ["burner", "base", "top"])
+    assert i == 0.0 and t["burner"] == "flowRateInletVelocity" and r["burner"][4] == 0.0 and t["top"] == "pressureInletOutletVelocity"
+    assert t["base"] == "noSlip"
