@@ -290,3 +290,24 @@ extern "C" int b1_read_field(const char* path, const char* patches, double* out,
     std::strncpy(typesOut, types.c_str(), typesCap - 1); typesOut[typesCap - 1] = 0;
     return n;
 }
+
+// generic look-up through include/ffmDictionary.H: keyPath = "a/b/c" walks sub-dictionaries (pattern keywords included); the
+// tokens of the entry come back blank-separated (a sub-dictionary answers "{}")
+extern "C" int b1_dict_lookup(const char* path, const char* keyPath, char* out, int cap)
+{
+    const dictionaryFile f(path);
+    const dictionaryFile::node* n = &f.top;
+    std::string kp(keyPath), res;
+    size_t p0 = 0;
+    for (;;) {
+        const size_t q = kp.find('/', p0);
+        const word k = kp.substr(p0, q == std::string::npos ? std::string::npos : q - p0);
+        const dictionaryFile::entry* e = n->find(k);
+        if (!e) return -1;
+        if (q == std::string::npos) { if (e->sub && e->tokens.empty()) res = "{}"; else for (const word& t : e->tokens) res += (res.empty() ? "" : " ") + t; break; }
+        if (!e->sub) return -1;
+        n = e->sub.get(); p0 = q + 1;
+    }
+    std::strncpy(out, res.c_str(), cap - 1); out[cap - 1] = 0;
+    return (int)res.size();
+}

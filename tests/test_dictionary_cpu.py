@@ -103,3 +103,24 @@ def test_steckler_field_files_hold_what_the_golden_log_match_rests_on():
     i, r, t = _field("steckler", "U", ["burner", "base", "top"])
     assert i == 0.0 and t["burner"] == "flowRateInletVelocity" and r["burner"][4] == 0.0 and t["top"] == "pressureInletOutletVelocity"
     assert t["base"] == "noSlip"
+
+
+def test_case_constants_of_the_oracle_come_from_the_reference_files():
+    """the constants oracle/steckler.py, oracle/plume.py and bench.py quote from the reference's case, looked up in its files"""
+    lib, _ = _lib()
+    lib.b1_dict_lookup.restype = C.c_int
+    lib.b1_dict_lookup.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+
+    def look(rel, key):
+        buf = C.create_string_buffer(512)
+        assert lib.b1_dict_lookup(os.path.join(REF, "steckler", rel).encode(), key.encode(), buf, 512) >= 0, (rel, key)
+        return buf.value.decode()
+    assert look("constant/g", "value") == "(0 -9.81 0)" and float(look("constant/hRef", "value")) == 3.0
+    assert float(look("constant/pRef", "value")) == 101325.0
+    assert (look("constant/radiationProperties", "fvDOMCoeffs/nPhi"), look("constant/radiationProperties", "fvDOMCoeffs/nTheta")) == ("2", "4")
+    assert look("constant/radiationProperties", "solverFreq") == "100" and look("constant/radiationProperties", "fvDOMCoeffs/maxIter") == "1"
+    assert look("system/controlDict", "adjustTimeStep") == "yes" and float(look("system/controlDict", "maxCo")) == 0.9
+    assert float(look("constant/thermo.compressibleGas", "O2/specie/molWeight")) == 31.9988
+    assert float(look("constant/thermo.compressibleGas", "N2/specie/molWeight")) == 28.0134
+    assert look("system/fvSolution", "solvers/UFinal/smoother") == "symGaussSeidel"      # through the pattern "U.*"
+    assert look("system/fvSchemes", "divSchemes/div(Ji,Ii_h)") == "Gauss upwind"
