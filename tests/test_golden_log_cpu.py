@@ -73,3 +73,42 @@ def test_fvdom_ray_solid_angles_against_golden_log(O):
     assert len(rays) == len(gold) == 32
     for (_, omega), g in zip(rays, gold):
         assert "%.8g" % omega == "%.8g" % g
+
+
+def test_steckler_geometry_of_the_oracle_follows_the_reference_case_files(O):
+    """oracle/steckler.py hard-codes the room as cell index ranges; here the same ranges are derived from the numbers in the
+    reference's own files -- blockMeshDict (vertices, convertToMeters, cells), topoSetDictCompartment (compartment and doorway
+    boxes) -- and the baffle / doorway face counts of the oracle's mesh are compared with them.  Skipped where the reference is
+    not mounted."""
+    import re
+    import pytest
+    case = "/root/reference/cases/steckler"
+    if not os.path.exists(os.path.join(case, "system", "topoSetDictCompartment")):
+        pytest.skip("reference not mounted")
+    from oracle import steckler
+    strip = lambda s: re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", s, flags=re.S))
+    bm = strip(open(os.path.join(case, "constant", "polyMesh", "blockMeshDict")).read())
+    scale = float(re.search(r"convertToMeters\s+([0-9.eE+-]+)", bm).group(1))
+    verts = np.array([[float(x) for x in v.split()] for v in re.findall(r"\(\s*(-?[\d.]+\s+-?[\d.]+\s+-?[\d.]+)\s*\)", bm.split("vertices")[1].split("blocks")[0])]) * scale
+    n = tuple(int(x) for x in re.search(r"hex\s*\([^)]*\)\s*\(\s*(\d+)\s+(\d+)\s+(\d+)\s*\)", bm).groups())
+    lo, hi = verts.min(axis=0), verts.max(axis=0)
+    assert n == (30, 15, 20) and np.allclose(lo, (-2, 0, -2)) and np.allclose(hi, (4, 3, 2))
+    ts = strip(open(os.path.join(case, "system", "topoSetDictCompartment")).read())
+    boxes = [np.array([float(x) for x in (a + " " + b).split()]).reshape(2, 3)
+             for a, b in re.findall(r"box\s*\(([^)]*)\)\s*\(([^)]*)\)", ts)]
+    room = next(b for b in boxes if np.allclose(b, [(-1.4, 0, -1.4), (1.4, 2.18, 1.4)]))
+    door = next(b for b in boxes if np.allclose(b, [(0, 0, -0.5), (10, 1, 0.5)]))
+    d = (hi - lo) / np.array(n)
+    m = steckler.build_mesh()
+    centres = [lo[a] + (np.arange(n[a]) + 0.5) * d[a] for a in range(3)]
+    inside = [np.nonzero((centres[a] >= room[0, a]) & (centres[a] <= room[1, a]))[0] for a in range(3)]
+    assert (inside[0][0], inside[0][-1], inside[1][-1], inside[2][0], inside[2][-1]) == (3, 16, 10, 3, 16)      # oracle/steckler.py:build_mesh
+    ni, nj, nk = (len(x) for x in inside)
+    # shell of the room = faces between a room cell and an outside cell (the floor, y = 0, is a boundary, not a baffle)
+    shell = 2 * nj * nk + 2 * ni * nj + ni * nk
+    eps = 1e-9
+    door_j = np.nonzero(centres[1] <= door[1, 1] + eps)[0]                      # face centres of the x = 1.4 wall: same y, z as the cells
+    door_k = np.nonzero((centres[2] >= door[0, 2] - eps) & (centres[2] <= door[1, 2] + eps))[0]     # inclusive: z = +-0.5 are in
+    assert (door_j[-1], door_k[0], door_k[-1]) == (4, 7, 12)
+    baffle = m.patch("baffle1DWall_master").size
+    assert baffle == m.patch("baffle1DWall_slave").size == shell - len(door_j) * len(door_k)
