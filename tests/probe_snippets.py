@@ -1,9 +1,9 @@
 """Time the reference's equation files (examples/fireFoam_snippets.C -> libffm_refsnippets.so) on a box of n^3 cells next to the
 compiled plume driver: the cost of the unfused class layer (one kernel and one temporary per operator).
-usage: snippets_probe.py n [steps]"""
+usage: tests/probe_snippets.py n [steps]   (lives under tests/ because it takes its constants and mesh from the oracle)"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from ffm_import import ffm
 from oracle import plume            # constants and the mesh description only (probe script, not product)
