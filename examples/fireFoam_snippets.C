@@ -43,6 +43,7 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     const double* psiB; double* resOut;
     // time-step control (controlDict adjustTimeStep / maxCo / maxDeltaT) for firefoam_snippets_time_step; dtOut: the deltaT used
     int adjustTimeStep; double maxCo, maxDeltaT; double* dtOut;
+    int emptyDirections;        // bit d set: direction d is not solved (a 2-D case's `empty` patches): mesh.solutionD[d] = -1
 };
 
 // ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
@@ -107,6 +108,7 @@ struct snippetSolver
       timeControls{cs->adjustTimeStep != 0, cs->maxCo, cs->maxDeltaT}, maxDi(pyrolysis.maxDiff())
     {
         runTime.link(mesh.deltaT);
+        for (int d = 0; d < 3; d++) if (cs->emptyDirections & (1 << d)) mesh.solutionD[d] = -1;
         mesh.solvers["rho"] = mesh.solvers["rhoFinal"] = {FFM_DIAGONAL, FFM_NONE, 1e-6, 0, 0, 1000, 1};
         mesh.solvers["U"] = mesh.solvers["UFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-6, 0, 0, 1000, 1};
         mesh.solvers["Yi"] = mesh.solvers["YiFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-8, 0, 0, 1000, 1};

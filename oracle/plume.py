@@ -57,6 +57,7 @@ def make_mesh(n, h=0.05, empty=()):
         m._bdefs[name] = fv.Patch(name, ymin.faceCells[sel], ymin.Sf[sel], ymin.Cf[sel], ymin.deltaCoeffs[sel])
     m.set_patches([("inlet", ["inlet_part"]), ("floor", ["floor_part"]), ("top", ["ymax"]),
                    ("sides", [g for g in ("xmin", "xmax", "zmin", "zmax") if g not in empty])])
+    m.solutionD = [-1 if ("xmin" in empty and "xmax" in empty) else 1, 1, -1 if ("zmin" in empty and "zmax" in empty) else 1]
     return m
 
 
@@ -292,6 +293,8 @@ class Plume:
         sgp, sgpb = fv.snGrad(m, self.p_rgh, self.p_rgh_b if self.stored_bc else bcp.values(m, self.p_rgh))
         rec = fv.reconstruct(m, (-self.ghf * sgr - sgp) * m.magSf, [-s * p.magSf for s, p in zip(sgpb, m.patches)])
         for c in range(3):
+            if getattr(m, "solutionD", (1, 1, 1))[c] < 0:          # fvMatrix<vector>::solveSegregated skips the empty directions
+                continue
             d, s = UEqn.solve_system(c)
             s = s + m.V * rec[:, c]
             self.U[c] = self.sol.solve("U", "U" + "xyz"[c], m, d, UEqn.upper, UEqn.lower, s, self.U[c])
