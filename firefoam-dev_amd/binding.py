@@ -121,6 +121,8 @@ def lib():
         "ffm_bench_spmv": ([vp, dp, dp, C.c_int, hp], C.c_int),
         "ffm_bench_precond": ([vp, C.c_int, dp, dp, C.c_int, hp], C.c_int),
         "ffm_debug_tile_trace": ([vp, C.c_void_p, C.c_int], C.c_int),
+        "ffm_debug_set_sweep_ticket": ([vp, C.c_uint], C.c_int),
+        "ffm_ldu_set_exchange_tags": ([vp, C.c_int, C.c_int, ip], C.c_int),
         "ffm_reduce_sum": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_min": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_max": ([vp, dp, C.c_long, hp], C.c_int),
@@ -356,8 +358,12 @@ class lduMatrix:
 
     @property
     def sweep_mode(self):
-        """0 level-scheduled, 2 tiled wavefront, 1 pipelined groups (experimental)"""
+        """0 level-scheduled, 2 tiled wavefront"""
         return lib().ffm_ldu_sweep_mode(self.h)
+
+    def debug_set_sweep_ticket(self, value):
+        """tests: preset the group ticket counter of the tiled sweeps (each sweep launch zeroes it again)"""
+        _check(lib().ffm_debug_set_sweep_ticket(self.h, int(value) & 0xFFFFFFFF), "ffm_debug_set_sweep_ticket")
 
     @property
     def native_order(self):

@@ -35,6 +35,38 @@
         }                                                                        \
     } while (0)
 
+// inside an ncclGroup: close the group before reporting the error, so that the next call does not find it open
+#define FFM_NCCL_IN_GROUP(call)                                                  \
+    do {                                                                         \
+        ncclResult_t r_ = (call);                                                \
+        if (r_ != ncclSuccess) {                                                 \
+            ffm_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call,           \
+                          ncclGetErrorString(r_));                               \
+            ncclGroupEnd();                                                      \
+            return FFM_ERR_COMM;                                                 \
+        }                                                                        \
+    } while (0)
+
+// posting order of the point-to-point messages of one exchange: RCCL matches several messages between the same pair of
+// ranks in issue order, so both ranks must post the messages they share in the same relative order -- ascending pair tag
+// (ffm_ldu_set_exchange_tags; default: the entry index, i.e. both sides list their common patches in the same order)
+static std::vector<int> posting_order(int n, const std::vector<int> &tags)
+{
+    std::vector<int> o(n);
+    for (int i = 0; i < n; i++) o[i] = i;
+    if ((int)tags.size() == n) std::stable_sort(o.begin(), o.end(), [&](int a, int b) { return tags[a] < tags[b]; });
+    return o;
+}
+
+extern "C" int ffm_ldu_set_exchange_tags(ffm_ldu *A, int kind, int n, const int *tags)
+{
+    if (!A || (kind != 0 && kind != 1) || n < 0 || (n && !tags)) return FFM_ERR_ARG;
+    const int have = kind == 0 ? (int)A->ifaces.size() : (int)A->ghNbrRank.size();
+    if (n != have) { ffm_set_error("ffm_ldu_set_exchange_tags: %d tags for %d entries", n, have); return FFM_ERR_ARG; }
+    (kind == 0 ? A->ifaceTags : A->ghTags).assign(tags, tags + n);
+    return FFM_OK;
+}
+
 extern "C" int ffm_comm_unique_id(void *uniqueId128)
 {
     if (!uniqueId128) return FFM_ERR_ARG;
@@ -122,7 +154,7 @@ extern "C" int ffm_ldu_set_interfaces(ffm_ldu *A, int nPatches, const int *patch
     if (A->haloRecv_h) { hipHostFree(A->haloRecv_h); A->haloRecv_h = nullptr; }
     A->ifFaceCells = nullptr; A->ifBou = A->ifInt = A->haloSend = A->haloRecv = nullptr;
     A->ifCell = A->ifCellStart = A->ifItem = nullptr;
-    A->ifaces.clear(); A->haloTotal = 0; A->nIfCells = 0;
+    A->ifaces.clear(); A->ifaceTags.clear(); A->haloTotal = 0; A->nIfCells = 0;
     for (auto &kv : A->graphs) hipGraphExecDestroy(kv.second);   // halo buffers are baked into no graph, but be safe
     A->graphs.clear();
     if (!nPatches) return FFM_OK;
@@ -201,11 +233,13 @@ int ffm_halo_exchange(ffm_ldu *A, const double *x)
                        A->haloTotal, A->ifFaceCells, x, A->haloSend);
     FFM_HIP(hipGetLastError());
     if (c->comm) {
+        const std::vector<int> order = posting_order((int)A->ifaces.size(), A->ifaceTags);
         FFM_NCCL(ncclGroupStart());
-        for (const ffm_iface &p : A->ifaces) {
+        for (int i : order) {
+            const ffm_iface &p = A->ifaces[i];
             if (!p.size) continue;
-            FFM_NCCL(ncclSend(A->haloSend + p.offset, p.size, ncclDouble, p.nbrRank, (ncclComm_t)c->comm, c->stream));
-            FFM_NCCL(ncclRecv(A->haloRecv + p.offset, p.size, ncclDouble, p.nbrRank, (ncclComm_t)c->comm, c->stream));
+            FFM_NCCL_IN_GROUP(ncclSend(A->haloSend + p.offset, p.size, ncclDouble, p.nbrRank, (ncclComm_t)c->comm, c->stream));
+            FFM_NCCL_IN_GROUP(ncclRecv(A->haloRecv + p.offset, p.size, ncclDouble, p.nbrRank, (ncclComm_t)c->comm, c->stream));
         }
         FFM_NCCL(ncclGroupEnd());
         return FFM_OK;
@@ -252,7 +286,7 @@ extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRa
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); A->ghSendCells = nullptr; A->ghSendBuf = nullptr;
     if (A->ghSendBuf_h) { hipHostFree(A->ghSendBuf_h); A->ghSendBuf_h = nullptr; }
     if (A->ghRecvBuf_h) { hipHostFree(A->ghRecvBuf_h); A->ghRecvBuf_h = nullptr; }
-    A->ghNbrRank.assign(nbrRank, nbrRank + nNbr);
+    A->ghNbrRank.assign(nbrRank, nbrRank + nNbr); A->ghTags.clear();
     A->ghSendOff.assign(nNbr + 1, 0); A->ghRecvOff.assign(nNbr + 1, 0);
     for (int q = 0; q < nNbr; q++) { A->ghSendOff[q + 1] = A->ghSendOff[q] + sendCount[q]; A->ghRecvOff[q + 1] = A->ghRecvOff[q] + recvCount[q]; }
     if (A->ghRecvOff[nNbr] != A->nCells - A->nOwned) { ffm_set_error("ghost exchange: receive counts (%d) != ghost cells (%d)", A->ghRecvOff[nNbr], A->nCells - A->nOwned); A->ghNbrRank.clear(); return FFM_ERR_ARG; }
@@ -277,11 +311,12 @@ int ffm_ghost_exchange(ffm_ldu *A, double *x)
     FFM_HIP(hipGetLastError());
     double *ghost = x + A->nOwned;
     if (c->comm) {
+        const std::vector<int> order = posting_order(nNbr, A->ghTags);
         FFM_NCCL(ncclGroupStart());
-        for (int q = 0; q < nNbr; q++) {
+        for (int q : order) {
             const int ns = A->ghSendOff[q + 1] - A->ghSendOff[q], nr = A->ghRecvOff[q + 1] - A->ghRecvOff[q];
-            if (ns) FFM_NCCL(ncclSend(A->ghSendBuf + A->ghSendOff[q], ns, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
-            if (nr) FFM_NCCL(ncclRecv(ghost + A->ghRecvOff[q], nr, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
+            if (ns) FFM_NCCL_IN_GROUP(ncclSend(A->ghSendBuf + A->ghSendOff[q], ns, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
+            if (nr) FFM_NCCL_IN_GROUP(ncclRecv(ghost + A->ghRecvOff[q], nr, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
         }
         FFM_NCCL(ncclGroupEnd());
         return FFM_OK;

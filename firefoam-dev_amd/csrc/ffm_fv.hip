@@ -298,7 +298,8 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
                 const double gradcf = dx * gx[up] + dy * gy[up] + dz * gz[up];
                 double r;
                 if (fabs(gradcf) >= 1000.0 * fabs(gradf)) {
-                    const double sa = (gradcf > 0) - (gradcf < 0), sb = (gradf > 0) - (gradf < 0);
+                    // OpenFOAM's sign(): (s >= 0) ? 1 : -1, never 0 -- a uniform region gets r = 1999, limiter 1, linear weights
+                    const double sa = gradcf >= 0 ? 1.0 : -1.0, sb = gradf >= 0 ? 1.0 : -1.0;
                     r = 2.0 * 1000.0 * sa * sb - 1.0;
                 } else r = 2.0 * (gradcf / gradf) - 1.0;
                 double lim = fmax(fmin(twoByk * r, 1.0), 0.0);

@@ -74,12 +74,16 @@ struct ffm_ctx {
     size_t poolCachedBytes = 0, poolCapBytes = (size_t)96 << 30;
 };
 
+// key of a cached hipGraph of level-scheduled sweeps: EVERY device pointer the captured kernels bake in
 struct SweepGraphKey {
-    int kind; const void *a; const void *b; const void *c;
+    int kind; const void *p[6];
     bool operator<(const SweepGraphKey &o) const {
-        return std::tie(kind, a, b, c) < std::tie(o.kind, o.a, o.b, o.c);
+        if (kind != o.kind) return kind < o.kind;
+        for (int i = 0; i < 6; i++) if (p[i] != o.p[i]) return p[i] < o.p[i];
+        return false;
     }
 };
+constexpr size_t FFM_MAX_SWEEP_GRAPHS = 24;     // cap of the per-matrix graph cache (oldest entries are dropped first)
 
 struct ffm_iface {
     int size = 0, nbrRank = -1;
@@ -152,6 +156,7 @@ struct ffm_ldu {
 
     // interfaces (processor patches), packed patch after patch
     std::vector<ffm_iface> ifaces;
+    std::vector<int> ifaceTags, ghTags;   // pair tags: posting order of the point-to-point messages (ffm_ldu_set_exchange_tags)
     int haloTotal = 0;
     int *ifFaceCells = nullptr;    // [haloTotal] internal numbering
     double *ifBou = nullptr, *ifInt = nullptr;   // [haloTotal]
@@ -168,23 +173,19 @@ struct ffm_ldu {
     int *ghSendCells = nullptr;
     double *ghSendBuf = nullptr, *ghSendBuf_h = nullptr, *ghRecvBuf_h = nullptr;
 
-    // ---- pipelined sweep plan (sweepMode == 1): cells are numbered group-major, level-major inside a group;
-    // group g = cells [grpCell[g], grpCell[g+1]); one workgroup sweeps one group level by level
-    int sweepMode = 0;              // 0: one launch per level (level-major numbering); 1: pipelined groups
+    // ---- tiled sweep plan (sweepMode == 2): cells are numbered group-major, level-major inside a group;
+    // group g = cells [grpCell[g], grpCell[g+1]); one workgroup sweeps one group level by level (ffm_tile.hip)
+    int sweepMode = 0;              // 0: one launch per level (level-major numbering); 2: tiled wavefront sweeps
     int nGroups = 0;
     bool bwdIsReverse = false;      // inside every group the backward order is the exact reverse of the forward order
     int *grpCell = nullptr;         // [G+1]
-    int *fEntStart = nullptr, *fEntLevel = nullptr, *fEntCell = nullptr;   // [G+1], [E], [E+1]  forward entries (level, first cell)
-    int *fPredStart = nullptr, *fPreds = nullptr;                           // [G+1], [..] groups owning lower neighbours
-    int *bEntStart = nullptr, *bEntLevel = nullptr, *bEntPos = nullptr;    // backward entries: positions into bwdCells
-    int *bPredStart = nullptr, *bPreds = nullptr;                           // groups owning upper neighbours
     int *bwdCells = nullptr;        // [nOwned] cells in (group, backward level) order
-    unsigned long long *pipeProgress = nullptr;   // [G] (epoch<<32 | levels done)
-    unsigned int *pipeTicket = nullptr;           // [2]: ticket counter, abort flag
+    unsigned int *sweepTicket = nullptr;          // [2]: ticket counter (zeroed on the stream before every sweep), abort flag
     ffm_tile_plan *tile = nullptr;                // tiled wavefront plan (sweepMode == 2)
 
     // cached hipGraphs of level-scheduled sweeps
     std::map<SweepGraphKey, hipGraphExec_t> graphs;
+    std::vector<SweepGraphKey> graphOrder;         // insertion order, for the cap
 };
 
 struct LduView;
@@ -218,10 +219,7 @@ int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot);     // r
 void ffm_tile_free(ffm_ldu *A);
 bool ffm_tile_usable(const ffm_ldu *A);
 int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
-int ffm_pipe_calc_rD(ffm_ldu *A);
-int ffm_pipe_precond(ffm_ldu *A, const double *cf, const double *cb, const double *r, double *w);
-int ffm_pipe_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSave);
-int ffm_pipe_check_abort(ffm_ldu *A);
+int ffm_tile_check_abort(ffm_ldu *A);
 int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b);
 int ffm_halo_exchange(ffm_ldu *A, const double *x);
 int ffm_ghost_exchange(ffm_ldu *A, double *x);                 // refresh x[nOwned..nCells) from the neighbour ranks          // pack x[faceCells], exchange into haloRecv

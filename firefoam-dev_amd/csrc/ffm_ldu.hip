@@ -43,22 +43,21 @@ struct LduAnalysis {
     std::vector<int> bwdLevelStart;        // [nBwd+1] into bwdOrder
     std::vector<int> bwdOrder;             // cells sorted by backward level
     bool identity = true, bwdContig = true;
-    // pipelined-sweep plan (mode 1)
+    // group plan of the tiled sweeps (mode 2)
     int mode = 0, nGroups = 0; bool bwdIsReverse = false;
     std::vector<int> levNew, blNew;         // forward / backward level of every owned cell (new numbering)
-    std::vector<int> grpCell, fEntStart, fEntLevel, fEntCell, fPredStart, fPreds, bEntStart, bEntLevel, bEntPos, bPredStart, bPreds, bwdCells;
+    std::vector<int> grpCell, bwdCells;
 };
 
-// Sweep modes.  0 "levels": one launch per dependency level (level-major numbering).  1 "pipe": pipelined group sweep with
-// a hand-off per level (ffm_pipe.hip, experimental, FFM_SWEEP=pipe only).  2 "tile": tiled wavefront sweep (ffm_tile.hip).
-// Default (FFM_SWEEP unset or "auto"): tile when the caller gives a group hint or the mesh is a blockMesh-numbered box and
-// the plan is feasible, levels otherwise.  FFM_SWEEP=tile also tiles un-hinted meshes (chunks of the cell order; tests).
+// Sweep modes.  0 "levels": one launch per dependency level (level-major numbering).  2 "tile": tiled wavefront sweep
+// (ffm_tile.hip).  Default (FFM_SWEEP unset or "auto"): tile when the caller gives a group hint or the mesh is a
+// blockMesh-numbered box and the plan is feasible, levels otherwise.  FFM_SWEEP=tile also tiles un-hinted meshes (chunks of
+// the cell order; tests).
 enum { SWEEP_AUTO = 3 };
 static int default_sweep_mode()
 {
     const char *e = getenv("FFM_SWEEP");
     if (!e || e[0] == 'a' || e[0] == 'A') return SWEEP_AUTO;
-    if (e[0] == 'p' || e[0] == 'P' || e[0] == '1') return 1;
     if (e[0] == 't' || e[0] == 'T' || e[0] == '2') return 2;
     return 0;
 }
@@ -309,50 +308,20 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         const int G = a.nGroups;
         a.levNew.resize(nOwn); a.blNew.assign(bl.begin(), bl.begin() + nOwn);
         for (int c = 0; c < nOwn; c++) a.levNew[c] = lev[a.newToOldCell[c]];
-        // forward entries: runs of equal level inside each group (new numbering is level-major inside a group)
-        a.fEntStart.assign(G + 1, 0);
-        for (int g = 0; g < G; g++) {
-            int prev = -1;
-            for (int c = a.grpCell[g]; c < a.grpCell[g + 1]; c++) {
-                const int L = lev[a.newToOldCell[c]];
-                if (L != prev) { a.fEntLevel.push_back(L); a.fEntCell.push_back(c); prev = L; }
-            }
-            a.fEntStart[g + 1] = (int)a.fEntLevel.size();
-        }
-        a.fEntCell.push_back(nOwn);
-        // fix the end of each group's last entry: fEntCell[e+1] of the last entry of g must be grpCell[g+1]; since groups are
-        // contiguous and entries are appended in cell order, fEntCell[e+1] is the first cell of the next group's first entry = grpCell[g+1]
-        // predecessors / successors between groups
-        std::vector<std::vector<int>> fp(G), bp(G);
+        // the group graph must be acyclic in the new numbering: every cross-group face points from a lower to a higher group
         auto grpOfNew = [&](int c) { return grpOfOld[a.newToOldCell[c]]; };
         for (int f = 0; f < F; f++) {
             if (a.u[f] >= nOwn) continue;
-            const int gl = grpOfNew(a.l[f]), gu = grpOfNew(a.u[f]);
-            if (gl != gu) { fp[gu].push_back(gl); bp[gl].push_back(gu); }
-        }
-        a.fPredStart.assign(G + 1, 0); a.bPredStart.assign(G + 1, 0);
-        for (int g = 0; g < G; g++) {
-            std::sort(fp[g].begin(), fp[g].end()); fp[g].erase(std::unique(fp[g].begin(), fp[g].end()), fp[g].end());
-            std::sort(bp[g].begin(), bp[g].end()); bp[g].erase(std::unique(bp[g].begin(), bp[g].end()), bp[g].end());
-            a.fPreds.insert(a.fPreds.end(), fp[g].begin(), fp[g].end()); a.fPredStart[g + 1] = (int)a.fPreds.size();
-            a.bPreds.insert(a.bPreds.end(), bp[g].begin(), bp[g].end()); a.bPredStart[g + 1] = (int)a.bPreds.size();
-            for (int q : fp[g]) if (q >= g) { ffm_set_error("internal: group graph not acyclic"); return FFM_ERR_ADDR; }
+            if (grpOfNew(a.l[f]) > grpOfNew(a.u[f])) { ffm_set_error("internal: group graph not acyclic"); return FFM_ERR_ADDR; }
         }
         // backward order inside each group: by backward level, then descending cell index
-        a.bwdCells.resize(nOwn); a.bEntStart.assign(G + 1, 0); a.bwdIsReverse = true;
+        a.bwdCells.resize(nOwn); a.bwdIsReverse = true;
         for (int g = 0; g < G; g++) {
             const int c0 = a.grpCell[g], c1 = a.grpCell[g + 1];
             for (int c = c0; c < c1; c++) a.bwdCells[c0 + (c1 - 1 - c)] = c;      // descending cell index
             std::stable_sort(a.bwdCells.begin() + c0, a.bwdCells.begin() + c1, [&](int x, int y) { return bl[x] < bl[y]; });
-            int prev = -1;
-            for (int p = c0; p < c1; p++) {
-                if (a.bwdCells[p] != c1 - 1 - (p - c0)) a.bwdIsReverse = false;
-                const int L = bl[a.bwdCells[p]];
-                if (L != prev) { a.bEntLevel.push_back(L); a.bEntPos.push_back(p); prev = L; }
-            }
-            a.bEntStart[g + 1] = (int)a.bEntLevel.size();
+            for (int p = c0; p < c1; p++) if (a.bwdCells[p] != c1 - 1 - (p - c0)) a.bwdIsReverse = false;
         }
-        a.bEntPos.push_back(nOwn);
     }
     if (a.mode == 2 && !ffm_tile_feasible(nOwn, F, a.l.data(), a.u.data())) {
         if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm: tiled sweeps not applicable (more than 3 lower or upper neighbours): level-scheduled sweeps\n");
@@ -446,14 +415,31 @@ extern "C" int ffm_ldu_create(ffm_ctx *ctx, int N, int F, const int *l, const in
 extern "C" int ffm_ldu_create_ext(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int *l, const int *u, ffm_ldu **out)
 { return ffm_ldu_create_hint(ctx, nOwn, nGhost, F, l, u, nullptr, out); }
 
+static int ldu_create_impl(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int *l, const int *u, const int *groupHint, int forceMode,
+                           ffm_ldu **out);
+
 extern "C" int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int *l, const int *u, const int *groupHint,
                                    ffm_ldu **out)
 {
-    const int N = nOwn + nGhost;
     if (!ctx || !out || nOwn < 0 || nGhost < 0 || F < 0 || (F && (!l || !u))) { ffm_set_error("ffm_ldu_create: bad argument"); return FFM_ERR_ARG; }
     FFM_HIP(hipSetDevice(ctx->device));
+    FFM_TRY(ldu_create_impl(ctx, nOwn, nGhost, F, l, u, groupHint, -1, out));
+    if ((*out)->sweepMode == 2 && !ffm_tile_usable(*out)) {
+        // the tile planner gave up on this grouping (entry order, external references per entry, ghost faces before owned
+        // ones): the same matrix with level-scheduled sweeps instead
+        if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm: no tile plan for this mesh / grouping: level-scheduled sweeps\n");
+        ffm_ldu_destroy(*out); *out = nullptr;
+        FFM_TRY(ldu_create_impl(ctx, nOwn, nGhost, F, l, u, nullptr, 0, out));
+    }
+    return FFM_OK;
+}
+
+static int ldu_create_impl(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int *l, const int *u, const int *groupHint, int forceMode,
+                           ffm_ldu **out)
+{
+    const int N = nOwn + nGhost;
     LduAnalysis a;
-    FFM_TRY(analyse(N, nOwn, F, l, u, true, false, a, groupHint));
+    FFM_TRY(analyse(N, nOwn, F, l, u, true, false, a, groupHint, forceMode));
     ffm_ldu *A = new ffm_ldu();
     A->ctx = ctx; A->nCells = N; A->nOwned = nOwn; A->nFaces = F; A->globalCells = nOwn;
     A->identity = a.identity; A->bwdContig = a.bwdContig;
@@ -527,21 +513,9 @@ extern "C" int ffm_ldu_create_hint(ffm_ctx *ctx, int nOwn, int nGhost, int F, co
         if (A->sweepMode == 0 && !A->bwdContig && (rc = upload(ctx, &A->bwdOrder, a.bwdOrder))) break;
         if (A->sweepMode >= 1) {
             if ((rc = upload(ctx, &A->grpCell, a.grpCell))) break;
-            if ((rc = upload(ctx, &A->fEntStart, a.fEntStart))) break;
-            if ((rc = upload(ctx, &A->fEntLevel, a.fEntLevel))) break;
-            if ((rc = upload(ctx, &A->fEntCell, a.fEntCell))) break;
-            if ((rc = upload(ctx, &A->fPredStart, a.fPredStart))) break;
-            if ((rc = upload(ctx, &A->fPreds, a.fPreds))) break;
-            if ((rc = upload(ctx, &A->bEntStart, a.bEntStart))) break;
-            if ((rc = upload(ctx, &A->bEntLevel, a.bEntLevel))) break;
-            if ((rc = upload(ctx, &A->bEntPos, a.bEntPos))) break;
-            if ((rc = upload(ctx, &A->bPredStart, a.bPredStart))) break;
-            if ((rc = upload(ctx, &A->bPreds, a.bPreds))) break;
             if ((rc = upload(ctx, &A->bwdCells, a.bwdCells))) break;
-            if (hipMalloc((void **)&A->pipeProgress, sizeof(unsigned long long) * std::max(A->nGroups, 1)) != hipSuccess ||
-                hipMalloc((void **)&A->pipeTicket, 2 * sizeof(unsigned int)) != hipSuccess) { rc = FFM_ERR_HIP; break; }
-            hipMemsetAsync(A->pipeProgress, 0, sizeof(unsigned long long) * std::max(A->nGroups, 1), ctx->stream);
-            hipMemsetAsync(A->pipeTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
+            if (hipMalloc((void **)&A->sweepTicket, 2 * sizeof(unsigned int)) != hipSuccess) { rc = FFM_ERR_HIP; break; }
+            hipMemsetAsync(A->sweepTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
         }
         if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
         if (A->sweepMode == 2) { A->h_loEnt = loEnt; A->h_upNbr = upNbr; rc = ffm_tile_build(A, a.levNew, a.blNew, a.grpCell, a.bwdIsReverse ? nullptr : &a.bwdCells); A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit(); if (rc) break; }
@@ -593,9 +567,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     for (int i = 0; i < 3; i++) hipFree(A->permIn[i]);
     hipFree(A->upOff); hipFree(A->loOff); hipFree(A->upNbr); hipFree(A->loEnt); hipFree(A->faceSrc);
     hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative);
-    hipFree(A->grpCell); hipFree(A->fEntStart); hipFree(A->fEntLevel); hipFree(A->fEntCell); hipFree(A->fPredStart); hipFree(A->fPreds);
-    hipFree(A->bEntStart); hipFree(A->bEntLevel); hipFree(A->bEntPos); hipFree(A->bPredStart); hipFree(A->bPreds); hipFree(A->bwdCells);
-    hipFree(A->pipeProgress); hipFree(A->pipeTicket); hipFree(A->rowSched);
+    hipFree(A->grpCell); hipFree(A->bwdCells); hipFree(A->sweepTicket); hipFree(A->rowSched);
     ffm_tile_free(A);
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); if (A->ghSendBuf_h) hipHostFree(A->ghSendBuf_h); if (A->ghRecvBuf_h) hipHostFree(A->ghRecvBuf_h);
     hipFree(A->diagBuf); hipFree(A->upperBuf); hipFree(A->lowerBuf); hipFree(A->rD);
@@ -606,7 +578,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
 }
 
 extern "C" int ffm_ldu_ncells(const ffm_ldu *A) { return A ? A->nCells : FFM_ERR_ARG; }
-extern "C" int ffm_ldu_sweep_mode(const ffm_ldu *A) { return !A ? FFM_ERR_ARG : (A->sweepMode == 2 ? (ffm_tile_usable(A) ? 2 : 1) : A->sweepMode); }
+extern "C" int ffm_ldu_sweep_mode(const ffm_ldu *A) { return !A ? FFM_ERR_ARG : A->sweepMode; }
 extern "C" int ffm_ldu_nowned(const ffm_ldu *A) { return A ? A->nOwned : FFM_ERR_ARG; }
 extern "C" int ffm_ldu_nfaces(const ffm_ldu *A) { return A ? A->nFaces : FFM_ERR_ARG; }
 extern "C" int ffm_ldu_nlevels(const ffm_ldu *A) { return A ? A->nLevels : FFM_ERR_ARG; }

@@ -15,6 +15,9 @@
 #include "../../include/ffm.h"
 #include <array>
 #include <cctype>
+#include <cerrno>
+#include <algorithm>
+#include <exception>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -57,6 +60,30 @@ struct Tokens {
         return true;
     }
     bool done() const { return i >= t.size(); }
+    // the next token as a label / scalar: false (with an error) when the file ends or the token is not a number
+    bool label(long &v)
+    {
+        if (done()) { ffm_set_error("polyMesh: file ends where a label is expected"); return false; }
+        const std::string &w = t[i]; char *end = nullptr; errno = 0;
+        v = std::strtol(w.c_str(), &end, 10);
+        if (end == w.c_str() || *end != 0 || errno) { ffm_set_error("polyMesh: '%s' is not a label", w.c_str()); return false; }
+        i++; return true;
+    }
+    bool scalar(double &v)
+    {
+        if (done()) { ffm_set_error("polyMesh: file ends where a number is expected"); return false; }
+        const std::string &w = t[i]; char *end = nullptr;
+        v = std::strtod(w.c_str(), &end);
+        if (end == w.c_str() || *end != 0) { ffm_set_error("polyMesh: '%s' is not a number", w.c_str()); return false; }
+        i++; return true;
+    }
+    // a list size: 0 <= n and the file holds at least n more tokens (so a corrupt count cannot drive a huge allocation)
+    bool count(long &n, size_t tokensPerItem)
+    {
+        if (!label(n)) return false;
+        if (n < 0 || (size_t)n > (t.size() - i) / std::max<size_t>(tokensPerItem, 1)) { ffm_set_error("polyMesh: list size %ld does not fit the file", n); return false; }
+        return true;
+    }
     const std::string &peek() const { static const std::string e; return done() ? e : t[i]; }
     std::string next() { return done() ? std::string() : t[i++]; }
     bool expect(const char *s) { if (peek() == s) { i++; return true; } ffm_set_error("polyMesh: expected '%s', found '%s'", s, peek().c_str()); return false; }
@@ -69,7 +96,7 @@ struct Tokens {
         while (!done() && depth > 0) {
             const std::string w = next();
             if (w == "{") depth++; else if (w == "}") depth--;
-            else if (w == "format" && peek() == "binary") { ffm_set_error("polyMesh: binary files are not supported"); return false; }
+            else if (w == "format" && peek() != "ascii") { ffm_set_error("polyMesh: format %s is not supported (ascii only)", peek().c_str()); return false; }
         }
         return true;
     }
@@ -94,34 +121,41 @@ static bool read_all(const std::string &dir, ffm_polymesh *m)
 {
     {
         Tokens k; if (!k.load(dir + "/points") || !k.header()) return false;
-        const long n = std::atol(k.next().c_str()); if (!k.expect("(")) return false;
+        long n; if (!k.count(n, 5) || !k.expect("(")) return false;
         m->points.resize(n);
         for (long p = 0; p < n; p++) {
             if (!k.expect("(")) return false;
-            for (int d = 0; d < 3; d++) m->points[p][d] = std::atof(k.next().c_str());
+            for (int d = 0; d < 3; d++) if (!k.scalar(m->points[p][d])) return false;
             if (!k.expect(")")) return false;
         }
     }
     {
         Tokens k; if (!k.load(dir + "/faces") || !k.header()) return false;
-        const long n = std::atol(k.next().c_str()); if (!k.expect("(")) return false;
+        long n; if (!k.count(n, 6) || !k.expect("(")) return false;
         m->faces.resize(n);
         for (long f = 0; f < n; f++) {
-            const int nv = std::atoi(k.next().c_str()); if (!k.expect("(")) return false;
+            long nv; if (!k.count(nv, 1)) return false;
+            if (nv < 3) { ffm_set_error("polyMesh: face %ld has %ld vertices", f, nv); return false; }
+            if (!k.expect("(")) return false;
             m->faces[f].resize(nv);
-            for (int v = 0; v < nv; v++) {
-                m->faces[f][v] = std::atoi(k.next().c_str());
-                if (m->faces[f][v] < 0 || m->faces[f][v] >= (int)m->points.size()) { ffm_set_error("polyMesh: face %ld refers to point %d", f, m->faces[f][v]); return false; }
+            for (long v = 0; v < nv; v++) {
+                long pt; if (!k.label(pt)) return false;
+                if (pt < 0 || pt >= (long)m->points.size()) { ffm_set_error("polyMesh: face %ld refers to point %ld", f, pt); return false; }
+                m->faces[f][v] = (int)pt;
             }
             if (!k.expect(")")) return false;
         }
     }
     for (int which = 0; which < 2; which++) {
         Tokens k; if (!k.load(dir + (which ? "/neighbour" : "/owner")) || !k.header()) return false;
-        const long n = std::atol(k.next().c_str()); if (!k.expect("(")) return false;
+        long n; if (!k.count(n, 1) || !k.expect("(")) return false;
         std::vector<int> &a = which ? m->neighbour : m->owner;
         a.resize(n);
-        for (long f = 0; f < n; f++) a[f] = std::atoi(k.next().c_str());
+        for (long f = 0; f < n; f++) {
+            long c; if (!k.label(c)) return false;
+            if (c < 0 || c > 0x7ffffffe) { ffm_set_error("polyMesh: %s of face %ld is %ld", which ? "neighbour" : "owner", f, c); return false; }
+            a[f] = (int)c;
+        }
     }
     if (m->owner.size() != m->faces.size() || m->neighbour.size() > m->faces.size()) { ffm_set_error("polyMesh: owner / neighbour / faces sizes disagree"); return false; }
     m->nCells = 0;
@@ -130,20 +164,22 @@ static bool read_all(const std::string &dir, ffm_polymesh *m)
         if (m->neighbour[f] <= m->owner[f]) { ffm_set_error("polyMesh: internal face %zu is not in upper-triangular order", f); return false; }
         m->nCells = std::max(m->nCells, m->neighbour[f] + 1);
     }
+    // every cell owns or neighbours at least one face, so a valid mesh has fewer cells than 2 x faces
+    if ((size_t)m->nCells > 2 * m->faces.size() + 1) { ffm_set_error("polyMesh: cell labels up to %d with %zu faces", m->nCells - 1, m->faces.size()); return false; }
     {
         Tokens k; if (!k.load(dir + "/boundary") || !k.header()) return false;
-        const int n = std::atoi(k.next().c_str()); if (!k.expect("(")) return false;
-        for (int p = 0; p < n; p++) {
+        long n; if (!k.count(n, 3) || !k.expect("(")) return false;
+        for (long p = 0; p < n; p++) {
             Patch P; P.name = k.next(); if (!k.expect("{")) return false;
             int depth = 1;
             while (!k.done() && depth > 0) {
                 const std::string w = k.next();
                 if (w == "{") depth++; else if (w == "}") depth--;
                 else if (depth == 1 && w == "type") P.type = k.next();
-                else if (depth == 1 && w == "nFaces") P.size = std::atoi(k.next().c_str());
-                else if (depth == 1 && w == "startFace") P.start = std::atoi(k.next().c_str());
+                else if (depth == 1 && w == "nFaces") { long v; if (!k.label(v) || v < 0 || v > (long)m->faces.size()) return false; P.size = (int)v; }
+                else if (depth == 1 && w == "startFace") { long v; if (!k.label(v) || v < 0 || v > (long)m->faces.size()) return false; P.start = (int)v; }
             }
-            if (P.start < (int)m->neighbour.size() || P.start + P.size > (int)m->faces.size()) { ffm_set_error("polyMesh: patch %s out of range", P.name.c_str()); return false; }
+            if (P.start < (int)m->neighbour.size() || (long)P.start + P.size > (long)m->faces.size()) { ffm_set_error("polyMesh: patch %s out of range", P.name.c_str()); return false; }
             m->patches.push_back(P);
         }
     }
@@ -204,9 +240,17 @@ static void geometry(ffm_polymesh *m)
 extern "C" int ffm_polymesh_read(const char *polyMeshDir, ffm_polymesh **out)
 {
     if (!polyMeshDir || !out) return FFM_ERR_ARG;
-    ffm_polymesh *m = new ffm_polymesh();
-    if (!read_all(polyMeshDir, m)) { delete m; return FFM_ERR_ARG; }
-    geometry(m);
+    // nothing may leave an extern "C" function by exception (a file too large for memory, a corrupt count)
+    ffm_polymesh *m = nullptr;
+    try {
+        m = new ffm_polymesh();
+        if (!read_all(polyMeshDir, m)) { delete m; return FFM_ERR_ARG; }
+        geometry(m);
+    } catch (const std::exception &e) {
+        ffm_set_error("polyMesh: %s", e.what());
+        delete m;
+        return FFM_ERR_ARG;
+    }
     *out = m;
     return FFM_OK;
 }

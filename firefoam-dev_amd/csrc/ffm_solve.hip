@@ -364,7 +364,13 @@ static int run_graphed(ffm_ldu *A, const SweepGraphKey &key, Body body)
         e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (e != hipSuccess) { ffm_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return FFM_ERR_HIP; }
+        if (A->graphs.size() >= FFM_MAX_SWEEP_GRAPHS) {        // bounded cache: drop the oldest graph
+            auto old = A->graphs.find(A->graphOrder.front());
+            if (old != A->graphs.end()) { hipGraphExecDestroy(old->second); A->graphs.erase(old); }
+            A->graphOrder.erase(A->graphOrder.begin());
+        }
         it = A->graphs.emplace(key, ge).first;
+        A->graphOrder.push_back(key);
     }
     FFM_HIP(hipGraphLaunch(it->second, s));
     return FFM_OK;
@@ -381,13 +387,13 @@ static inline void bwd_range(const ffm_ldu *A, int b, int &p0, int &p1, const in
 static int calc_rD(ffm_ldu *A)
 {
     hipStream_t s = A->ctx->stream;
-    if (A->sweepMode >= 1) {
-        if (A->sweepMode == 2 && ffm_tile_usable(A)) FFM_TRY(ffm_tile_calc_rD(A)); else FFM_TRY(ffm_pipe_calc_rD(A));
+    if (A->sweepMode == 2) {
+        FFM_TRY(ffm_tile_calc_rD(A));
         hipLaunchKernelGGL(k_recip, dim3(sgrid(A->nOwned)), dim3(256), 0, s, (long)A->nOwned, A->rD, A->rD);
         FFM_HIP(hipGetLastError());
         return FFM_OK;
     }
-    SweepGraphKey key{SW_RD, A->lower, A->upper, nullptr};
+    SweepGraphKey key{SW_RD, {A->lower, A->upper, A->diag, A->rD, nullptr, nullptr}};
     FFM_TRY(run_graphed(A, key, [&]() -> int {
         for (int L = 0; L < A->nLevels; L++) {
             const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
@@ -431,9 +437,8 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
     // DIC: fwd upper / bwd upper.  DILU: fwd lower / bwd upper.  DILU^T: fwd upper / bwd lower.
     const double *cf = (precond == FFM_DIC) ? A->upper : (transpose ? A->upper : A->lower);
     const double *cb = (precond == FFM_DIC) ? A->upper : (transpose ? A->lower : A->upper);
-    if (A->sweepMode == 2 && ffm_tile_usable(A)) return ffm_tile_precond(A, precond, transpose, r, w);
-    if (A->sweepMode >= 1) return ffm_pipe_precond(A, cf, cb, r, w);
-    SweepGraphKey key{SW_PRECOND + 16 * (transpose ? 1 : 0) + 32 * precond, r, w, cf};
+    if (A->sweepMode == 2) return ffm_tile_precond(A, precond, transpose, r, w);
+    SweepGraphKey key{SW_PRECOND + 16 * (transpose ? 1 : 0) + 32 * precond, {r, w, cf, cb, A->rD, nullptr}};
     return run_graphed(A, key, [&]() -> int {
         for (int L = 0; L < A->nLevels; L++) {
             const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
@@ -476,8 +481,7 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             FFM_TRY(ffm_tile_gs(A, sym, psi, bUse, bSave, A->gsProd));
             continue;
         }
-        if (A->sweepMode >= 1) { FFM_TRY(ffm_pipe_gs(A, sym, psi, bUse, bSave)); continue; }
-        SweepGraphKey key{sym ? SW_SYMGS : SW_GS, psi, bUse, A->lower};
+        SweepGraphKey key{sym ? SW_SYMGS : SW_GS, {psi, bUse, A->lower, A->upper, A->diag, bSave}};
         FFM_TRY(run_graphed(A, key, [&]() -> int {
             for (int L = 0; L < A->nLevels; L++) {
                 const int c0 = A->h_fwdLevelStart[L], c1 = A->h_fwdLevelStart[L + 1];
@@ -714,7 +718,7 @@ extern "C" int ffm_solve_d(ffm_ldu *A, int solver, int precond, double tol, doub
         FFM_TRY(ffm_from_internal(A, pi, psi_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
     return FFM_OK;
 }
 
@@ -740,7 +744,7 @@ extern "C" int ffm_precond_setup(ffm_ldu *A, int precond, double *rD_out_d)
     FFM_TRY(ffm_precond_setup_i(A, precond));
     if (rD_out_d) FFM_TRY(ffm_from_internal(A, A->rD, rD_out_d));
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
     return FFM_OK;
 }
 
@@ -777,7 +781,7 @@ extern "C" int ffm_precond_apply(ffm_ldu *A, int precond, int transpose, const d
         FFM_TRY(ffm_from_internal(A, wi, w_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
     return FFM_OK;
 }
 
@@ -792,6 +796,6 @@ extern "C" int ffm_gs_smooth(ffm_ldu *A, int symmetric_sweep, int nSweeps, doubl
         FFM_TRY(ffm_from_internal(A, A->permIn[2], psi_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode >= 1) FFM_TRY(ffm_pipe_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
     return FFM_OK;
 }

@@ -4,7 +4,7 @@
 // DILUPreconditioner::calcReciprocalD and ::precondition, reference selection cases/steckler/system/fvSolution:21-46).
 // Motivation and measurements (MI355X, 400^3 box = 1198 dependency levels): a hand-off between workgroups costs about as
 // much as a dependent kernel launch (3-5 us under load), so neither one launch per level nor a persistent kernel that
-// publishes a progress word per level (ffm_pipe.hip) gets under ~3.6 us per level.  Here
+// publishes a progress word per level (tried in round 1, removed) gets under ~3.6 us per level.  Here
 //   * cells are split into groups (2-D tiles of cell columns: a host hint or a detected blockMesh box) whose dependency
 //     graph is acyclic; cells are numbered group-major and level-major inside a group; one workgroup sweeps one group,
 //     one "entry" (<= 256 cells of one level) per step;
@@ -21,7 +21,7 @@
 //     FMAs, one LDS write and one barrier;
 //   * groups are handed out by an atomic ticket in topological order, so a workgroup only waits for groups that are
 //     already running or finished (no residency assumption, no deadlock); every spin is bounded and raises the abort word
-//     that ffm_pipe_check_abort() reports when the solve ends.
+//     that ffm_tile_check_abort() reports when the solve ends.
 #include "ffm_internal.hpp"
 #include "ffm_device.hpp"
 #include <algorithm>
@@ -410,6 +410,8 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
         FFM_HIP(hipMalloc((void **)&T->mailAll, sizeof(double) * T->nMail));
         T->f.mail = T->mailAll; T->b.mail = T->mailAll + T->f.nPub + 1;
         FFM_TRY(build_amul(A, grpOfCell, recF));
+        // the Gauss-Seidel sweeps use the Amul plan's cell-space tables: without it the matrix gets level-scheduled sweeps
+        if (!T->amulUsable) T->usable = false;
     }
     return FFM_OK;
 }
@@ -619,8 +621,11 @@ __global__ void k_tile_gather(long n, const int *__restrict__ src, const double 
         out[i] = (q >= 0) ? native[q] : 0.0;
     }
 }
-__global__ void k_tile_fill(long n, unsigned long long *p, unsigned long long v)
+// mailbox fill before a sweep (pair); it also zeroes the group ticket counter, so that the 32-bit counter never wraps and every
+// launch hands its groups out as ticket % G with ticket < 2 G (forward sweep 0..G-1, backward sweep G..2G-1)
+__global__ void k_tile_fill(long n, unsigned long long *p, unsigned long long v, unsigned int *ticket)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticket[0] = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
 }
 
@@ -636,7 +641,7 @@ __global__ void k_tile_permute(long n, const int *__restrict__ cellOf, const dou
 static TileView tview(const ffm_ldu *A, const TileDir &d)
 {
     TileView t; t.G = A->tile->G; t.grpCell = A->grpCell; t.grpEnt = d.grpEnt; t.extSrc = d.extSrc; t.rec = d.rec;
-    t.code = (const uint2 *)d.code; t.mail = d.mail; t.ticket = A->pipeTicket; t.trace = A->tile->trace;
+    t.code = (const uint2 *)d.code; t.mail = d.mail; t.ticket = A->sweepTicket; t.trace = A->tile->trace;
     return t;
 }
 
@@ -659,7 +664,7 @@ static int tile_coef(ffm_ldu *A, TileDir &d, bool upper, const double **out)
 static void tile_fill(ffm_ldu *A, double *p, long n)
 {
     const int g = std::max(1, std::min(ffm_grid(n, 256), 8 * RED_BLOCKS));
-    hipLaunchKernelGGL(k_tile_fill, dim3(g), dim3(256), 0, A->ctx->stream, n, (unsigned long long *)p, T_SENT);
+    hipLaunchKernelGGL(k_tile_fill, dim3(g), dim3(256), 0, A->ctx->stream, n, (unsigned long long *)p, T_SENT, A->sweepTicket);
 }
 
 // upper coefficients of the owned upper neighbours in cell space: the backward direction's gathered array on mirror-ordered
@@ -729,6 +734,21 @@ __global__ void k_tile_gs_products(long n3, const int *__restrict__ nbrCell, con
 }
 
 bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable; }
+
+// the abort word of the sweep kernels (a bounded mailbox wait ran out): reported when a solve ends
+int ffm_tile_check_abort(ffm_ldu *A)
+{
+    unsigned int h[2] = {0, 0};
+    FFM_HIP(hipMemcpyAsync(h, A->sweepTicket, sizeof(h), hipMemcpyDeviceToHost, A->ctx->stream));
+    FFM_HIP(hipStreamSynchronize(A->ctx->stream));
+    if (h[1]) {
+        ffm_set_error("tiled sweep timed out waiting for a value of a predecessor group (abort word set)");
+        unsigned int z = 0;
+        hipMemcpy(A->sweepTicket + 1, &z, sizeof(z), hipMemcpyHostToDevice);
+        return FFM_ERR_HIP;
+    }
+    return FFM_OK;
+}
 
 // One GaussSeidelSmoother / symGaussSeidelSmoother sweep (forward rows, then reverse rows when sym): psi in place, bP = bPrime
 // (source with the lagged interface terms), bSave = scratch [nCells].  prod = scratch [3*nCells].
@@ -993,6 +1013,14 @@ extern "C" int ffm_debug_tile_trace(ffm_ldu *A, unsigned long long *out, int nWo
     }
     if (out && nWords > 0) FFM_HIP(hipMemcpy(out, T->trace, sizeof(unsigned long long) * std::min(nWords, 4 * T->G), hipMemcpyDeviceToHost));
     return T->G;
+}
+
+extern "C" int ffm_debug_set_sweep_ticket(ffm_ldu *A, unsigned int value)
+{
+    if (!A || !A->sweepTicket) return FFM_ERR_ARG;
+    FFM_HIP(hipStreamSynchronize(A->ctx->stream));
+    FFM_HIP(hipMemcpy(A->sweepTicket, &value, sizeof(value), hipMemcpyHostToDevice));
+    return FFM_OK;
 }
 
 // Diagnostics: resident workgroups per CU the runtime predicts for the forward / backward sweep kernels and the tiled Amul

@@ -134,7 +134,7 @@ int ffm_ldu_ncells(const ffm_ldu *ldu);
 int ffm_ldu_nfaces(const ffm_ldu *ldu);
 int ffm_ldu_nlevels(const ffm_ldu *ldu);
 /* which sweep kernels DIC / DILU / Gauss-Seidel use on this matrix: 0 one launch per dependency level, 2 tiled wavefront
- * (ffm_tile.hip: group hint or detected blockMesh box), 1 the experimental pipelined groups (FFM_SWEEP=pipe)          */
+ * (ffm_tile.hip: group hint or detected blockMesh box)                                                              */
 int ffm_ldu_sweep_mode(const ffm_ldu *ldu);
 /* 1 when the caller's cell numbering is used as is (no permutation passes)   */
 int ffm_ldu_is_native_order(const ffm_ldu *ldu);
@@ -181,6 +181,12 @@ int ffm_ldu_set_interfaces(ffm_ldu *ldu, int nPatches, const int *patchSizes,
                            const double *const *intCoeffs,
                            const int *neighbRank);
 int ffm_ldu_set_global_cells(ffm_ldu *ldu, long globalCells);
+/* Pair tags of the point-to-point messages of one exchange (kind 0: the processor patches of ffm_ldu_set_interfaces, kind 1:
+ * the neighbour entries of ffm_ldu_set_ghost_exchange): tags[i] is a label both ranks give to the two entries that exchange
+ * with each other.  Messages are posted in ascending tag order, so two ranks that share several patches (cyclic / periodic
+ * two-rank decompositions, split processor patches) match them correctly whatever their local patch order.  Without tags
+ * the entry order is used, i.e. both sides must list their common patches in the same order (as OpenFOAM does).          */
+int ffm_ldu_set_exchange_tags(ffm_ldu *ldu, int kind, int n, const int *tags);
 
 /* ------------------------------------------------------- lduMatrix kernels */
 /* lduMatrix::Amul -- the metric kernel (solver/pEqn.H:39 via PCG; UEqn.H() in
@@ -380,6 +386,9 @@ int ffm_comm_size(const ffm_ctx *ctx);
  * calls copy out, for the last tiled launch, 4 words per group {start, first entry ready, end (100 MHz ticks), mailbox
  * re-loads}.  Not part of the reference interface. */
 int ffm_debug_tile_trace(ffm_ldu *A, unsigned long long *out, int nWords);
+/* tests: preset the group ticket counter of the tiled sweeps (every sweep launch zeroes it again on the stream, so a preset
+ * close to 2^32 must not change any result)                                                                             */
+int ffm_debug_set_sweep_ticket(ffm_ldu *A, unsigned int value);
 
 /* ------------------------------------------------------- polyMesh (host)    */
 /* SURVEY 8(f) N4, first part: OpenFOAM's on-disk mesh (ascii constant/polyMesh/{points,faces,owner,neighbour,boundary}, as

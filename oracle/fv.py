@@ -289,7 +289,10 @@ def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
     gradcf = np.where(phi > 0, np.einsum("fd,fd->f", d, gradvf[mesh.l]), np.einsum("fd,fd->f", d, gradvf[mesh.u]))
     big = np.abs(gradcf) >= 1000.0 * np.abs(gradf)
     with np.errstate(divide="ignore", invalid="ignore"):
-        r = np.where(big, 2.0 * 1000.0 * np.sign(gradcf) * np.sign(gradf) - 1.0, 2.0 * (gradcf / gradf) - 1.0)
+        # OpenFOAM's sign(s) is (s >= 0) ? 1 : -1 (never 0): in a uniform region (gradf == gradcf == 0) r = 1999, the limiter
+        # is 1 and the weights are the linear ones (NVDTVD::r, src/finiteVolume/.../limitedSchemes/LimitedScheme/NVDTVD.H)
+        sgn = lambda a: np.where(a >= 0, 1.0, -1.0)
+        r = np.where(big, 2.0 * 1000.0 * sgn(gradcf) * sgn(gradf) - 1.0, 2.0 * (gradcf / gradf) - 1.0)
     twoByk = 2.0 / max(k, 1e-15)
     lim = np.maximum(np.minimum(twoByk * r, 1.0), 0.0)
     if scheme == "limitedLinear01":

@@ -38,7 +38,7 @@ def test_renumber_levels_host_logic(ffm, O):
     N, l, u = H.hex_ldu(*n)
     No, lo, uo = O.hex_ldu(*n)
     assert N == No and np.array_equal(l, lo) and np.array_equal(u, uo)     # product mesh tool == oracle mesh
-    for env in ("pipe", "levels"):
+    for env in ("tile", "levels"):
         import os
         if env:
             os.environ["FFM_SWEEP"] = env

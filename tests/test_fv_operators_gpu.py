@@ -114,6 +114,24 @@ def test_limiter_unit_vectors(O):
     assert w[1] == 1.0
 
 
+@pytest.mark.parametrize("scheme,code", [("limitedLinear", 2), ("limitedLinear01", 3)])
+def test_limited_weights_piecewise_constant(setup, O, ctx, scheme, code):
+    """the same on the device: a field that is constant over most of the mesh (the ambient of a plume) gets linear weights
+    there, bitwise the oracle's"""
+    s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
+    vf, phi, vb = fields(s, O)
+    vf = np.where(vf > 0.8, vf, 0.25)                           # ~80 % of the cells at one value
+    vb = [np.full(p.size, 0.25) for p in m.patches]
+    grad = fv.grad(m, vf, vb)
+    w = ctx.zeros(mesh.nNative)
+    mesh.call("fv_limited_weights", code, 1.0, 0.0, 1.0, facef(s, phi), cellf(s, ctx, vf), *[cellf(s, ctx, grad[:, d]) for d in range(3)], w)
+    ref = fv.limited_weights(m, scheme, phi, vf, grad, 1.0)
+    got = back_face(s, w)
+    assert np.array_equal(got, ref)
+    flat = (vf[m.l] == 0.25) & (vf[m.u] == 0.25) & (np.abs(grad[m.l]).sum(axis=1) == 0) & (np.abs(grad[m.u]).sum(axis=1) == 0)
+    assert flat.sum() > 0 and np.all(got[flat] == m.weights[flat])
+
+
 def test_fvm_assembly_and_matrix_ops(setup, O, ctx):
     s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
     N, F, B = s["N"], s["F"], s["B"]

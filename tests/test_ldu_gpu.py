@@ -25,24 +25,19 @@ def meshes(O):
 
 
 @pytest.fixture(scope="module", params=["hex_natural", "hex_levelmajor", "dag_random", "chain", "plane",
-                                        "hex_natural_g37", "dag_random_g23", "chain_g64", "plane_g50", "hex_levelmajor_g41",
+                                        "hex_levelmajor_t41", "hex_natural_t29", "plane_t17",
                                         "hex_natural_t37", "dag_random_t23", "chain_t64", "plane_t50", "hex_natural_t500", "hex_tiles_t0",
                                         "hex_natural_lv", "hex_levelmajor_lv", "chain_lv", "plane_lv", "hex_big", "hex_big_lv", "hex_baffled_t0"])
 def case(request, O, ffm, ctx):
-    """`_gNN` variants force the pipelined sweep to split the mesh into groups of NN cells, so that the cross-workgroup
-    hand-off (progress words, sc1 loads/stores, LDS ring wrap-around) is exercised on small meshes too.  `_tNN`: tiled
-    wavefront sweep on chunks of NN cells (t0: a 2-D tile hint).  `_lv`: level-scheduled sweeps.  No suffix: the default
-    (tiled sweeps on detected boxes and hinted meshes, level-scheduled otherwise)."""
+    """`_tNN`: tiled wavefront sweep on chunks of NN cells, so that the cross-workgroup hand-off (mailboxes, LDS ring
+    wrap-around) is exercised on small meshes too (t0: a 2-D tile hint).  `_lv`: level-scheduled sweeps.  No suffix: the
+    default (tiled sweeps on detected boxes and hinted meshes, level-scheduled otherwise)."""
     import os
     name = request.param
     grp = None
     if name.endswith("_lv"):
         name = name[:-3]
         os.environ["FFM_SWEEP"] = "levels"
-    elif "_g" in name:
-        name, grp = name.rsplit("_g", 1)
-        os.environ["FFM_PIPE_GROUP_CELLS"] = grp
-        os.environ["FFM_SWEEP"] = "pipe"
     elif "_t" in name:                      # tiled wavefront sweep (ffm_tile.hip); t0 = 2-D tile hint instead of chunks
         name, grp = name.rsplit("_t", 1)
         if grp != "0":
@@ -108,6 +103,25 @@ def test_dic_bit_exact(O, ctx, case):
     rD = Ao.dic_rD()
     assert np.array_equal(A.reciprocalD("DIC").cpu().numpy(), rD)
     assert np.array_equal(A.precondition("DIC", ctx.to_device(r)).cpu().numpy(), Ao.dic_precondition(rD, r))
+
+
+def test_sweep_ticket_counter_cannot_wrap(O, ctx, case):
+    """the 32-bit group ticket of the tiled sweeps is zeroed on the stream before every sweep, so a counter left
+    close to 2^32 (what ~7 million launches would have reached) changes nothing: DIC stays bitwise the serial face loops."""
+    N, A, Ao = _both(O, ctx, case, 0.0)
+    if A.sweep_mode != 2:
+        pytest.skip("level-scheduled sweeps have no ticket")
+    r = 2 * O.hash_u(21, np.arange(N)) - 1
+    rD = Ao.dic_rD()
+    for preset in (2 ** 32 - 1, 2 ** 32 - 3, 2 ** 31 + 5):
+        A.debug_set_sweep_ticket(preset)
+        assert np.array_equal(A.reciprocalD("DIC").cpu().numpy(), rD)
+        A.debug_set_sweep_ticket(preset)
+        assert np.array_equal(A.precondition("DIC", ctx.to_device(r)).cpu().numpy(), Ao.dic_precondition(rD, r))
+    A.debug_set_sweep_ticket(2 ** 32 - 2)
+    psi0 = O.hash_u(13, np.arange(N)); b = O.hash_u(14, np.arange(N))
+    got = A.smooth(ctx.to_device(psi0), ctx.to_device(b), nSweeps=2, smoother="symGaussSeidel")
+    assert np.array_equal(got.cpu().numpy(), Ao.gs_smooth(psi0, b, nSweeps=2, sym=True))
 
 
 def test_dilu_bit_exact(O, ctx, case):

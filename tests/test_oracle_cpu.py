@@ -146,3 +146,20 @@ def test_fvdom_ray_set_properties(O):
     P.T[:] = plume.TREF
     P.radiation_correct()
     assert np.abs(P.G / (4 * plume.SIGMA_SB * plume.TREF ** 4) - 1).max() < 1e-4       # solves stop at 1e-4
+
+
+def test_limiter_uniform_zones_are_linear(O):
+    """NVDTVD::r with OpenFOAM's two-valued sign() (s >= 0 ? 1 : -1): in a uniform zone gradf = gradcf = 0 gives r = 1999, the
+    limiter is 1 and the weights are the LINEAR ones (a three-valued sign would give r = -1 and upwind weights over most of
+    the ambient of the reference cases' species / enthalpy fields); gradf = 0 with gradcf < 0 gives r = -2001 -> upwind."""
+    from oracle import fv
+    m = fv.HexMesh((6, 1, 1), (0, 0, 0), (6, 1, 1)).set_patches([])
+    vf = np.array([0.2, 0.2, 0.2, 0.7, 0.7, 0.7])               # piecewise constant
+    g = np.zeros((6, 3)); g[:, 0] = [0.0, 0.0, 0.25, 0.25, 0.0, 0.0]
+    for sgn in (1.0, -1.0):
+        for scheme in ("limitedLinear", "limitedLinear01"):
+            w = fv.limited_weights(m, scheme, sgn * np.ones(5), vf, g, 1.0)
+            assert w[0] == 0.5 and w[4] == 0.5, (scheme, sgn, w)   # both cells and the upwind gradient uniform: linear
+    g2 = np.zeros((6, 3)); g2[:, 0] = -0.1
+    w = fv.limited_weights(m, "limitedLinear", np.ones(5), vf, g2, 1.0)
+    assert w[0] == 1.0                                          # gradf = 0, gradcf < 0: r = 2000*(-1)(+1) - 1 < 0 -> upwind
