@@ -143,6 +143,10 @@ def lib():
         "ffm_fvc_snGrad_correction": ([vp, dp, dp, dp, dp], C.c_int),
         "ffm_fv_linear_upwind_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fvm_relax": ([vp, C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvc_grad_multi": ([vp, C.c_int] + [C.POINTER(C.c_void_p)] * 5, C.c_int),
+        "ffm_fvm_scalar_transport_multi": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
+                                           + [C.POINTER(C.c_void_p)] * 14, C.c_int),
+        "ffm_fvm_lust_source3": ([vp, C.c_double, dp, dp] + [C.POINTER(C.c_void_p)] * 5, C.c_int),
         "ffm_mesh_nboundary": ([vp], C.c_int),
         "ffm_mesh_nnative": ([vp], C.c_int),
         "ffm_faces_to_native": ([vp, hp, dp], C.c_int),
@@ -604,6 +608,8 @@ class fvMesh:
         for a in args:
             if a is None:
                 conv.append(None)
+            elif isinstance(a, (list, tuple)):          # host array of device pointers (None -> NULL)
+                conv.append((C.c_void_p * len(a))(*[None if t is None else t.data_ptr() for t in a]))
             elif hasattr(a, "data_ptr"):
                 conv.append(C.c_void_p(a.data_ptr()))
             else:

@@ -1,0 +1,292 @@
+// ffm_fused.hip -- fused assembly passes of the compiled time step (ffm_plume.hip).
+//
+// The per-operator kernels of ffm_fv.hip mirror OpenFOAM's one-pass-per-operator evaluation (what the Foam layer in
+// include/ffmFoam.H calls, operator by operator).  A transport equation assembled that way costs six passes over the mesh
+// (limiter weights, coefficients, boundary coefficients, ddt source, explicit source, addBoundaryDiag/Source), and the
+// face geometry and addressing are streamed again by each of them.  The kernels here produce the SAME numbers -- every
+// expression is the one of the per-operator kernel it replaces, evaluated in the same order, FMA contraction off -- in one
+// pass per equation, several equations that share phi / rho / the diffusivity (the species of solver/YEEqn.H:37-67) per launch:
+//   k_grad_multi        fvc::grad of NF fields in one pass (Gauss linear; solver/YEEqn.H:8 limiters, solver/UEqn.H:5 LUST)
+//   k_scalar_eqns       fvm::ddt(rho,Yi) + mvConvection->fvmDiv(phi,Yi) - fvm::laplacian(dEff,Yi) == Su  for NF fields:
+//                       limitedLinear / limitedLinear01 weights on the fly (NVDTVD::r), matrix coefficients, boundary
+//                       coefficients of the mixed patch condition, source with the explicit terms, addBoundaryDiag/Source
+//   k_lust_source       the explicit part of `div(phi,U) Gauss LUST grad(U)` (cases/steckler/system/fvSchemes:32) for the
+//                       three components + the ddt source:  source_c = rDeltaT*rho0*U0_c*V - V*surfaceIntegrate(phi*corr_c)
+// tests/test_fused_gpu.py checks each of them bitwise against the chain of per-operator entry points.
+#include "ffm_mesh.hpp"
+
+constexpr int FUSE_MAX = 4;
+
+struct GradMulti {
+    const double *vf[FUSE_MAX], *vb[FUSE_MAX];
+    double *gx[FUSE_MAX], *gy[FUSE_MAX], *gz[FUSE_MAX];
+};
+
+// fvc::grad, Gauss linear, of NF fields: one pass over the addressing and the face geometry (k_grad of ffm_fv.hip per field)
+template <int W, int NF>
+__global__ __launch_bounds__(256) void k_grad_multi(MeshView q, GradMulti a)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
+        double wl[W], wu[W], sx[2 * W], sy[2 * W], sz[2 * W];
+#pragma unroll
+        for (int s = 0; s < W; s++) {
+            wl[s] = q.w[L.f[s]]; wu[s] = q.w[U.f[s]];
+            sx[s] = q.Sfx[L.f[s]]; sy[s] = q.Sfy[L.f[s]]; sz[s] = q.Sfz[L.f[s]];
+            sx[W + s] = q.Sfx[U.f[s]]; sy[W + s] = q.Sfy[U.f[s]]; sz[W + s] = q.Sfz[U.f[s]];
+        }
+        const double V = q.V[c];
+        const int j = q.cellB[c];
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            const double *__restrict__ vf = a.vf[i];
+            const double P = vf[c];
+            double vl[W], vu[W];
+#pragma unroll
+            for (int s = 0; s < W; s++) { vl[s] = vf[L.nb[s]]; vu[s] = vf[U.nb[s]]; }
+            double ax = 0, ay = 0, az = 0;
+#pragma unroll
+            for (int s = 0; s < W; s++) if (L.on[s]) {
+                const double ff = wl[s] * vl[s] + (1.0 - wl[s]) * P;      // owner of this face is the neighbour cell
+                ax -= sx[s] * ff; ay -= sy[s] * ff; az -= sz[s] * ff;
+            }
+#pragma unroll
+            for (int s = 0; s < W; s++) if (U.on[s]) {
+                const double ff = wu[s] * P + (1.0 - wu[s]) * vu[s];
+                ax += sx[W + s] * ff; ay += sy[W + s] * ff; az += sz[W + s] * ff;
+            }
+            if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) {
+                const int k = q.bcItem[t]; const double b = a.vb[i][k];
+                ax += q.bSfx[k] * b; ay += q.bSfy[k] * b; az += q.bSfz[k] * b;
+            }
+            a.gx[i][c] = ax / V; a.gy[i][c] = ay / V; a.gz[i][c] = az / V;
+        }
+    }
+}
+
+// limitedLinear(k) / limitedLinear01(k) weight of one face (k_limited_weights of ffm_fv.hip): o = owner, n = neighbour
+__device__ __forceinline__ double limited_weight(int scheme, double twoByk, double lo, double hi, double flux, double wlin,
+                                                 double P, double Nn, double dx, double dy, double dz, double gxu, double gyu, double gzu)
+{
+    const double p0 = flux >= 0 ? 1.0 : 0.0;
+    const double gradf = Nn - P;
+    const double gradcf = dx * gxu + dy * gyu + dz * gzu;
+    double r;
+    if (fabs(gradcf) >= 1000.0 * fabs(gradf)) {
+        const double sa = gradcf >= 0 ? 1.0 : -1.0, sb = gradf >= 0 ? 1.0 : -1.0;
+        r = 2.0 * 1000.0 * sa * sb - 1.0;
+    } else r = 2.0 * (gradcf / gradf) - 1.0;
+    double lim = fmax(fmin(twoByk * r, 1.0), 0.0);
+    if (scheme == 3) {
+        if ((flux > 0 && (P < lo || Nn > hi)) || (flux < 0 && (Nn < lo || P > hi))) lim = 0.0;
+    }
+    return lim * wlin + (1.0 - lim) * p0;
+}
+
+struct ScalarEqns {
+    // per field
+    const double *vf[FUSE_MAX], *gx[FUSE_MAX], *gy[FUSE_MAX], *gz[FUSE_MAX], *vf0[FUSE_MAX];
+    const double *f[FUSE_MAX], *ref[FUSE_MAX], *refGrad[FUSE_MAX];      // mixed patch condition [B]
+    const double *su[FUSE_MAX];                                          // explicit volume source (nullable)
+    const double *expl[FUSE_MAX][3];                                     // explicit LHS volume terms (nullable)
+    double *diag[FUSE_MAX], *upper[FUSE_MAX], *lower[FUSE_MAX], *src[FUSE_MAX];
+    // shared
+    const double *rho, *rho0, *phi, *phib, *gamma, *gammab;
+    const double *Cx, *Cy, *Cz, *bMagSf, *bDelta;
+    double rdt, twoByk, lo, hi;
+    int scheme;                                                          // 2 limitedLinear, 3 limitedLinear01
+};
+
+template <int W, int NF>
+__global__ __launch_bounds__(256) void k_scalar_eqns(MeshView q, ScalarEqns a)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
+        // shared face data: flux, linear weight, laplacian coefficient gamma*magSf*delta, distance vector
+        double fl[W], fu[W], wl[W], wu[W], gl[W], gu[W], dlx[W], dly[W], dlz[W], dux[W], duy[W], duz[W];
+        const double cx = a.Cx[c], cy = a.Cy[c], cz = a.Cz[c];
+#pragma unroll
+        for (int s = 0; s < W; s++) {
+            const int el = L.f[s], eu = U.f[s];
+            fl[s] = a.phi[el]; fu[s] = a.phi[eu]; wl[s] = q.w[el]; wu[s] = q.w[eu];
+            gl[s] = a.gamma[el] * q.magSf[el] * q.delta[el]; gu[s] = a.gamma[eu] * q.magSf[eu] * q.delta[eu];
+            // d = C[neighbour] - C[owner]
+            dlx[s] = cx - a.Cx[L.nb[s]]; dly[s] = cy - a.Cy[L.nb[s]]; dlz[s] = cz - a.Cz[L.nb[s]];
+            dux[s] = a.Cx[U.nb[s]] - cx; duy[s] = a.Cy[U.nb[s]] - cy; duz[s] = a.Cz[U.nb[s]] - cz;
+        }
+        const double V = q.V[c], rhoc = a.rho[c], rho0c = a.rho0[c];
+        const int j = q.cellB[c];
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            const double *__restrict__ vf = a.vf[i], *__restrict__ gx = a.gx[i], *__restrict__ gy = a.gy[i], *__restrict__ gz = a.gz[i];
+            const double P = vf[c], gxc = gx[c], gyc = gy[c], gzc = gz[c];
+            double dDiv = 0.0, dLap = 0.0;
+            // faces where c is the neighbour (owner = L.nb[s]): diag -= upper[f]
+#pragma unroll
+            for (int s = 0; s < W; s++) if (L.on[s]) {
+                const int o = L.nb[s];
+                const double flux = fl[s];
+                const bool upO = flux > 0;                       // upwind cell: the owner when the flux is positive
+                const double w = limited_weight(a.scheme, a.twoByk, a.lo, a.hi, flux, wl[s], vf[o], P, dlx[s], dly[s], dlz[s],
+                                                upO ? gx[o] : gxc, upO ? gy[o] : gyc, upO ? gz[o] : gzc);
+                const double lo = -w * flux;
+                dDiv -= (lo + flux);
+                dLap -= gl[s];
+            }
+            // faces owned by c: write the coefficients, diag -= lower[f]
+#pragma unroll
+            for (int s = 0; s < W; s++) if (U.on[s]) {
+                const int n = U.nb[s];
+                const double flux = fu[s];
+                const bool upO = flux > 0;
+                const double w = limited_weight(a.scheme, a.twoByk, a.lo, a.hi, flux, wu[s], P, vf[n], dux[s], duy[s], duz[s],
+                                                upO ? gxc : gx[n], upO ? gyc : gy[n], upO ? gzc : gz[n]);
+                double lo = -w * flux, up = lo + flux;
+                dDiv -= lo;
+                dLap -= gu[s];
+                lo = lo - gu[s]; up = up - gu[s];
+                a.upper[i][U.f[s]] = up; a.lower[i][U.f[s]] = lo;
+            }
+            double d = a.rdt * rhoc * V;
+            d = d + dDiv;
+            d = d - dLap;
+            // source: ddt, explicit LHS terms (one `source -= V*term` each), explicit source
+            double sc = a.rdt * rho0c * a.vf0[i][c] * V;
+            if (a.expl[i][0]) sc = ((sc - V * a.expl[i][0][c]) - V * a.expl[i][1][c]) - V * a.expl[i][2][c];
+            if (a.su[i]) sc = sc + V * a.su[i][c];
+            // boundary coefficients of the mixed condition, added in (patch, face) order
+            if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) {
+                const int k = q.bcItem[t];
+                const double fk = a.f[i][k], rk = a.ref[i][k], gk = a.refGrad[i][k], dk = a.bDelta[k], pb = a.phib[k];
+                double ic = pb * (1.0 - fk), bc = -pb * (fk * rk + (1.0 - fk) * gk / dk);
+                const double pG = a.gammab[k] * a.bMagSf[k];
+                const double li = pG * (-fk * dk), lb = -pG * (fk * dk * rk + (1.0 - fk) * gk);
+                ic = ic - li; bc = bc - lb;
+                d += ic; sc += bc;
+            }
+            a.diag[i][c] = d; a.src[i][c] = sc;
+        }
+    }
+}
+
+struct LustSource {
+    const double *gx[3], *gy[3], *gz[3], *U0[3];
+    double *src[3];
+    const double *phi, *rho0, *Cx, *Cy, *Cz, *Cfx, *Cfy, *Cfz;
+    double rdt;
+};
+
+template <int W>
+__global__ __launch_bounds__(256) void k_lust_source(MeshView q, LustSource a)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
+        const double cx = a.Cx[c], cy = a.Cy[c], cz = a.Cz[c];
+        double fl[W], fu[W], dlx[W], dly[W], dlz[W], dux[W], duy[W], duz[W];
+        int upl[W], upu[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) {
+            const int el = L.f[s], eu = U.f[s];
+            fl[s] = a.phi[el]; fu[s] = a.phi[eu];
+            upl[s] = fl[s] > 0 ? L.nb[s] : c;           // lower face: owner = L.nb[s], neighbour = c
+            upu[s] = fu[s] > 0 ? c : U.nb[s];
+            dlx[s] = a.Cfx[el] - a.Cx[upl[s]]; dly[s] = a.Cfy[el] - a.Cy[upl[s]]; dlz[s] = a.Cfz[el] - a.Cz[upl[s]];
+            dux[s] = a.Cfx[eu] - a.Cx[upu[s]]; duy[s] = a.Cfy[eu] - a.Cy[upu[s]]; duz[s] = a.Cfz[eu] - a.Cz[upu[s]];
+        }
+        (void)cx; (void)cy; (void)cz;
+        const double V = q.V[c], r0 = a.rho0[c];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double *__restrict__ gx = a.gx[i], *__restrict__ gy = a.gy[i], *__restrict__ gz = a.gz[i];
+            double acc = 0.0;
+#pragma unroll
+            for (int s = 0; s < W; s++) if (L.on[s]) {
+                const int u = upl[s];
+                const double corr = 0.25 * ((dlx[s] * gx[u] + dly[s] * gy[u]) + dlz[s] * gz[u]);
+                acc -= fl[s] * corr;
+            }
+#pragma unroll
+            for (int s = 0; s < W; s++) if (U.on[s]) {
+                const int u = upu[s];
+                const double corr = 0.25 * ((dux[s] * gx[u] + duy[s] * gy[u]) + duz[s] * gz[u]);
+                acc += fu[s] * corr;
+            }
+            const double divc = acc / V;
+            a.src[i][c] = a.rdt * r0 * a.U0[i][c] * V - V * divc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ entry points (internal + C ABI) ---
+#define CHECK_M(m) if (!(m)) { ffm_set_error("null mesh"); return FFM_ERR_ARG; }
+
+extern "C" int ffm_fvc_grad_multi(ffm_mesh *m, int nf, const double *const *vf, const double *const *vb, double *const *gx,
+                                  double *const *gy, double *const *gz)
+{
+    CHECK_M(m);
+    if (nf < 1 || nf > FUSE_MAX || !vf || !vb || !gx || !gy || !gz) return FFM_ERR_ARG;
+    GradMulti a;
+    for (int i = 0; i < FUSE_MAX; i++) { const int k = i < nf ? i : 0; a.vf[i] = vf[k]; a.vb[i] = vb[k]; a.gx[i] = gx[k]; a.gy[i] = gy[k]; a.gz[i] = gz[k]; }
+    for (int i = 0; i < nf; i++) if (!vf[i] || (m->B && !vb[i]) || !gx[i] || !gy[i] || !gz[i]) return FFM_ERR_ARG;
+#define GM(NF) FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_grad_multi<W, NF>), mview(m), a))
+    switch (nf) { case 1: GM(1); break; case 2: GM(2); break; case 3: GM(3); break; default: GM(4); break; }
+#undef GM
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+extern "C" int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, double k, double lo, double hi, double rDeltaT,
+                                              const double *rho, const double *rho0, const double *phi_f, const double *phi_b,
+                                              const double *gamma_f, const double *gamma_b,
+                                              const double *const *vf, const double *const *gx, const double *const *gy,
+                                              const double *const *gz, const double *const *vf0, const double *const *f,
+                                              const double *const *ref, const double *const *refGrad, const double *const *su,
+                                              const double *const *expl3, double *const *diag, double *const *upper,
+                                              double *const *lower, double *const *source)
+{
+    CHECK_M(m);
+    if (nf < 1 || nf > FUSE_MAX || (scheme != 2 && scheme != 3) || !rho || !rho0 || !phi_f || !gamma_f || (m->B && (!phi_b || !gamma_b)))
+        return FFM_ERR_ARG;
+    if (!vf || !gx || !gy || !gz || !vf0 || !f || !ref || !refGrad || !diag || !upper || !lower || !source) return FFM_ERR_ARG;
+    ScalarEqns a;
+    for (int i = 0; i < FUSE_MAX; i++) {
+        const int q = i < nf ? i : 0;
+        if (i < nf && (!vf[q] || !gx[q] || !gy[q] || !gz[q] || !vf0[q] || !diag[q] || !upper[q] || !lower[q] || !source[q] ||
+                       (m->B && (!f[q] || !ref[q] || !refGrad[q])))) return FFM_ERR_ARG;
+        a.vf[i] = vf[q]; a.gx[i] = gx[q]; a.gy[i] = gy[q]; a.gz[i] = gz[q]; a.vf0[i] = vf0[q];
+        a.f[i] = f[q]; a.ref[i] = ref[q]; a.refGrad[i] = refGrad[q];
+        a.su[i] = su ? su[q] : nullptr;
+        for (int e = 0; e < 3; e++) a.expl[i][e] = expl3 ? expl3[3 * q + e] : nullptr;
+        if (a.expl[i][0] && (!a.expl[i][1] || !a.expl[i][2])) return FFM_ERR_ARG;
+        a.diag[i] = diag[q]; a.upper[i] = upper[q]; a.lower[i] = lower[q]; a.src[i] = source[q];
+    }
+    a.rho = rho; a.rho0 = rho0; a.phi = phi_f; a.phib = phi_b; a.gamma = gamma_f; a.gammab = gamma_b;
+    a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.bMagSf = m->bMagSf; a.bDelta = m->bDelta;
+    a.rdt = rDeltaT; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.scheme = scheme;
+#define SE(NF) FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_scalar_eqns<W, NF>), mview(m), a))
+    switch (nf) { case 1: SE(1); break; case 2: SE(2); break; case 3: SE(3); break; default: SE(4); break; }
+#undef SE
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+extern "C" int ffm_fvm_lust_source3(ffm_mesh *m, double rDeltaT, const double *phi_f, const double *rho0, const double *const *U0,
+                                    const double *const *gx, const double *const *gy, const double *const *gz, double *const *source)
+{
+    CHECK_M(m);
+    if (!phi_f || !rho0 || !U0 || !gx || !gy || !gz || !source) return FFM_ERR_ARG;
+    if (!m->Cf[0]) { ffm_set_error("ffm_fvm_lust_source3: face centres not set (ffm_mesh_set_face_centres)"); return FFM_ERR_ARG; }
+    LustSource a;
+    for (int i = 0; i < 3; i++) {
+        if (!U0[i] || !gx[i] || !gy[i] || !gz[i] || !source[i]) return FFM_ERR_ARG;
+        a.gx[i] = gx[i]; a.gy[i] = gy[i]; a.gz[i] = gz[i]; a.U0[i] = U0[i]; a.src[i] = source[i];
+    }
+    a.phi = phi_f; a.rho0 = rho0; a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.Cfx = m->Cf[0]; a.Cfy = m->Cf[1]; a.Cfz = m->Cf[2];
+    a.rdt = rDeltaT;
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_lust_source<W>, mview(m), a));
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}

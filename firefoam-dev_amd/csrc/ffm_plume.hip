@@ -40,6 +40,14 @@ int ffm_fvm_A(ffm_mesh *, int, const double *, const double *, const double *, c
 int ffm_fvm_H(ffm_mesh *, int, int, const double *, const double *, const double *, const double *, const double *, const double *,
               const double *, const double *, double *);
 int ffm_fvm_flux(ffm_mesh *, const double *, const double *, const double *, const double *, const double *, double *, double *);
+int ffm_fvc_grad_multi(ffm_mesh *, int, const double *const *, const double *const *, double *const *, double *const *, double *const *);
+int ffm_fvm_scalar_transport_multi(ffm_mesh *, int, int, double, double, double, double, const double *, const double *, const double *,
+                                   const double *, const double *, const double *, const double *const *, const double *const *,
+                                   const double *const *, const double *const *, const double *const *, const double *const *,
+                                   const double *const *, const double *const *, const double *const *, const double *const *,
+                                   double *const *, double *const *, double *const *, double *const *);
+int ffm_fvm_lust_source3(ffm_mesh *, double, const double *, const double *, const double *const *, const double *const *,
+                         const double *const *, const double *const *, double *const *);
 }
 const int *ffm_mesh_bcells(const ffm_mesh *m);
 const double *ffm_mesh_geom(const ffm_mesh *m, int which);
@@ -80,6 +88,9 @@ struct ffm_plume {
     // matrix + work
     double *diag, *upper, *lower, *src[3], *ic[3], *bc[3], *dWork, *sWork;
     double *wN[12], *wF[6], *wB[8];
+    // fused assembly (ffm_fused.hip): gradients of up to 4 fields, the matrices of the 4 transported species, their patch values
+    double *gM[4][3], *spD[4], *spU[4], *spL[4], *spS[4], *spB[4], *suM[4];
+    bool fused = true;                     // FFM_PLUME_UNFUSED: one kernel per operator (tests compare the two paths)
     // UEqn kept for pEqn (A, H)
     double *Udiag, *Uupper, *Ulower, *Usrc[3], *Uic[3], *Ubc[3];
     std::vector<SolveLog> log;
@@ -475,6 +486,15 @@ extern "C" int ffm_plume_step(ffm_plume *P)
     double *rx = P->wN[5], *ry = P->wN[6], *rz = P->wN[7];
     FFM_TRY(ffm_fvc_reconstruct(m, t, tb, rx, ry, rz));
     double *rec[3] = {rx, ry, rz};
+    if (P->fused) {
+        // one gradient pass for the three components, one pass for the LUST correction + the ddt source (ffm_fused.hip)
+        for (int c = 0; c < 3; c++) FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, mub, -1, P->fU[c], P->refU[c], P->zeroB, P->Uic[c], P->Ubc[c]));
+        const double *uf[3] = {P->U[0], P->U[1], P->U[2]}, *ub[3] = {Ub[0], Ub[1], Ub[2]}, *u0[3] = {P->U0[0], P->U0[1], P->U0[2]};
+        double *ggx[3] = {P->gM[0][0], P->gM[1][0], P->gM[2][0]}, *ggy[3] = {P->gM[0][1], P->gM[1][1], P->gM[2][1]}, *ggz[3] = {P->gM[0][2], P->gM[1][2], P->gM[2][2]};
+        FFM_TRY(ffm_fvc_grad_multi(m, 3, uf, ub, ggx, ggy, ggz));
+        for (int c = 0; c < 3; c++) { FFM_TRY(HX(P, ggx[c])); FFM_TRY(HX(P, ggy[c])); FFM_TRY(HX(P, ggz[c])); }
+        FFM_TRY(ffm_fvm_lust_source3(m, rdt, P->phi, P->rho0, u0, ggx, ggy, ggz, P->Usrc));
+    } else
     for (int c = 0; c < 3; c++) {
         FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, mub, -1, P->fU[c], P->refU[c], P->zeroB, P->Uic[c], P->Ubc[c]));
         // gaussConvectionScheme::fvmDiv with a corrected() scheme: fvm += fvc::surfaceIntegrate(phi*LUST::correction(U_c))
@@ -507,6 +527,32 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         const double *rho = P->rho, *fuel = P->Y[2], *o2 = P->Y[0];
         forN(P, N, [=] __device__(long i) { const double w = rho[i] * fmin(fuel[i], o2[i] / S_O2) / TAU; wFuel[i] = w; Qdot[i] = w * HC; Yt[i] = 0.0; });
     }
+    if (P->fused) {
+        // the four transported species share phi, rho and dEff: boundary values, gradients and matrices of all four in one
+        // pass each, then the solves in the reference's order (nothing a later equation reads changes in an earlier solve)
+        int sp[NSP - 1], ns = 0;
+        for (int i = 0; i < NSP; i++) if (i != INERT) sp[ns++] = i;
+        const double *vf[4], *vb[4], *vf0[4], *fq[4], *rq[4], *gq[4], *suq[4], *cgx[4], *cgy[4], *cgz[4];
+        double *ggx[4], *ggy[4], *ggz[4];
+        for (int j = 0; j < ns; j++) {
+            const int i = sp[j]; const double nu = NU[i]; double *sj = P->suM[j];
+            forN(P, N, [=] __device__(long c) { sj[c] = nu * wFuel[c]; });
+            FFM_TRY(ffm_bc_values(m, P->fS, P->refY[i], P->zeroB, P->Y[i], P->spB[j]));
+            vf[j] = P->Y[i]; vb[j] = P->spB[j]; vf0[j] = P->Y0[i]; fq[j] = P->fS; rq[j] = P->refY[i]; gq[j] = P->zeroB; suq[j] = sj;
+            ggx[j] = P->gM[j][0]; ggy[j] = P->gM[j][1]; ggz[j] = P->gM[j][2]; cgx[j] = ggx[j]; cgy[j] = ggy[j]; cgz[j] = ggz[j];
+        }
+        FFM_TRY(ffm_fvc_grad_multi(m, ns, vf, vb, ggx, ggy, ggz));
+        for (int j = 0; j < ns; j++) { FFM_TRY(HX(P, ggx[j])); FFM_TRY(HX(P, ggy[j])); FFM_TRY(HX(P, ggz[j])); }
+        FFM_TRY(ffm_fvm_scalar_transport_multi(m, ns, 3, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
+                                               fq, rq, gq, suq, nullptr, P->spD, P->spU, P->spL, P->spS));
+        for (int j = 0; j < ns; j++) {
+            const int i = sp[j];
+            FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[j], P->spL[j], P->Y[i], P->spS[j]));
+            FFM_TRY(HX(P, P->Y[i]));
+            double *Yi = P->Y[i];
+            forN(P, N, [=] __device__(long c) { const double v = fmax(Yi[c], 0.0); Yi[c] = v; Yt[c] += v; });
+        }
+    } else
     for (int i = 0; i < NSP; i++) {
         if (i == INERT) continue;
         const double nu = NU[i];
@@ -538,6 +584,19 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         double *ddtK = P->wN[0], *ndpdt = P->wN[5]; const double *rho = P->rho, *rho0 = P->rho0, *K = P->K, *K0 = P->K0, *dpdt = P->dpdt;
         forN(P, N, [=] __device__(long c) { ddtK[c] = rdt * (rho[c] * K[c] - rho0[c] * K0[c]); ndpdt[c] = -dpdt[c]; });
         const double *expl[3] = {ddtK, divK, ndpdt};       // fvc::ddt(rho,K) + fvc::div(phi,K) + (-dpdt), solver/YEEqn.H:89-101
+        if (P->fused) {
+            const double *vf[1] = {P->hs}, *vb[1] = {P->spB[0]}, *vf0[1] = {P->hs0}, *fq[1] = {P->fH}, *rq[1] = {P->refH}, *gq[1] = {P->zeroB}, *suq[1] = {Qdot};
+            double *ggx[1] = {P->gM[0][0]}, *ggy[1] = {P->gM[0][1]}, *ggz[1] = {P->gM[0][2]};
+            const double *cgx[1] = {ggx[0]}, *cgy[1] = {ggy[0]}, *cgz[1] = {ggz[0]};
+            double *dd[1] = {P->dWork}, *uu[1] = {P->upper}, *ll[1] = {P->lower}, *ss[1] = {P->sWork};
+            FFM_TRY(ffm_bc_values(m, P->fH, P->refH, P->zeroB, P->hs, P->spB[0]));
+            FFM_TRY(ffm_fvc_grad_multi(m, 1, vf, vb, ggx, ggy, ggz));
+            FFM_TRY(HX(P, ggx[0])); FFM_TRY(HX(P, ggy[0])); FFM_TRY(HX(P, ggz[0]));
+            FFM_TRY(ffm_fvm_scalar_transport_multi(m, 1, 2, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
+                                                   fq, rq, gq, suq, expl, dd, uu, ll, ss));
+            FFM_TRY(solve_named(P, "h", FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->dWork, P->upper, P->lower, P->hs, P->sWork));
+            FFM_TRY(HX(P, P->hs));
+        } else
         FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8));
     }
     standin_thermo(P);
@@ -735,6 +794,12 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     for (auto &w : P->wN) w = NN();
     for (auto &w : P->wF) w = dalloc(P, nNat);
     for (auto &w : P->wB) w = dalloc(P, B);
+    P->fused = getenv("FFM_PLUME_UNFUSED") == nullptr;
+    for (int j = 0; j < 4; j++) {
+        for (int d = 0; d < 3; d++) P->gM[j][d] = P->fused ? NN() : nullptr;
+        P->spD[j] = P->fused ? NN() : nullptr; P->spS[j] = P->fused ? NN() : nullptr; P->suM[j] = P->fused ? NN() : nullptr;
+        P->spU[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spL[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spB[j] = P->fused ? dalloc(P, B) : nullptr;
+    }
     for (double *p : P->pool) if (!p) { ffm_set_error("plume: out of device memory"); return FFM_ERR_HIP; }
     PL_HIP(hipDeviceSynchronize());
     // ---- initial state: quiescent ambient, then hydrostatic initialisation

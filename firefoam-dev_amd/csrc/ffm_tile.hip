@@ -76,6 +76,7 @@ struct ffm_tile_plan {
     unsigned long rDpEpoch = ~0ul; int rDpKind = -1;
     // ---- tiled Amul (symmetric matrices): same groups and entries as the forward sweep
     bool amulUsable = false;
+    bool gsTables = false;          // the cell-space upper-neighbour tables below exist (Gauss-Seidel sweeps, Amul tail)
     std::vector<int> grpEntHost;    // forward entries of each group (host copy)
     int4 *arec = nullptr;           // [nEnt + pad] {first cell, cells | externals << 16, first index into aext, 0}
     uint4 *acode = nullptr;         // [nOwn] 8 x 16 bit: 3 lower codes, 3 upper codes (A_* encoding below), 2 spare
@@ -307,13 +308,39 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
 {
     ffm_tile_plan *T = A->tile;
     const int nOwn = A->nOwned, nEnt = (int)recF.size();
+    // ---- cell-space tables of the owned upper neighbours + the faces towards ghost cells (Gauss-Seidel sweeps, Amul tail):
+    // structural requirements only (<= 3 owned upper neighbours, ghost neighbours after the owned ones in slot order)
+    std::vector<int> tailCell, tailStart(1, 0), tailFace, tailNbr;
+    std::vector<int> upSrc((size_t)3 * nOwn, -1), upNb((size_t)3 * nOwn, -1);
+    for (int c = 0; c < nOwn; c++) {
+        const int sl = c >> 6, lane = c & 63;
+        const int uw = (A->h_upOff[sl + 1] - A->h_upOff[sl]) / 64;
+        int k = 0;
+        bool ghostSeen = false;
+        for (int s = 0; s < uw; s++) {
+            const int idx = A->h_upOff[sl] + s * 64 + lane, nb = A->h_upNbr[idx];
+            if (nb < 0) continue;
+            if (nb >= nOwn) {
+                if (!ghostSeen) { tailCell.push_back(c); ghostSeen = true; }
+                tailFace.push_back(idx); tailNbr.push_back(nb);
+                continue;
+            }
+            if (ghostSeen || k >= 3) return FFM_OK;                      // owned after ghost, or too many: no cell-space tables
+            upSrc[(size_t)3 * c + k] = idx; upNb[(size_t)3 * c + k] = nb;
+            k++;
+        }
+        if (ghostSeen) tailStart.push_back((int)tailFace.size());
+    }
+    FFM_TRY(upv(&T->upSrcCell, upSrc)); FFM_TRY(upv(&T->upNbrCell, upNb));
+    T->nTail = (int)tailCell.size();
+    FFM_TRY(upv(&T->tailCell, tailCell)); FFM_TRY(upv(&T->tailStart, tailStart)); FFM_TRY(upv(&T->tailFace, tailFace)); FFM_TRY(upv(&T->tailNbr, tailNbr));
+    T->gsTables = true;
+    // ---- ring plan of the tiled Amul: may give up (too many out-of-window neighbours in one entry), Amul then runs on the row kernel
     std::vector<int> entOf(nOwn, -1);
     for (int e = 0; e < nEnt; e++) for (int c = recF[e].x; c < recF[e].x + (recF[e].y & 0xFFFF); c++) entOf[c] = e;
     std::vector<unsigned short> code((size_t)8 * nOwn, (unsigned short)A_NONE);
     std::vector<int4> arec(nEnt);
     std::vector<int2> aext;
-    std::vector<int> tailCell, tailStart(1, 0), tailFace, tailNbr;
-    std::vector<int> upSrc((size_t)3 * nOwn, -1), upNb((size_t)3 * nOwn, -1);
     auto inRing = [&](int c, int nb) { return grpOfCell[nb] == grpOfCell[c] && std::abs(entOf[nb] - entOf[c]) <= A_WIN; };
     for (int e = 0; e < nEnt; e++) {
         const int c0 = recF[e].x, cnt = recF[e].y & 0xFFFF;
@@ -337,29 +364,17 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
                 }
                 k++;
             }
-            // upper slots in slot order: owned neighbours first, ghost neighbours must follow them
-            const int uw = (A->h_upOff[sl + 1] - A->h_upOff[sl]) / 64;
-            k = 0;
-            bool ghostSeen = false;
-            for (int s = 0; s < uw; s++) {
-                const int idx = A->h_upOff[sl] + s * 64 + lane, nb = A->h_upNbr[idx];
-                if (nb < 0) continue;
-                if (nb >= nOwn) {
-                    if (!ghostSeen) { tailCell.push_back(c); ghostSeen = true; }
-                    tailFace.push_back(idx); tailNbr.push_back(nb);
-                    continue;
-                }
-                if (ghostSeen || k >= 3) return FFM_OK;                      // owned after ghost, or too many: not usable
-                upSrc[(size_t)3 * c + k] = idx; upNb[(size_t)3 * c + k] = nb;
+            // owned upper neighbours in slot order (cell-space tables above)
+            for (k = 0; k < 3; k++) {
+                const int nb = upNb[(size_t)3 * c + k];
+                if (nb < 0) break;
                 if (inRing(c, nb) && nb - c < 2048) code[(size_t)8 * c + 3 + k] = (unsigned short)(nb - c);
                 else {
                     if (t >= A_XMAX) return FFM_OK;
                     code[(size_t)8 * c + 3 + k] = (unsigned short)(A_EXT | t);
                     aext.push_back(make_int2(nb, -1)); t++;
                 }
-                k++;
             }
-            if (ghostSeen) tailStart.push_back((int)tailFace.size());
         }
         arec[e] = make_int4(c0, cnt | (t << 16), extOff, 0);
     }
@@ -368,9 +383,6 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
     FFM_TRY(upv(&T->arec, arec)); FFM_TRY(upv(&T->aext, aext));
     FFM_HIP(hipMalloc((void **)&T->acode, sizeof(unsigned short) * 8 * std::max<size_t>(nOwn, 1)));
     FFM_HIP(hipMemcpy(T->acode, code.data(), sizeof(unsigned short) * code.size(), hipMemcpyHostToDevice));
-    FFM_TRY(upv(&T->upSrcCell, upSrc)); FFM_TRY(upv(&T->upNbrCell, upNb));
-    T->nTail = (int)tailCell.size();
-    FFM_TRY(upv(&T->tailCell, tailCell)); FFM_TRY(upv(&T->tailStart, tailStart)); FFM_TRY(upv(&T->tailFace, tailFace)); FFM_TRY(upv(&T->tailNbr, tailNbr));
     // segments: enough workgroups to fill the chip, each long enough to amortise the A_WIN entries read twice at either end
     {
         const std::vector<int> &grpEntH = T->grpEntHost;
@@ -410,8 +422,8 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
         FFM_HIP(hipMalloc((void **)&T->mailAll, sizeof(double) * T->nMail));
         T->f.mail = T->mailAll; T->b.mail = T->mailAll + T->f.nPub + 1;
         FFM_TRY(build_amul(A, grpOfCell, recF));
-        // the Gauss-Seidel sweeps use the Amul plan's cell-space tables: without it the matrix gets level-scheduled sweeps
-        if (!T->amulUsable) T->usable = false;
+        // the Gauss-Seidel sweeps need the cell-space tables: without them the matrix gets level-scheduled sweeps
+        if (!T->gsTables) T->usable = false;
     }
     return FFM_OK;
 }
@@ -733,7 +745,7 @@ __global__ void k_tile_gs_products(long n3, const int *__restrict__ nbrCell, con
     }
 }
 
-bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable; }
+bool ffm_tile_gs_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->gsTables; }
 
 // the abort word of the sweep kernels (a bounded mailbox wait ran out): reported when a solve ends
 int ffm_tile_check_abort(ffm_ldu *A)

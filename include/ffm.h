@@ -317,6 +317,31 @@ int ffm_fvm_H(ffm_mesh *m, int nCmpt, int cmpt, const double *upper, const doubl
 int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lower, const double *internalCoeffs,
                  const double *boundaryCoeffs, const double *psi, double *out_f, double *out_b);
 
+/* ------------------------------------------------------- fused assembly passes */
+/* The entry points above evaluate one operator per pass, like OpenFOAM's tmp-field algebra (and like the Foam layer of
+ * include/ffmFoam.H calls them).  These produce the same numbers, bit for bit, in one pass per equation and for up to 4
+ * fields that share the flux / density / diffusivity per launch (the species loop of solver/YEEqn.H:37-67); the compiled
+ * time step (ffm_plume_step) is built on them.  Arrays of nf device pointers are HOST arrays.                          */
+/* fvc::grad (Gauss linear) of nf <= 4 fields */
+int ffm_fvc_grad_multi(ffm_mesh *m, int nf, const double *const *vf, const double *const *vb, double *const *gx,
+                       double *const *gy, double *const *gz);
+/* per field i: fvm::ddt(rho,vf_i) + fvm::div(phi,vf_i) [scheme 2 limitedLinear k | 3 limitedLinear01 k in [lo,hi], limiter from
+ * vf_i and its gradient] - fvm::laplacian(gamma,vf_i) == su_i, minus the explicit volume terms expl3[3*i+0..2] (all three or
+ * none; NULL array: none), with the boundary coefficients of the mixed condition (f_i, ref_i, refGrad_i) added:
+ * diag_i, upper_i, lower_i, source_i are what fvMatrix::solveSegregated hands to the linear solver                       */
+int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, double k, double lo, double hi, double rDeltaT,
+                                   const double *rho, const double *rho0, const double *phi_f, const double *phi_b,
+                                   const double *gamma_f, const double *gamma_b,
+                                   const double *const *vf, const double *const *gx, const double *const *gy,
+                                   const double *const *gz, const double *const *vf0, const double *const *f,
+                                   const double *const *ref, const double *const *refGrad, const double *const *su,
+                                   const double *const *expl3, double *const *diag, double *const *upper,
+                                   double *const *lower, double *const *source);
+/* momentum source of solver/UEqn.H:5 with `div(phi,U) Gauss LUST grad(U)`: source_c = rDeltaT*rho0*U0_c*V
+ * - V*fvc::surfaceIntegrate(phi*LUST::correction(U_c)) for the three components from their gradients                  */
+int ffm_fvm_lust_source3(ffm_mesh *m, double rDeltaT, const double *phi_f, const double *rho0, const double *const *U0,
+                         const double *const *gx, const double *const *gy, const double *const *gz, double *const *source);
+
 /* ------------------------------------------------------- synthetic plume case */
 /* Host-side driver (C++ over the entry points above) of one fireFoam time step on
  * the synthetic buoyant-plume box of SURVEY 8(d): rhoEqn, UEqn, YEEqn, 2 x pEqn in

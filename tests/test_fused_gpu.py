@@ -1,0 +1,143 @@
+"""The fused assembly passes (csrc/ffm_fused.hip: ffm_fvc_grad_multi, ffm_fvm_scalar_transport_multi, ffm_fvm_lust_source3) must
+give, bit for bit, what the chain of per-operator entry points gives (each of which is compared with the oracle in
+tests/test_fv_operators_gpu.py): same expressions, same order, FMA contraction off.  And the compiled time step built on them
+must equal the one built on the per-operator kernels (FFM_PLUME_UNFUSED) in every field, bitwise."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(O, ffm, ctx):
+    from oracle import fv, plume
+    m = plume.make_mesh((9, 8, 7), h=0.1)
+    N, F = m.nCells, m.nFaces
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    mesh.set_face_centres(m.Cf[fOrd].T.copy())
+    yield dict(fv=fv, m=m, A=A, mesh=mesh, cOrd=cOrd, fOrd=fOrd, N=N, F=F, B=sum(p.size for p in m.patches))
+    mesh.close(); A.close()
+
+
+def _fields(s, O, ctx, nf):
+    N, F, B, mesh = s["N"], s["F"], s["B"], s["mesh"]
+    dev = ctx.to_device
+    vf = [dev(0.2 + O.hash_u(31 + 7 * i, np.arange(N))) for i in range(nf)]
+    # one field that is constant over most of the mesh (exercises the large-ratio branch of NVDTVD::r)
+    a = 0.2 + O.hash_u(31, np.arange(N)); vf[0] = dev(np.where(a > 0.9, a, 0.25))
+    vb = [dev(0.1 + O.hash_u(133 + i, np.arange(B))) for i in range(nf)]
+    phi = mesh.to_native(0.3 * (O.hash_u(32, np.arange(F)) - 0.5))
+    return vf, vb, phi
+
+
+@pytest.mark.parametrize("nf", [1, 3, 4])
+def test_grad_multi_equals_grad(setup, O, ctx, nf):
+    s, mesh = setup, setup["mesh"]
+    vf, vb, _ = _fields(s, O, ctx, nf)
+    g = [[ctx.zeros(s["N"]) for _ in range(3)] for _ in range(nf)]
+    mesh.call("fvc_grad_multi", nf, vf, vb, [x[0] for x in g], [x[1] for x in g], [x[2] for x in g])
+    for i in range(nf):
+        r = [ctx.zeros(s["N"]) for _ in range(3)]
+        mesh.call("fvc_grad", vf[i], vb[i], *r)
+        for d in range(3):
+            assert np.array_equal(g[i][d].cpu().numpy(), r[d].cpu().numpy()), (i, d)
+
+
+@pytest.mark.parametrize("nf,scheme,with_expl", [(4, 3, False), (1, 2, True), (2, 2, False)])
+def test_scalar_transport_multi_equals_the_operator_chain(setup, O, ctx, nf, scheme, with_expl):
+    s, mesh = setup, setup["mesh"]
+    N, F, B = s["N"], s["F"], s["B"]
+    dev = ctx.to_device
+    vf, vb, phi = _fields(s, O, ctx, nf)
+    if scheme == 3:
+        vf = [v * 1.1 - 0.2 for v in vf]                          # some values outside [0, 1]
+    rho, rho0 = dev(1.0 + O.hash_u(60, np.arange(N))), dev(1.0 + O.hash_u(61, np.arange(N)))
+    vf0 = [dev(O.hash_u(62 + i, np.arange(N))) for i in range(nf)]
+    gam = mesh.to_native(0.01 * (1 + O.hash_u(63, np.arange(F)))); gamb = dev(0.01 * (1 + O.hash_u(64, np.arange(B))))
+    phib = dev(0.2 * (O.hash_u(70, np.arange(B)) - 0.5))
+    f = [dev(np.round(O.hash_u(80 + i, np.arange(B)) * 2) / 2) for i in range(nf)]
+    ref = [dev(O.hash_u(84 + i, np.arange(B))) for i in range(nf)]
+    rg = [dev(O.hash_u(88 + i, np.arange(B)) - 0.5) for i in range(nf)]
+    su = [dev(O.hash_u(90 + i, np.arange(N)) - 0.3) if i % 2 == 0 else None for i in range(nf)]
+    expl = [dev(O.hash_u(95 + e, np.arange(N)) - 0.5) for e in range(3)] if with_expl else None
+    rdt = 1000.0
+    # gradients of the fields (the limiter's input)
+    g = [[ctx.zeros(N) for _ in range(3)] for _ in range(nf)]
+    for i in range(nf):
+        mesh.call("fvc_grad", vf[i], vb[i], *g[i])
+    D = [ctx.zeros(N) for _ in range(nf)]; S = [ctx.zeros(N) for _ in range(nf)]
+    Up = [ctx.zeros(mesh.nNative) for _ in range(nf)]; Lo = [ctx.zeros(mesh.nNative) for _ in range(nf)]
+    mesh.call("fvm_scalar_transport_multi", nf, scheme, 1.0, 0.0, 1.0, rdt, rho, rho0, phi, phib, gam, gamb,
+              vf, [x[0] for x in g], [x[1] for x in g], [x[2] for x in g], vf0, f, ref, rg, su,
+              (expl + [None] * (3 * (nf - 1))) if with_expl else None, D, Up, Lo, S)
+    V = dev(s["m"].V[s["cOrd"]])
+    for i in range(nf):
+        w = ctx.zeros(mesh.nNative)
+        mesh.call("fv_limited_weights", scheme, 1.0, 0.0, 1.0, phi, vf[i], *g[i], w)
+        d, up, lo = ctx.zeros(N), ctx.zeros(mesh.nNative), ctx.zeros(mesh.nNative)
+        mesh.call("fvm_transport", rdt, rho, phi, w, gam, -1, d, up, lo)
+        ic, bc = ctx.zeros(B), ctx.zeros(B)
+        mesh.call("fvm_boundary_coeffs", phib, gamb, -1, f[i], ref[i], rg[i], ic, bc)
+        src = rdt * rho0 * vf0[i] * V
+        if with_expl and i == 0:
+            src = ((src - V * expl[0]) - V * expl[1]) - V * expl[2]
+        if su[i] is not None:
+            src = src + V * su[i]
+        dO, sO = ctx.zeros(N), ctx.zeros(N)
+        mesh.call("fvm_add_boundary", ic, bc, d, src, None, dO, sO)
+        assert np.array_equal(Up[i].cpu().numpy(), up.cpu().numpy()), i
+        assert np.array_equal(Lo[i].cpu().numpy(), lo.cpu().numpy()), i
+        assert np.array_equal(D[i].cpu().numpy(), dO.cpu().numpy()), i
+        assert np.array_equal(S[i].cpu().numpy(), sO.cpu().numpy()), i
+
+
+def test_lust_source3_equals_the_operator_chain(setup, O, ctx):
+    s, mesh = setup, setup["mesh"]
+    N, B = s["N"], s["B"]
+    dev = ctx.to_device
+    vf, vb, phi = _fields(s, O, ctx, 3)
+    rho0 = dev(1.0 + O.hash_u(61, np.arange(N)))
+    U0 = [dev(O.hash_u(62 + i, np.arange(N)) - 0.5) for i in range(3)]
+    g = [[ctx.zeros(N) for _ in range(3)] for _ in range(3)]
+    for i in range(3):
+        mesh.call("fvc_grad", vf[i], vb[i], *g[i])
+    out = [ctx.zeros(N) for _ in range(3)]
+    rdt = 250.0
+    mesh.call("fvm_lust_source3", rdt, phi, rho0, U0, [x[0] for x in g], [x[1] for x in g], [x[2] for x in g], out)
+    V = dev(s["m"].V[s["cOrd"]])
+    zb = ctx.zeros(B)
+    for i in range(3):
+        corr = ctx.zeros(mesh.nNative)
+        mesh.call("fv_lust_correction", phi, *g[i], corr)
+        corr = phi * corr
+        divc = ctx.zeros(N)
+        mesh.call("fvc_surface_integrate", corr, zb, divc)
+        ref = rdt * rho0 * U0[i] * V - V * divc
+        assert np.array_equal(out[i].cpu().numpy(), ref.cpu().numpy()), i
+
+
+FIELDS = ["rho", "p", "p_rgh", "T", "h", "Ux", "Uy", "Uz", "O2", "H2O", "C3H8", "CO2", "N2", "K"]
+
+
+@pytest.mark.parametrize("n", [(12, 16, 12), (40, 36, 33)])
+def test_time_step_fused_equals_per_operator(ffm, ctx, n):
+    """the compiled time step on the fused passes == the same step on one kernel per operator: every field and every
+    iteration count identical after three steps (the second size has several tiles and levels wider than one entry)"""
+    fused = ffm.Plume(ctx, n)
+    os.environ["FFM_PLUME_UNFUSED"] = "1"
+    try:
+        plain = ffm.Plume(ctx, n)
+    finally:
+        os.environ.pop("FFM_PLUME_UNFUSED", None)
+    for step in range(3):
+        fused.step(); plain.step()
+        assert [(a, p["nIterations"]) for a, p in fused.solves()] == [(a, p["nIterations"]) for a, p in plain.solves()]
+        for name in FIELDS:
+            assert np.array_equal(fused.field(name), plain.field(name)), (step, name)
+    fused.close(); plain.close()
