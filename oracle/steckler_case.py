@@ -1,0 +1,571 @@
+"""ORACLE (test infrastructure): the reference's steckler room-fire case (cases/steckler) set up from its case files and advanced
+through the FIRST TIME STEP of solver/fireFoam.C:76-121 with the real physics plug-ins (stage 1):
+  hePsiThermo<singleStepReactingMixture<sutherland<janaf<perfectGas>>>>   oracle/thermo.py
+  LES kEqn, delta cubeRootVol (cases/steckler/constant/turbulenceProperties:18-30)     [upstream kEqn.C, LESeddyViscosity.C]
+  eddyDissipationModel::correct / R / Qdot (lib/thermophysicalModels/combustionModels/eddyDissipationModel/eddyDissipationModel.C:93-149)
+  flowRateInletVelocity (cases/steckler/0/U:40-54), totalFlowRateAdvectiveDiffusive (cases/steckler/0/C3H8:44-50), inletOutlet,
+  pressureInletOutletVelocity, prghTotalHydrostaticPressure, fixedFluxPressure, noSlip, fixedValue, zeroGradient, calculated
+with OpenFOAM's stored-boundary-value semantics (a patch value changes only when something evaluates or assigns it).
+Golden data: cases/steckler/original/linux64/log.fireFoam:163-226 (the first time step): deltaT, the Ux/Uy/Uz, O2, C3H8, h, p_rgh
+and k solves, species min/ave/max, min/max(T).  What of it this restatement reproduces, and how closely, is asserted in
+tests/test_steckler_first_step_cpu.py; every deviation is documented there.  NOT modelled: the fvDOM radiation solve and its
+source radiation->Sh in the enthalpy equation, and the thermalBaffle1D temperature condition of the baffles (treated as
+fixedValue 300 K): both enter the first step through h only (and through thermo.correct() the pressure corrector after it).
+Only tests/ may import this module."""
+import os
+
+import numpy as np
+
+from . import fv, oracle as O, steckler, thermo as TH
+
+CASE_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "steckler_case_data.json")
+PATCHES = ["top", "sides", "base", "burner", "floor", "baffle1DWall_master", "baffle1DWall_slave"]
+G = np.array([0.0, -9.81, 0.0])
+HREF, PREF = 3.0, 101325.0
+SMALL = 1.0e-15
+
+
+def build_mesh():
+    """steckler.build_mesh() with the floor of the block split as topoSet + createPatch do (cases/steckler/system/
+    topoSetDictBurner, topoSetDictCompartment:405-455, createPatchDict): burner = base faces with centre in
+    (-0.1524 .. 0.1524)^3, floor = base faces with centre in (-1.4 0 -1.4)-(1.4 2.18 1.4) minus burner; patch order
+    top, sides, base, burner, floor, baffle1DWall_master, baffle1DWall_slave"""
+    m = steckler.build_mesh()
+    ymin = m._bdefs["ymin"]
+    cx, cz = ymin.Cf[:, 0], ymin.Cf[:, 2]
+    burner = (np.abs(cx) <= 0.1524) & (np.abs(cz) <= 0.1524)
+    floor = (np.abs(cx) <= 1.4) & (np.abs(cz) <= 1.4) & ~burner
+    for name, sel in (("base_part", ~burner & ~floor), ("burner_part", burner), ("floor_part", floor)):
+        m._bdefs[name] = fv.Patch(name, ymin.faceCells[sel], ymin.Sf[sel], ymin.Cf[sel], ymin.deltaCoeffs[sel])
+    m.set_patches([("top", ["ymax"]), ("sides", ["zmax", "zmin", "xmax", "xmin"]), ("base", ["base_part"]), ("burner", ["burner_part"]),
+                   ("floor", ["floor_part"]), ("baffle1DWall_master", ["baffle1DWall_master"]), ("baffle1DWall_slave", ["baffle1DWall_slave"])])
+    return m
+
+
+def _outer(a, b):
+    return a[:, :, None] * b[:, None, :]
+
+
+def grad_vector(m, U, Ub):
+    """fvc::grad(U), Gauss linear (gaussGrad::calcGrad + correctBoundaryConditions): cell tensors T_ij = d_i U_j and their
+    patch values (cell value with the normal component replaced by n*snGrad(U))"""
+    Uf = m.weights[:, None] * U[m.l] + (1.0 - m.weights[:, None]) * U[m.u]
+    g = np.zeros((m.nCells, 3, 3))
+    Sfssf = _outer(m.Sf, Uf)
+    np.add.at(g, m.l, Sfssf)
+    np.subtract.at(g, m.u, Sfssf)
+    for p, ub in zip(m.patches, Ub):
+        np.add.at(g, p.faceCells, _outer(p.Sf, ub))
+    g /= m.V[:, None, None]
+    gb = []
+    for p, ub in zip(m.patches, Ub):
+        n = p.Sf / p.magSf[:, None]
+        gc = g[p.faceCells]
+        sn = p.deltaCoeffs[:, None] * (ub - U[p.faceCells])
+        gb.append(gc + _outer(n, sn - np.einsum("fi,fij->fj", n, gc)))
+    return g, gb
+
+
+def dev2T(g):
+    """dev2(T(gradU)) = T - (2/3) tr(T) I of the transposed tensors"""
+    t = np.swapaxes(g, 1, 2).copy()
+    tr = (t[:, 0, 0] + t[:, 1, 1]) + t[:, 2, 2]
+    for a in range(3):
+        t[:, a, a] = t[:, a, a] - (2.0 / 3.0) * tr
+    return t
+
+
+def div_tensor(m, X, Xb):
+    """fvc::div(volTensorField), Gauss linear: surfaceIntegrate(Sf & interpolate(X))"""
+    Xf = m.weights[:, None, None] * X[m.l] + (1.0 - m.weights[:, None, None]) * X[m.u]
+    fl = np.einsum("fi,fij->fj", m.Sf, Xf)
+    out = np.zeros((m.nCells, 3))
+    np.add.at(out, m.l, fl)
+    np.subtract.at(out, m.u, fl)
+    for p, xb in zip(m.patches, Xb):
+        np.add.at(out, p.faceCells, np.einsum("fi,fij->fj", p.Sf, xb))
+    return out / m.V[:, None]
+
+
+class StecklerCase:
+    def __init__(self, data=None):
+        """data: the species table and reaction of the case (tests/golden/steckler_case_data.json, made from the reference's
+        constant/thermo.compressibleGas and constant/reactions by tests/golden/make_steckler_case_data.py)"""
+        self.m = m = build_mesh()
+        if data is None:
+            import json
+            data = json.load(open(CASE_DATA))
+        tab = {n: {k: (np.array(v) if isinstance(v, list) else v) for k, v in d.items()} for n, d in data["table"].items()}
+        names = data["species"]
+        lhs = [tuple(t) for t in data["reaction"]["lhs"]]; rhs = [tuple(t) for t in data["reaction"]["rhs"]]
+        self.sp = TH.Species(names, tab)
+        self.rx = TH.SingleStep(self.sp, lhs, rhs, fuel=data["fuel"], inert=data["inertSpecie"])
+        self.names = names                                   # O2 H2O C3H8 CO2 N2
+        self.iO2, self.iFuel, self.iN2 = names.index("O2"), names.index("C3H8"), names.index("N2")
+        N = m.nCells
+        self.pidx = {n: q for q, n in enumerate(PATCHES)}
+        P = lambda v: [np.full(p.size, float(v)) for p in m.patches]
+        # ---- 0/ files (cases/steckler/0/*): internal values and the stored patch values after construction
+        self.T = np.full(N, 298.15); self.Tb = P(298.15)
+        for nm in ("baffle1DWall_master", "baffle1DWall_slave"):
+            self.Tb[self.pidx[nm]][:] = 300.0
+        self.p = np.full(N, PREF); self.pb = P(PREF)
+        Y0 = {"O2": 0.23301, "N2": 0.76699}
+        self.Y = np.stack([np.full(N, Y0.get(n, 0.0)) for n in names])
+        self.Yb = [P(0.0) for _ in names]
+        for q, pn in enumerate(PATCHES):
+            wall = pn.startswith("baffle")
+            for i, n in enumerate(names):
+                if n == "O2":
+                    v = 0.232 if wall else (0.0 if pn == "burner" else 0.23301)     # inletOutlet value / zeroGradient copy / fixedValue
+                elif n == "N2":
+                    v = 0.768 if wall else 0.0                                       # calculated 0 ; burner value 0
+                elif n == "C3H8":
+                    v = 1.0 if pn == "burner" else 0.0
+                else:
+                    v = 0.0
+                self.Yb[i][q][:] = v
+        self.U = np.zeros((N, 3)); self.Ub = [np.zeros((p.size, 3)) for p in m.patches]
+        self.k = np.full(N, 1.0e-4); self.kb = P(1.0e-4)
+        self.nut = np.full(N, 1.0e-8); self.nutb = P(0.0)
+        for pn in ("top", "sides", "burner"):
+            self.nutb[self.pidx[pn]][:] = 1.0e-8                                     # zeroGradient copies of the internal value
+        self.alphat = np.zeros(N); self.alphatb = P(0.0)
+        self.delta = np.cbrt(m.V)                                                    # cubeRootVol, deltaCoeff 1
+        self.Ck, self.Ce, self.Prt = 0.094, 1.048, 1.0
+        ghRef = -np.linalg.norm(G) * HREF
+        self.gh = m.C @ G - ghRef
+        self.ghf = m.Cf @ G - ghRef
+        self.ghb = [p.Cf @ G - ghRef for p in m.patches]
+        self.phi = np.zeros(m.nFaces); self.phib = P(0.0)
+        self.log = []
+        # ---- thermo construction: he = Hs(p, T) cell / face values, then calculate()
+        self.he = self.mix().Hs(self.p, self.T)
+        self.heb = [mx.Hs(pb, tb) for mx, pb, tb in zip(self.mixb(), self.pb, self.Tb)]
+        self.thermo_correct()
+        self.rho = self.psi * self.p; self.rhob = [a * b for a, b in zip(self.psib, self.pb)]
+        self.p_rgh = np.zeros(N); self.p_rghb = P(0.0); self.p_rgh_grad = P(0.0)
+
+    # ------------------------------------------------------------------ thermo
+    def mix(self):
+        return self.sp.mixture(self.Y)
+
+    def mixb(self):
+        return [self.sp.mixture(np.stack([self.Yb[i][q] for i in range(len(self.names))])) for q in range(len(self.m.patches))]
+
+    FIXES_T = ("base", "burner", "floor")
+
+    def thermo_correct(self):
+        """hePsiThermo::calculate(): cells, then patch faces (T from he unless the T patch fixes its value)"""
+        mx = self.mix()
+        self.T = mx.THs(self.he, self.p, self.T)
+        self.psi = mx.psi(self.p, self.T); self.mu = mx.mu(self.p, self.T); self.alpha = mx.alphah(self.p, self.T)
+        self.psib, self.mub, self.alphab = [], [], []
+        for q, (pn, mb) in enumerate(zip(PATCHES, self.mixb())):
+            if pn in self.FIXES_T or (self.baffle_fixed and pn.startswith("baffle")):
+                self.heb[q] = mb.Hs(self.pb[q], self.Tb[q])
+            else:
+                self.Tb[q] = mb.THs(self.heb[q], self.pb[q], self.Tb[q])
+            self.psib.append(mb.psi(self.pb[q], self.Tb[q])); self.mub.append(mb.mu(self.pb[q], self.Tb[q]))
+            self.alphab.append(mb.alphah(self.pb[q], self.Tb[q]))
+
+    baffle_fixed = False          # True: the baffle temperature kept at its file value (300 K) instead of thermalBaffle1D
+
+    # ------------------------------------------------------------------ hydrostatic initialisation (solver/phrghEqn.H)
+    def hydrostatic_init(self, nCorr=5):
+        m = self.m
+        ph = np.zeros(m.nCells); phb = [np.zeros(p.size) for p in m.patches]
+        self.p = ph + self.rho * self.gh + PREF
+        self.pb = [a + r * g + PREF for a, r, g in zip(phb, self.rhob, self.ghb)]
+        self.thermo_correct()
+        self.rho = self.psi * self.p; self.rhob = [a * b for a, b in zip(self.psib, self.pb)]
+        for _ in range(nCorr):
+            rhof, rhofb = fv.interpolate(m, self.rho, self.rhob)
+            sg, sgb = fv.snGrad(m, self.rho, self.rhob)
+            phig = -rhof * self.ghf * sg * m.magSf
+            phigb = [-rf * gf * s * pp.magSf for rf, gf, s, pp in zip(rhofb, self.ghb, sgb, m.patches)]
+            grads = [phigb[q] / (pp.magSf * rhofb[q]) for q, pp in enumerate(m.patches)]       # constrainPressure, U = 0
+            bcs = [("fixedValue", 0.0) if pp.name == "top" else ("fixedGradient", grads[q]) for q, pp in enumerate(m.patches)]
+            M = fv.laplacian(m, rhof, rhofb, bcs)
+            M.source += m.V * fv.surface_integrate(m, phig, phigb)
+            d, s = M.solve_ready()
+            ph, perf = O.Ldu(m.nCells, m.l, m.u).set_coeffs(d, M.upper).solve(O.PCG, O.DIC, ph, s, tolerance=1e-6, relTol=0.01)
+            self.log.append(("ph_rgh", perf))
+            phb = [np.zeros(pp.size) if bcs[q][0] == "fixedValue" else ph[pp.faceCells] + bcs[q][1] / pp.deltaCoeffs for q, pp in enumerate(m.patches)]
+            self.p = ph + self.rho * self.gh + PREF
+            self.pb = [a + r * g + PREF for a, r, g in zip(phb, self.rhob, self.ghb)]
+            self.thermo_correct()
+            self.rho = self.psi * self.p; self.rhob = [a * b for a, b in zip(self.psib, self.pb)]
+        self.ph_rgh, self.ph_rghb = ph, phb
+        # p_rgh = ph_rgh: internal values; patch values are copied except on the fixedValue-derived patches (top, sides:
+        # prghTotalHydrostaticPressure), whose assignment operators do nothing; stored gradients stay as read (0)
+        self.p_rgh = ph.copy()
+        for q, pn in enumerate(PATCHES):
+            if pn not in ("top", "sides"):
+                self.p_rghb[q] = phb[q].copy()
+
+    # ------------------------------------------------------------------ turbulence (kEqn)
+    def correct_nut(self):
+        """kEqn::correctNut: nut = Ck*sqrt(k)*delta; nut.correctBoundaryConditions(); alphat = rho*nut/Prt (+ its BCs)"""
+        m = self.m
+        self.nut = self.Ck * np.sqrt(self.k) * self.delta
+        for q, pn in enumerate(PATCHES):
+            if pn in ("top", "sides", "burner"):
+                self.nutb[q] = self.nut[m.patches[q].faceCells].copy()               # zeroGradient
+            else:
+                self.nutb[q] = np.zeros(m.patches[q].size)                            # fixedValue 0 / calculated 0 (nutk wall value not used)
+        self.alphat = self.rho * self.nut / self.Prt
+        for q, pn in enumerate(PATCHES):
+            if pn.startswith("baffle"):
+                self.alphatb[q] = self.rhob[q] * self.nutb[q] / 0.85                  # alphatWallFunction, Prt 0.85: 0 here
+            else:
+                self.alphatb[q] = self.alphat[m.patches[q].faceCells].copy()         # zeroGradient
+
+    def nuEff_rho(self):
+        """rho*nuEff as the volScalarField product: rho*(nut + mu/rho), cells and patch faces"""
+        c = self.rho * (self.nut + self.mu / self.rho)
+        b = [r * (n + mu / r) for r, n, mu in zip(self.rhob, self.nutb, self.mub)]
+        return c, b
+
+    # ------------------------------------------------------------------ one time step
+    def set_delta_t_first(self):
+        """solver/setMultiRegionDeltaT.H + setDeltaT.H with CoNum = 0 and Time::adjustDeltaT (adjustableRunTime, writeInterval 1):
+        0.05 -> 0.06 -> 1/17 -> 1.2/17 -> 1/15; the log prints deltaT = 0.066666667"""
+        dt = 0.05
+
+        def adjust(d, toWrite=1.0):
+            n = int(toWrite / d - 1e-15) + 1
+            nd = toWrite / n
+            return min(nd, 2.0 * d) if nd >= d else max(nd, 0.2 * d)
+        dt = adjust(min(dt * 1.2, 0.1))
+        dt = adjust(min(1.2 * dt, 0.1))
+        self.dt = dt; self.rdt = 1.0 / dt
+
+    def solve_smooth(self, name, d, up, lo, s, psi0, tol):
+        m = self.m
+        A = O.Ldu(m.nCells, m.l, m.u).set_coeffs(d, up, lo)
+        psi, perf = A.solve(O.SMOOTH, O.SYMGS, psi0, s, tolerance=tol, relTol=0.0, maxIter=10)
+        self.log.append((name, perf))
+        return psi
+
+    def bc_U(self):
+        """mixed-form coefficients of the U patches per component: noSlip / fixedValue / flowRateInletVelocity f = 1 (ref = stored
+        value), pressureInletOutletVelocity: normal component zeroGradient, tangential f = 1 - pos0(phi) with ref 0"""
+        m = self.m
+        bcs = [fv.MixedBC(m) for _ in range(3)]
+        for q, pn in enumerate(PATCHES):
+            p = m.patches[q]
+            for c in range(3):
+                if pn in ("top", "sides"):
+                    nrm = np.abs(p.Sf[:, c]) > 0
+                    bcs[c].f[q] = np.where(nrm, 0.0, 1.0 - fv.pos0(self.phib[q]))
+                else:
+                    bcs[c].f[q][:] = 1.0
+                    bcs[c].ref[q] = self.Ub[q][:, c].copy()
+        return bcs
+
+    def update_burner_velocity(self):
+        """flowRateInletVelocity::updateCoeffs (massFlowRate table, constant 0.03 kg/s; extrapolateProfile false):
+        U = -massFlowRate/gSum(rho_patch*magSf) * nf with the CURRENT patch values of the field rho; runs whenever U's patch
+        fields are updated (matrix construction, U.correctBoundaryConditions())"""
+        q = self.pidx["burner"]; pb = self.m.patches[q]
+        avgU = -0.03 / np.sum(self.rhob[q] * pb.magSf)
+        self.Ub[q] = avgU * (pb.Sf / pb.magSf[:, None])
+
+    def U_eqn(self):
+        m, rdt = self.m, self.rdt
+        # fvm::ddt(rho, U) constructs the matrix: U's patch fields updateCoeffs() -> flowRateInletVelocity sets the burner value
+        self.update_burner_velocity()
+        bcU = self.bc_U()
+        UEqn = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.U0.T)
+        wU = fv.lust_weights(m, self.phi)
+        divU = fv.fvm_div(m, self.phi, self.phib, wU, bcU)
+        Ubc = [np.stack([bcU[c].values(m, self.U[:, c])[qq] for c in range(3)], axis=1) for qq in range(len(m.patches))]
+        zb = [np.zeros(p.size) for p in m.patches]
+        divU.add_vol(np.stack([fv.surface_integrate(m, self.phi * fv.lust_correction(m, self.phi, fv.grad(m, self.U[:, c], [b[:, c] for b in Ubc])), zb)
+                               for c in range(3)]))
+        UEqn += divU
+        # turbulence->divDevRhoReff(U) = - fvc::div((rho*nuEff)*dev2(T(grad(U)))) - fvm::laplacian(rho*nuEff, U)
+        gam, gamb = self.nuEff_rho()
+        gU, gUb = grad_vector(m, self.U, Ubc)
+        X = gam[:, None, None] * dev2T(gU); Xb = [g[:, None, None] * dev2T(t) for g, t in zip(gamb, gUb)]
+        gamf, _ = fv.interpolate(m, gam, gamb)
+        lap = fv.fvm_laplacian(m, gamf, gamb, bcU)
+        # (- div(X)) - laplacian: the matrix negated, source -= V*(-div X)
+        neg = fv.Matrix(m, 3); neg -= lap
+        neg.add_vol(-div_tensor(m, X, Xb).T)
+        UEqn += neg
+        self.UEqn = UEqn
+        # solve(UEqn == fvc::reconstruct((-ghf*snGrad(rho) - snGrad(p_rgh))*magSf))
+        sgr, sgrb = fv.snGrad(m, self.rho, self.rhob)
+        sgp = m.deltaCoeffs * (self.p_rgh[m.u] - self.p_rgh[m.l])
+        sgpb = []
+        for qq, pn in enumerate(PATCHES):
+            p = m.patches[qq]
+            if pn in ("top", "sides"):                                        # fixedValue-derived: delta*(value - cell)
+                sgpb.append(p.deltaCoeffs * (self.p_rghb[qq] - self.p_rgh[p.faceCells]))
+            else:                                                             # fixedGradient::snGrad() = the stored gradient
+                sgpb.append(self.p_rgh_grad[qq].copy())
+        fl = (-self.ghf * sgr - sgp) * m.magSf
+        flb = [(-g * a - b) * p.magSf for g, a, b, p in zip(self.ghb, sgrb, sgpb, m.patches)]
+        rec = fv.reconstruct(m, fl, flb)
+        for c in range(3):
+            d, s = UEqn.solve_system(c)
+            s = s + m.V * rec[:, c]
+            self.U[:, c] = self.solve_smooth("U" + "xyz"[c], d, UEqn.upper, UEqn.lower, s, self.U[:, c], 1e-6)
+        # U.correctBoundaryConditions()
+        Ubc = [np.stack([bcU[c].values(m, self.U[:, c])[qq] for c in range(3)], axis=1) for qq in range(len(m.patches))]
+        self.Ub = Ubc
+        self.K = 0.5 * (self.U ** 2).sum(axis=1)
+
+    def step_begin(self):
+        self.set_delta_t_first()
+        self.rho0, self.U0 = self.rho.copy(), self.U.copy()
+        m = self.m
+        # rhoEqn.H: fvm::ddt(rho) + fvc::div(phi) == 0, diagonal solve
+        d = self.rdt * m.V
+        s = self.rdt * self.rho0 * m.V - m.V * fv.surface_integrate(m, self.phi, self.phib)
+        self.rho = s / d
+        self.log.append(("rho", dict(initialResidual=0.0, finalResidual=0.0, nIterations=0)))
+
+
+    # ------------------------------------------------------------------ solver/YEEqn.H
+    def alphaEff(self):
+        """heThermo::alphaEff(alphat) for sensibleEnthalpy: CpByCpv (= 1) * (alpha + alphat), cells and patch faces"""
+        return 1.0 * (self.alpha + self.alphat), [1.0 * (a + t) for a, t in zip(self.alphab, self.alphatb)]
+
+    def edc_correct(self):
+        """eddyDissipationModel::correct (reference lib/.../eddyDissipationModel.C:93-149): C_EDC 4, C_Diff 0, C_Stiff 1;
+        kEqn::epsilon = Ce*k*sqrt(k)/delta"""
+        C_EDC, Cd, Cstiff = 4.0, 0.0, 1.0
+        eps = self.Ce * self.k * np.sqrt(self.k) / self.delta
+        rtTurb = C_EDC * eps / np.maximum(self.k, SMALL)
+        rtDiff = Cd * self.alpha / self.rho / self.delta ** 2
+        rt = np.maximum(rtTurb, rtDiff)
+        self.wFuel = self.rho * np.minimum(self.Y[self.iFuel], self.Y[self.iO2] / self.rx.s) / self.dt / Cstiff * (1.0 - np.exp(-Cstiff * self.dt * rt))
+        self.Qdot = self.rx.qFuel * self.wFuel          # singleStepCombustion::Qdot = -qFuel*(R(fuel) & Yfuel), R(fuel) = -wFuel
+
+    def bc_specie(self, i, dEffb):
+        """mixed-form patch coefficients of specie i (cases/steckler/0/{O2,N2,C3H8,Ydefault})"""
+        m, n = self.m, self.names[i]
+        bc = fv.MixedBC(m)
+        inlet = {"O2": 0.23301}.get(n, 0.0)
+        for q, pn in enumerate(PATCHES):
+            p = m.patches[q]
+            io = pn in ("top", "sides") or (n == "C3H8" and pn in ("base", "floor"))
+            if pn == "burner":            # totalFlowRateAdvectiveDiffusive
+                bc.ref[q][:] = 1.0 if n == "C3H8" else 0.0
+                bc.f[q] = 1.0 / (1.0 + dEffb[q] * p.deltaCoeffs * p.magSf / np.maximum(np.abs(self.phib[q]), SMALL))
+            elif io:
+                bc.f[q] = 1.0 - fv.pos0(self.phib[q]); bc.ref[q][:] = inlet
+            elif pn.startswith("baffle") and n in ("O2", "N2"):
+                bc.f[q][:] = 1.0; bc.ref[q][:] = 0.232 if n == "O2" else 0.768
+            # else zeroGradient
+        return bc
+
+    def YE_eqn(self, with_h=True):
+        m, rdt = self.m, self.rdt
+        dEff, dEffb = self.alphaEff()                      # lewisNo 1: dEff -= alpha*(1 - 1/1) leaves it unchanged
+        dEff = dEff - self.alpha * (1 - 1.0 / 1.0); dEffb = [a - b * (1 - 1.0 / 1.0) for a, b in zip(dEffb, self.alphab)]
+        self.edc_correct()
+        df, _ = fv.interpolate(m, dEff, dEffb)
+        self.Y0 = self.Y.copy()
+        Yt = 0.0 * self.Y[0]; Ytb = [0.0 * b for b in self.Yb[0]]
+        for i, n in enumerate(self.names):
+            if i == self.iN2:
+                continue
+            bc = self.bc_specie(i, dEffb)
+            Yb = bc.values(m, self.Y[i])
+            w = fv.limited_weights(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0)
+            E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.Y0[i])
+            E += fv.fvm_div(m, self.phi, self.phib, w, [bc])
+            E -= fv.fvm_laplacian(m, df, dEffb, [bc])
+            E.add_su(self.rx.massCoeffs[i] * self.wFuel)            # combustion->R(Yi), semiImplicit no
+            d, s = E.solve_system()
+            Yi = self.solve_smooth(n, d, E.upper, E.lower, s, self.Y[i], 1e-8)
+            self.Y[i] = np.maximum(Yi, 0.0)
+            self.Yb[i] = [np.maximum(b, 0.0) for b in bc.values(m, Yi)]
+            Yt = Yt + self.Y[i]; Ytb = [a + b for a, b in zip(Ytb, self.Yb[i])]
+        self.Y[self.iN2] = np.maximum(1.0 - Yt, 0.0)
+        self.Yb[self.iN2] = [np.maximum(1.0 - b, 0.0) for b in Ytb]
+        self.species_stats = {n: (self.Y[i].min(), self.Y[i].mean(), self.Y[i].max()) for i, n in enumerate(self.names)}
+        if not with_h:
+            return
+        # ---- EEqn (radiation->Sh not modelled; baffle temperature fixed at its file value)
+        aE, aEb = self.alphaEff()
+        af, _ = fv.interpolate(m, aE, aEb)
+        mxb = self.mixb(); mxc = self.mix()
+        bch = fv.MixedBC(m)
+        Cpb = [mx.Cp(pb, tb) for mx, pb, tb in zip(mxb, self.pb, self.Tb)]
+        for q, pn in enumerate(PATCHES):
+            p = m.patches[q]
+            if pn in ("top", "sides") or (pn.startswith("baffle") and not self.baffle_fixed):
+                # mixedEnergy::updateCoeffs: Tw.evaluate() first (its own updateCoeffs included), then the mixed form in he
+                if pn in ("top", "sides"):                   # T inletOutlet, inletValue 298.15
+                    fT = 1.0 - fv.pos0(self.phib[q]); refT = np.full(p.size, 298.15); gradT = np.zeros(p.size)
+                else:
+                    # compressible::thermalBaffle1D<hConstSolidThermoPhysics> (cases/steckler/0/T:51-82): thickness 0.005, Qs 100,
+                    # solid kappa 1, Qr none; the other side's wall temperature is its stored patch value (the master is updated
+                    # first, the slave then sees the master's new value); the face pairs of the two patches are listed in the same order
+                    other = self.pidx["baffle1DWall_slave" if pn.endswith("master") else "baffle1DWall_master"]
+                    kappaw = Cpb[q] * (self.alphab[q] + self.alphatb[q])               # turbModel.kappaEff(patchi)
+                    myKDelta = p.deltaCoeffs * kappaw
+                    nbrTp = self.Tb[other]
+                    KDeltaSolid = np.full(p.size, 1.0) / 0.005
+                    alpha_ = KDeltaSolid - 0.0 / self.Tb[q]
+                    fT = alpha_ / (alpha_ + myKDelta)
+                    refT = (KDeltaSolid * nbrTp + 100.0 / 2.0) / alpha_
+                    gradT = np.zeros(p.size)
+                self.Tb[q] = fT * refT + (1.0 - fT) * (self.T[p.faceCells] + gradT / p.deltaCoeffs)
+                cellmix = self.sp.mixture(self.Y[:, p.faceCells])
+                bch.f[q] = fT
+                bch.ref[q] = mxb[q].Hs(self.pb[q], refT)
+                bch.refGrad[q] = mxb[q].Cp(self.pb[q], self.Tb[q]) * gradT + p.deltaCoeffs * (mxb[q].Hs(self.pb[q], self.Tb[q]) - cellmix.Hs(self.pb[q], self.Tb[q]))
+            else:                                            # fixedValue T -> fixedEnergy
+                bch.f[q][:] = 1.0
+                bch.ref[q] = mxb[q].Hs(self.pb[q], self.Tb[q])
+        self.he0 = self.he.copy()
+        # K.oldTime() is first asked for here (fvc::ddt(rho, K)) and K was already assigned in UEqn.H: GeometricField::oldTime()
+        # creates the old-time field as a copy of the CURRENT one, so in the first time step K0 == K (from the second step on the
+        # old value is stored at the first assignment of the new step)
+        self.K0 = self.K.copy()
+        hb = bch.values(m, self.he)
+        wh = fv.limited_weights(m, "limitedLinear", self.phi, self.he, fv.grad(m, self.he, hb), 1.0)
+        Kb = [0.5 * (u ** 2).sum(axis=1) for u in self.Ub]
+        wK = fv.limited_weights(m, "limitedLinear", self.phi, self.K, fv.grad(m, self.K, Kb), 1.0)
+        Kf = wK * self.K[m.l] + (1.0 - wK) * self.K[m.u]
+        E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.he0)
+        E += fv.fvm_div(m, self.phi, self.phib, wh, [bch])
+        E.add_vol(rdt * (self.rho * self.K - self.rho0 * self.K0))
+        E.add_vol(fv.surface_integrate(m, self.phi * Kf, [pb * kb for pb, kb in zip(self.phib, Kb)]))
+        E.add_vol(-self.dpdt)
+        E -= fv.fvm_laplacian(m, af, aEb, [bch])
+        E.add_su(self.Qdot)
+        d, s = E.solve_system()
+        self.he = self.solve_smooth("h", d, E.upper, E.lower, s, self.he, 1e-8)
+        self.heb = bch.values(m, self.he)
+        self.thermo_correct()
+        self.minmaxT = (min(self.T.min(), min(b.min() for b in self.Tb)), max(self.T.max(), max(b.max() for b in self.Tb)))
+
+    # ------------------------------------------------------------------ solver/pEqn.H
+    def p_corrector(self, final):
+        m, rdt, UEqn = self.m, self.rdt, self.UEqn
+        self.rho = self.psi * self.p; self.rhob = [a * b for a, b in zip(self.psib, self.pb)]
+        A = UEqn.A()
+        rAU = 1.0 / A; rAUb = [1.0 / A[p.faceCells] for p in m.patches]           # extrapolatedCalculated patches
+        rhorAU = self.rho * rAU; rhorAUb = [a * b for a, b in zip(self.rhob, rAUb)]
+        rhorAUf, rhorAUfb = fv.interpolate(m, rhorAU, rhorAUb)
+        H = UEqn.H(self.U.T).T
+        HbyA = rAU[:, None] * H
+        bcU = self.bc_U()
+        HbyAb = []
+        for q, pn in enumerate(PATCHES):
+            p = m.patches[q]
+            if pn in ("top", "sides"):                        # assignable: the extrapolated value
+                HbyAb.append(rAUb[q][:, None] * H[p.faceCells])
+            else:                                             # constrainHbyA: U's value
+                HbyAb.append(self.Ub[q].copy())
+        sgr, sgrb = fv.snGrad(m, self.rho, self.rhob)
+        phig = -rhorAUf * self.ghf * sgr * m.magSf
+        phigb = [-a * g * s_ * p.magSf for a, g, s_, p in zip(rhorAUfb, self.ghb, sgrb, m.patches)]
+        rhoH = self.rho[:, None] * HbyA; rhoHb = [r[:, None] * h for r, h in zip(self.rhob, HbyAb)]
+        flux = sum((m.weights * rhoH[m.l, c] + (1.0 - m.weights) * rhoH[m.u, c]) * m.Sf[:, c] for c in range(3))
+        fluxb = [sum(rh[:, c] * p.Sf[:, c] for c in range(3)) for rh, p in zip(rhoHb, m.patches)]
+        # fvc::ddtCorr(rho, U, phi): old-time flux and velocity are zero in the first step
+        rhoU0 = self.rho0[:, None] * self.U0
+        phiCorr = self.phi0 - sum((m.weights * rhoU0[m.l, c] + (1.0 - m.weights) * rhoU0[m.u, c]) * m.Sf[:, c] for c in range(3))
+        coeff = 1.0 - np.minimum(np.abs(phiCorr) / (np.abs(self.phi0) + SMALL), 1.0)
+        phiHbyA = (flux + rhorAUf * (coeff * rdt * phiCorr)) + phig
+        phiHbyAb = [a + b for a, b in zip(fluxb, phigb)]
+        # constrainPressure: gradient of the fixedFluxPressure patches
+        bcp = fv.MixedBC(m)
+        for q, pn in enumerate(PATCHES):
+            p = m.patches[q]
+            if pn in ("top", "sides"):                        # prghTotalHydrostaticPressure
+                bcp.f[q][:] = 1.0
+                bcp.ref[q] = self.ph_rghb[q] - 0.5 * self.rhob[q] * (1.0 - fv.pos0(self.phib[q])) * (self.Ub[q] ** 2).sum(axis=1)
+            else:
+                self.p_rgh_grad[q] = (phiHbyAb[q] - self.rhob[q] * sum(p.Sf[:, c] * self.Ub[q][:, c] for c in range(3))) / (p.magSf * rhorAUfb[q])
+                bcp.refGrad[q] = self.p_rgh_grad[q]
+        E = fv.fvm_ddt(m, rdt, self.psi, self.psi0, self.p_rgh0)
+        E.add_vol(rdt * (self.psi * self.rho - self.psi0 * self.rho0) * self.gh)
+        E.add_vol(rdt * (self.psi - self.psi0) * PREF)
+        E.add_vol(fv.surface_integrate(m, phiHbyA, phiHbyAb))
+        E -= fv.fvm_laplacian(m, rhorAUf, rhorAUfb, [bcp])
+        d, s = E.solve_system()
+        A_ = O.Ldu(m.nCells, m.l, m.u).set_coeffs(d, E.upper)
+        self.p_rgh, perf = A_.solve(O.PCG, O.DIC, self.p_rgh, s, tolerance=1e-6, relTol=0.0 if final else 0.01)
+        self.log.append(("p_rgh", perf))
+        self.p_rghb = bcp.values(m, self.p_rgh)
+        fl, flb = E.flux(self.p_rgh)
+        self.phi = phiHbyA + fl
+        self.phib = [a + b for a, b in zip(phiHbyAb, flb)]
+        rec = fv.reconstruct(m, (fl + phig) / rhorAUf, [(a + b) / r for a, b, r in zip(flb, phigb, rhorAUfb)])
+        self.U = HbyA + rAU[:, None] * rec
+        self.update_burner_velocity()                         # U.correctBoundaryConditions()
+        bcU = self.bc_U()
+        self.Ub = [np.stack([bcU[c].values(m, self.U[:, c])[qq] for c in range(3)], axis=1) for qq in range(len(m.patches))]
+        self.p = self.p_rgh + self.rho * self.gh + PREF
+        self.pb = [a + r * g + PREF for a, r, g in zip(self.p_rghb, self.rhob, self.ghb)]
+        # rhoEqn.H + compressibleContinuityErrs.H
+        self.rho = (rdt * self.rho0 * m.V - m.V * fv.surface_integrate(m, self.phi, self.phib)) / (rdt * m.V)
+        self.log.append(("rho", dict(initialResidual=0.0, finalResidual=0.0, nIterations=0)))
+        trho = self.psi * self.p
+        totalMass = (self.rho * m.V).sum()
+        self.contErr = ((np.abs(self.rho - trho) * m.V).sum() / totalMass, ((self.rho - trho) * m.V).sum() / totalMass)
+        self.contErrs = getattr(self, "contErrs", []) + [self.contErr]
+        self.K = 0.5 * (self.U ** 2).sum(axis=1)
+        self.dpdt = rdt * (self.p - self.p0)
+
+    # ------------------------------------------------------------------ turbulence->correct(): kEqn
+    def k_eqn(self):
+        m, rdt = self.m, self.rdt
+        rhof, _ = fv.interpolate(m, self.rho, self.rhob)
+        divU = fv.surface_integrate(m, self.phi / rhof, [a / b for a, b in zip(self.phib, self.rhob)])
+        gU, _ = grad_vector(m, self.U, self.Ub)
+        twoSymm = gU + np.swapaxes(gU, 1, 2)
+        tr = (twoSymm[:, 0, 0] + twoSymm[:, 1, 1]) + twoSymm[:, 2, 2]
+        dev = twoSymm.copy()
+        for a in range(3):
+            dev[:, a, a] = dev[:, a, a] - (1.0 / 3.0) * tr
+        Gk = self.nut * np.einsum("nij,nij->n", gU, dev)
+        bck = fv.MixedBC(m)
+        for q, pn in enumerate(PATCHES):
+            if pn in ("top", "sides"):
+                bck.f[q] = 1.0 - fv.pos0(self.phib[q]); bck.ref[q][:] = 1.0e-4
+            elif pn == "burner":
+                bck.f[q][:] = 1.0; bck.ref[q][:] = 1.0e-4
+        Dk = self.rho * (self.nut + self.mu / self.rho); Dkb = [r * (n + mu / r) for r, n, mu in zip(self.rhob, self.nutb, self.mub)]
+        Dkf, _ = fv.interpolate(m, Dk, Dkb)
+        kb = bck.values(m, self.k)
+        w = fv.limited_weights(m, "limitedLinear", self.phi, self.k, fv.grad(m, self.k, kb), 1.0)
+        self.k0 = self.k.copy()
+        E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.k0)
+        E += fv.fvm_div(m, self.phi, self.phib, w, [bck])
+        E -= fv.fvm_laplacian(m, Dkf, Dkb, [bck])
+        E.add_su(self.rho * Gk)
+        # - fvm::SuSp((2/3)*rho*divU, k): the matrix SuSp(s): diag += V*max(s,0), source -= V*min(s,0)*k; subtracted from the RHS
+        ss = (2.0 / 3.0) * self.rho * divU
+        E.diag += m.V * np.maximum(ss, 0.0); E.source[0] -= m.V * np.minimum(ss, 0.0) * self.k
+        sp = self.Ce * self.rho * np.sqrt(self.k) / self.delta
+        E.diag += m.V * sp
+        d, s = E.solve_system()
+        self.k = self.solve_smooth("k", d, E.upper, E.lower, s, self.k, 1e-8)
+        self.kb = bck.values(m, self.k)
+        self.k = np.maximum(self.k, SMALL)                   # bound(k, kMin): kMin = SMALL
+        self.correct_nut()
+
+
+def first_step_records(with_h=True):
+    c = StecklerCase()
+    c.hydrostatic_init()
+    c.correct_nut()                      # turbulence->validate()
+    c.psi0, c.p0, c.p_rgh0, c.phi0 = c.psi.copy(), c.p.copy(), c.p_rgh.copy(), c.phi.copy()
+    c.dpdt = np.zeros(c.m.nCells); c.K = np.zeros(c.m.nCells)
+    c.step_begin()
+    c.U_eqn()
+    c.YE_eqn(with_h)
+    c.p_corrector(False)
+    c.p_corrector(True)
+    c.k_eqn()
+    return c
