@@ -365,6 +365,14 @@ class lduMatrix:
         """0 level-scheduled, 2 tiled wavefront"""
         return lib().ffm_ldu_sweep_mode(self.h)
 
+    def bind_coeffs_native(self, diag, upper, lower=None):
+        """zero-copy: the matrix reads device tensors in the library's native layout (diag [nCells], upper / lower [nNative])
+        until the next set / bind call; the caller keeps them alive (ffm_ldu_bind_coeffs_native_d)"""
+        self._bound = (diag, upper, lower)
+        _check(lib().ffm_ldu_bind_coeffs_native_d(self.h, C.c_void_p(diag.data_ptr()), C.c_void_p(upper.data_ptr()),
+                                                  None if lower is None else C.c_void_p(lower.data_ptr()), 0), "ffm_ldu_bind_coeffs_native_d")
+        return self
+
     def debug_set_sweep_ticket(self, value):
         """tests: preset the group ticket counter of the tiled sweeps (each sweep launch zeroes it again)"""
         _check(lib().ffm_debug_set_sweep_ticket(self.h, int(value) & 0xFFFFFFFF), "ffm_debug_set_sweep_ticket")

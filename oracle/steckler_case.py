@@ -241,11 +241,15 @@ class StecklerCase:
         dt = adjust(min(1.2 * dt, 0.1))
         self.dt = dt; self.rdt = 1.0 / dt
 
-    def solve_smooth(self, name, d, up, lo, s, psi0, tol):
+    hook = None       # tests: hook(name, info) is called before every linear solve with the inputs of the equation's assembly
+
+    def solve_smooth(self, name, d, up, lo, s, psi0, tol, info=None):
         m = self.m
         A = O.Ldu(m.nCells, m.l, m.u).set_coeffs(d, up, lo)
         psi, perf = A.solve(O.SMOOTH, O.SYMGS, psi0, s, tolerance=tol, relTol=0.0, maxIter=10)
         self.log.append((name, perf))
+        if self.hook and info is not None:
+            self.hook(name, dict(info, kind="SMOOTH", psi0=psi0, tol=tol, relTol=0.0, maxIter=10, d=d, upper=up, lower=lo, s=s, psi=psi, perf=perf))
         return psi
 
     def bc_U(self):
@@ -312,7 +316,9 @@ class StecklerCase:
         for c in range(3):
             d, s = UEqn.solve_system(c)
             s = s + m.V * rec[:, c]
-            self.U[:, c] = self.solve_smooth("U" + "xyz"[c], d, UEqn.upper, UEqn.lower, s, self.U[:, c], 1e-6)
+            info = dict(rdt=rdt, coef=self.rho, phi=self.phi, phib=self.phib, w=wU, gamma_f=gamf, gamma_b=gamb, bc=bcU[c],
+                        source=UEqn.source[c] + m.V * rec[:, c], diag_extra=None)
+            self.U[:, c] = self.solve_smooth("U" + "xyz"[c], d, UEqn.upper, UEqn.lower, s, self.U[:, c], 1e-6, info)
         # U.correctBoundaryConditions()
         Ubc = [np.stack([bcU[c].values(m, self.U[:, c])[qq] for c in range(3)], axis=1) for qq in range(len(m.patches))]
         self.Ub = Ubc
@@ -382,7 +388,8 @@ class StecklerCase:
             E -= fv.fvm_laplacian(m, df, dEffb, [bc])
             E.add_su(self.rx.massCoeffs[i] * self.wFuel)            # combustion->R(Yi), semiImplicit no
             d, s = E.solve_system()
-            Yi = self.solve_smooth(n, d, E.upper, E.lower, s, self.Y[i], 1e-8)
+            info = dict(rdt=rdt, coef=self.rho, phi=self.phi, phib=self.phib, w=w, gamma_f=df, gamma_b=dEffb, bc=bc, source=E.source[0], diag_extra=None)
+            Yi = self.solve_smooth(n, d, E.upper, E.lower, s, self.Y[i], 1e-8, info)
             self.Y[i] = np.maximum(Yi, 0.0)
             self.Yb[i] = [np.maximum(b, 0.0) for b in bc.values(m, Yi)]
             Yt = Yt + self.Y[i]; Ytb = [a + b for a, b in zip(Ytb, self.Yb[i])]
@@ -442,7 +449,8 @@ class StecklerCase:
         E -= fv.fvm_laplacian(m, af, aEb, [bch])
         E.add_su(self.Qdot)
         d, s = E.solve_system()
-        self.he = self.solve_smooth("h", d, E.upper, E.lower, s, self.he, 1e-8)
+        info = dict(rdt=rdt, coef=self.rho, phi=self.phi, phib=self.phib, w=wh, gamma_f=af, gamma_b=aEb, bc=bch, source=E.source[0], diag_extra=None)
+        self.he = self.solve_smooth("h", d, E.upper, E.lower, s, self.he, 1e-8, info)
         self.heb = bch.values(m, self.he)
         self.thermo_correct()
         self.minmaxT = (min(self.T.min(), min(b.min() for b in self.Tb)), max(self.T.max(), max(b.max() for b in self.Tb)))
@@ -494,8 +502,13 @@ class StecklerCase:
         E -= fv.fvm_laplacian(m, rhorAUf, rhorAUfb, [bcp])
         d, s = E.solve_system()
         A_ = O.Ldu(m.nCells, m.l, m.u).set_coeffs(d, E.upper)
+        psi0 = self.p_rgh
         self.p_rgh, perf = A_.solve(O.PCG, O.DIC, self.p_rgh, s, tolerance=1e-6, relTol=0.0 if final else 0.01)
         self.log.append(("p_rgh", perf))
+        if self.hook:
+            self.hook("p_rgh", dict(kind="PCG", rdt=rdt, coef=self.psi, phi=None, phib=None, w=None, gamma_f=rhorAUf, gamma_b=rhorAUfb, bc=bcp,
+                                    source=E.source[0], diag_extra=None, psi0=psi0, tol=1e-6, relTol=0.0 if final else 0.01, maxIter=1000,
+                                    d=d, upper=E.upper, lower=E.lower, s=s, psi=self.p_rgh, perf=perf, matrix=E))
         self.p_rghb = bcp.values(m, self.p_rgh)
         fl, flb = E.flux(self.p_rgh)
         self.phi = phiHbyA + fl
@@ -550,14 +563,17 @@ class StecklerCase:
         sp = self.Ce * self.rho * np.sqrt(self.k) / self.delta
         E.diag += m.V * sp
         d, s = E.solve_system()
-        self.k = self.solve_smooth("k", d, E.upper, E.lower, s, self.k, 1e-8)
+        info = dict(rdt=rdt, coef=self.rho, phi=self.phi, phib=self.phib, w=w, gamma_f=Dkf, gamma_b=Dkb, bc=bck, source=E.source[0],
+                    diag_extra=m.V * np.maximum(ss, 0.0) + m.V * sp)
+        self.k = self.solve_smooth("k", d, E.upper, E.lower, s, self.k, 1e-8, info)
         self.kb = bck.values(m, self.k)
         self.k = np.maximum(self.k, SMALL)                   # bound(k, kMin): kMin = SMALL
         self.correct_nut()
 
 
-def first_step_records(with_h=True):
+def first_step_records(with_h=True, hook=None):
     c = StecklerCase()
+    c.hook = hook
     c.hydrostatic_init()
     c.correct_nut()                      # turbulence->validate()
     c.psi0, c.p0, c.p_rgh0, c.phi0 = c.psi.copy(), c.p.copy(), c.p_rgh.copy(), c.phi.copy()
