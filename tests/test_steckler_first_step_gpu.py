@@ -79,8 +79,14 @@ def test_first_time_step_solves_on_the_device(O, ffm, ctx, tiled):
     assert [n for n, _, _ in got] == [g["name"] for g in gold]
     for (name, perf, operf), g in zip(got, gold):
         assert perf["nIterations"] == g["nIterations"] == operf["nIterations"], (name, perf, g)
-        digits = 7 if name in ("Ux", "Uy", "Uz") else (8 if name in ("O2", "C3H8", "H2O", "CO2") else 5)
-        assert sig(perf["initialResidual"], digits) == sig(g["initialResidual"], digits), (name, perf, g)
+        if name in ("O2", "C3H8"):
+            # the golden 0.99999577 / 0.9999975 differ from 1 by the rounding error of OpenFOAM's SERIAL gAverage of a uniform field
+            # (normFactor's xRef; 9000 equal addends): the oracle's serial C sum reproduces all 8 digits (CPU test), the device's
+            # two-stage tree sum is more accurate and gives 1 - 4e-9 -- agreement to 1e-5 is what a different summation order allows
+            assert abs(perf["initialResidual"] - g["initialResidual"]) < 1e-5, (name, perf, g)
+        else:
+            digits = 7 if name in ("Ux", "Uy", "Uz") else (8 if name in ("H2O", "CO2") else 5)
+            assert sig(perf["initialResidual"], digits) == sig(g["initialResidual"], digits), (name, perf, g)
         if name in ("Ux", "Uy", "Uz", "h", "p_rgh", "H2O", "CO2"):
             assert abs(perf["finalResidual"] - g["finalResidual"]) <= 2e-5 * g["finalResidual"] + 0.0, (name, perf, g)
         # and the device solve follows the oracle's (whose numbers for O2 / C3H8 / k are discussed in the CPU test)
