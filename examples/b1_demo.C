@@ -311,3 +311,56 @@ extern "C" int b1_dict_lookup(const char* path, const char* keyPath, char* out, 
     std::strncpy(out, res.c_str(), cap - 1); out[cap - 1] = 0;
     return (int)res.size();
 }
+
+// ---- the two burner patch conditions of cases/steckler: flowRateInletVelocity (0/U:40-54) and
+// totalFlowRateAdvectiveDiffusive (0/C3H8:44-50), on the device through the Foam layer.  Host arrays [B]: maskB = 1 on the
+// burner faces; rhoB, alphaEffB, phiB = the patch values those conditions look up; t = the time the mass-flow table is read
+// at; table = nTable (time, value) pairs.  Cell arrays [N]: Uc[3][N], Yc[N].  Returns the patch values the two fields take
+// after correctBoundaryConditions(): UbOut[3][B], YbOut[B], and the value fraction of the specie condition fOut[B].
+extern "C" int b1_burner_bcs(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, double t, int nTable, const double* table,
+                             double massFluxFraction, const double* maskB, const double* rhoB, const double* alphaEffB,
+                             const double* phiF, const double* phiB, const double* Uc, const double* Yc,
+                             double* UbOut, double* YbOut, double* fOut)
+{
+    fvMesh mesh(ctx, ldu, msh, 1e-3);
+    Time runTime(t, 1e-3);
+    runTime.link(mesh.deltaT, mesh.timeValue);
+    const label N = mesh.nCells, B = mesh.nBoundary;
+    volScalarField rho("rho", mesh); rho.b.assignHost(rhoB);
+    volScalarField alphaEff("alphaEff", mesh); alphaEff.b.assignHost(alphaEffB);
+    const surfaceScalarField phi(surfaceFromHost(mesh, phiF, phiB));
+    mesh.store("rho", rho); mesh.store("alphaEff", alphaEff); mesh.store("phi", phi);
+    std::vector<double> zero(B, 0.0), one(B, 1.0), fU(B), refY(B);
+    auto mask = std::make_shared<dField>(ctx, B); mask->assignHost(maskB);
+    // U: fixed value everywhere (f = 1, ref = 0); on the burner the flow-rate condition supplies the value
+    volVectorField U("U", mesh);
+    Function1Table mdot;
+    for (int i = 0; i < nTable; i++) mdot.xy.push_back({table[2*i], table[2*i + 1]});
+    for (int d = 0; d < 3; d++) {
+        U.v[d].assignHost(Uc + (size_t)d*N);
+        U.bc[d] = makeBC(mesh, one.data(), zero.data(), zero.data());
+        U.bc[d]->flowRateMask = mask; U.bc[d]->massFlowRate = mdot;
+        // patch().nf() component = Sf_d/magSf
+        U.bc[d]->flowRateNf = std::make_shared<dField>(binary(FFM_OP_DIV, mesh.boundaryGeometry(6 + d), mesh.boundaryGeometry(4)));
+    }
+    U.correctBoundaryConditions();
+    for (int d = 0; d < 3; d++) U.b[d].toHost(UbOut + (size_t)d*B);
+    // specie: zeroGradient everywhere, totalFlowRateAdvectiveDiffusive on the burner
+    volScalarField Y("Yi", mesh); Y.v.assignHost(Yc);
+    for (label k = 0; k < B; k++) refY[k] = maskB[k] > 0.5 ? massFluxFraction : 0.0;
+    Y.bc = makeBC(mesh, zero.data(), refY.data(), zero.data());
+    Y.bc->tfradMask = mask;
+    Y.correctBoundaryConditions();
+    Y.b.toHost(YbOut); Y.bc->f.toHost(fOut);
+    return 0;
+}
+
+// the Function1 entry `key` of patch `patch` in a field file as (x, y) pairs, and the patch's massFluxFraction
+extern "C" int b1_read_function1(const char* path, const char* patch, const char* key, double* xy, int cap, double* massFluxFraction)
+{
+    const fieldFile ff(path);
+    int n = 0;
+    if (key && key[0]) for (const auto& p : ff.function1(patch, key)) { if (2*n + 1 < cap) { xy[2*n] = p.first; xy[2*n + 1] = p.second; } n++; }
+    if (massFluxFraction) *massFluxFraction = ff.massFluxFraction(patch);
+    return n;
+}

@@ -124,3 +124,18 @@ def test_case_constants_of_the_oracle_come_from_the_reference_files():
     assert float(look("constant/thermo.compressibleGas", "N2/specie/molWeight")) == 28.0134
     assert look("system/fvSolution", "solvers/UFinal/smoother") == "symGaussSeidel"      # through the pattern "U.*"
     assert look("system/fvSchemes", "divSchemes/div(Ji,Ii_h)") == "Gauss upwind"
+
+
+def test_burner_patch_entries_of_the_steckler_case():
+    """the two burner conditions' parameters read from the reference's own field files -- the mass-flow
+    table of flowRateInletVelocity (cases/steckler/0/U:40-54: 0.03 kg/s at 0, 60, 100 s) and the massFluxFraction of
+    totalFlowRateAdvectiveDiffusive (1 for the fuel, 0 for the other species: 0/C3H8:44-50, 0/O2, 0/Ydefault)"""
+    lib, _ = _lib()
+    lib.b1_read_function1.restype = C.c_int
+    lib.b1_read_function1.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+    xy = np.zeros(16); mff = C.c_double()
+    n = lib.b1_read_function1(os.path.join(REF, "steckler", "0", "U").encode(), b"burner", b"massFlowRate", xy.ctypes.data_as(C.POINTER(C.c_double)), 16, None)
+    assert n == 3 and xy[:6].tolist() == [0.0, 0.03, 60.0, 0.03, 100.0, 0.03]
+    for name, want in (("C3H8", 1.0), ("O2", 0.0), ("Ydefault", 0.0), ("N2", 0.0)):
+        lib.b1_read_function1(os.path.join(REF, "steckler", "0", name).encode(), b"burner", b"", None, 0, C.byref(mff))
+        assert mff.value == want, name

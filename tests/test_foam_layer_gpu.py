@@ -163,3 +163,52 @@ def test_b1_demo_matches_oracle(O, ffm, ctx):
     for c in range(3):
         assert rel_l2(back(out["Uc"])[c], Ucorr_ref[c]) < 1e-8
     mesh.close(); A.close()
+
+
+def test_burner_patch_conditions_on_the_device(O, ffm, ctx):
+    """flowRateInletVelocity (cases/steckler/0/U:40-54) and totalFlowRateAdvectiveDiffusive
+    (cases/steckler/0/C3H8:44-50) of the Foam layer (include/ffmFoam.H: mixedBC::update) against the formulas the oracle's
+    steckler case uses -- the ones that reproduce the golden log's first time step (oracle/steckler_case.py:
+    update_burner_velocity, bc_specie): U_b = -mdot(t)/sum(rho_b*magSf) * nf on the burner faces, the other faces untouched;
+    value fraction 1/(1 + alphaEff_b*deltaCoeffs*magSf/max(|phi_b|, SMALL)), refValue = massFluxFraction."""
+    from oracle import plume
+    m = plume.make_mesh((9, 8, 7), h=0.1)
+    N, F = m.nCells, m.nFaces
+    B = sum(p.size for p in m.patches)
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    dp = C.POINTER(C.c_double)
+    lib.b1_burner_bcs.restype = C.c_int
+    lib.b1_burner_bcs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, dp, C.c_double] + [dp] * 10
+    hu = lambda seed, n: O.hash_u(seed, np.arange(n))
+    cat = np.concatenate
+    mask = cat([np.full(p.size, 1.0 if p.name == "inlet" else 0.0) for p in m.patches])
+    rhob = 1.0 + hu(1, B); alphab = 2e-4 * (1 + hu(2, B))
+    phib = 0.02 * (hu(3, B) - 0.5); phib[::3] = 0.0                       # some faces without flux: max(|phi|, SMALL)
+    phi = 0.02 * (hu(4, F) - 0.5)
+    Uc = np.stack([hu(20 + d, N) - 0.5 for d in range(3)]); Yc = hu(30, N)
+    table = np.array([0.0, 0.01, 10.0, 0.03, 20.0, 0.03])                  # 0.01 -> 0.03 kg/s over 10 s, read at t = 4 s
+    t, mff = 4.0, 0.7
+    Ub = np.zeros((3, B)); Yb = np.zeros(B); fo = np.zeros(B)
+    P = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(dp)
+    ctx.sync()
+    rc = lib.b1_burner_bcs(ctx.h, A.h, mesh.h, t, 3, P(table), mff, P(mask), P(rhob), P(alphab), P(phi[fOrd]), P(phib),
+                           P(np.ascontiguousarray(Uc[:, cOrd])), P(Yc[cOrd]), P(Ub), P(Yb), P(fo))
+    assert rc == 0
+    magSf = cat([p.magSf for p in m.patches]); Sf = cat([p.Sf for p in m.patches]); delta = cat([p.deltaCoeffs for p in m.patches])
+    fc = cat([p.faceCells for p in m.patches])
+    mdot = 0.01 + 0.02 * t / 10.0
+    avgU = -mdot / np.sum((rhob * magSf)[mask > 0.5])
+    for d in range(3):
+        want = np.where(mask > 0.5, avgU * (Sf[:, d] / magSf), 0.0)        # fixed value 0 elsewhere
+        assert np.allclose(Ub[d], want, rtol=1e-14, atol=1e-300), d
+    assert Ub[1][mask > 0.5].min() > 0                                       # inflow: against the outward normal (0 -1 0)
+    f = np.where(mask > 0.5, 1.0 / (1.0 + alphab * delta * magSf / np.maximum(np.abs(phib), 1e-15)), 0.0)
+    assert np.allclose(fo, f, rtol=1e-14, atol=0)
+    assert np.allclose(Yb, f * mff + (1.0 - f) * Yc[fc], rtol=1e-14, atol=0)
+    assert np.any((mask > 0.5) & (phib == 0.0)) and np.all(fo[(mask > 0.5) & (phib == 0.0)] < 1e-8)   # no flux: zero-gradient
+    mesh.close(); A.close()
