@@ -143,6 +143,7 @@ def lib():
         "ffm_fvc_snGrad_correction": ([vp, dp, dp, dp, dp], C.c_int),
         "ffm_fv_linear_upwind_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fvm_relax": ([vp, C.c_double, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fv_filtered_linear2V_weights": ([vp, C.c_double, C.c_double, dp] + [C.POINTER(C.c_void_p)] * 4 + [dp], C.c_int),
         "ffm_fvc_grad_multi": ([vp, C.c_int] + [C.POINTER(C.c_void_p)] * 5, C.c_int),
         "ffm_fvm_scalar_transport_multi": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
                                            + [C.POINTER(C.c_void_p)] * 14, C.c_int),

@@ -258,6 +258,40 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
     }
 }
 
+// filteredLinear2V k l (cases/wallFireSpread2D/system/fvSchemes:41, `div(phi,U)`): one limiter per face for the three components of
+// a vector field, from the face difference of the vector and twice the two cells' gradients projected on it
+// (filteredLinear2VLimiter<NVDVTVDV>::limiter; oracle/fv.py: filtered_linear2V_weights)
+struct FL2V { const double *U[3], *gx[3], *gy[3], *gz[3]; };
+__global__ void k_filtered_linear2V_weights(MeshView q, double kk, double l1, const double *__restrict__ phi, FL2V a,
+                                            const double *__restrict__ Cx, const double *__restrict__ Cy, const double *__restrict__ Cz,
+                                            double *__restrict__ out)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        const double P0 = a.U[0][c], P1 = a.U[1][c], P2 = a.U[2][c];
+        FOR_OWN_FACES(q, c, e, nb) {
+            const double g0 = a.U[0][nb] - P0, g1 = a.U[1][nb] - P1, g2 = a.U[2][nb] - P2;      // gradfV
+            const double df = (g0 * g0 + g1 * g1) + g2 * g2;
+            const double dx = Cx[nb] - Cx[c], dy = Cy[nb] - Cy[c], dz = Cz[nb] - Cz[c];
+            double tc[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const int cc = s ? nb : c;
+                const double d0 = (dx * a.gx[0][cc] + dy * a.gy[0][cc]) + dz * a.gz[0][cc];
+                const double d1 = (dx * a.gx[1][cc] + dy * a.gy[1][cc]) + dz * a.gz[1][cc];
+                const double d2 = (dx * a.gx[2][cc] + dy * a.gy[2][cc]) + dz * a.gz[2][cc];
+                tc[s] = 2.0 * ((g0 * d0 + g1 * d1) + g2 * d2);
+            }
+            const double den = fmax(fabs(tc[0]), fabs(tc[1])) + 1.0e-15;
+            double lim = (df > 0) ? l1 - kk * fmin(fmax(df - tc[0], 0.0), fmax(df - tc[1], 0.0)) / den
+                                  : l1 - kk * fmin(fmax(tc[0] - df, 0.0), fmax(tc[1] - df, 0.0)) / den;
+            lim = fmax(fmin(lim, 1.0), 0.0);
+            const double p0 = phi[e] >= 0 ? 1.0 : 0.0;
+            out[e] = lim * q.w[e] + (1.0 - lim) * p0;
+        }
+    }
+}
+
 // LUST<Type>::correction = 0.25 * linearUpwind<Type>::correction: (Cf - C_c) & grad(vf)_c, c = owner if the flux is > 0, else
 // the neighbour (one scalar component; zero on non-coupled patches, which is what the boundary part of the caller holds)
 __global__ void k_lust_correction(MeshView q, const double *__restrict__ phi, const double *__restrict__ gx, const double *__restrict__ gy,
@@ -577,6 +611,19 @@ extern "C" int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double 
     CHECK_M(m);
     if (scheme < 0 || scheme > 5 || !phi_f || !out_w || ((scheme == 2 || scheme == 3) && (!vf || !gx || !gy || !gz))) return FFM_ERR_ARG;
     LAUNCH_CELLS(k_limited_weights, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], out_w);
+    DONE();
+}
+extern "C" int ffm_fv_filtered_linear2V_weights(ffm_mesh *m, double k, double l, const double *phi_f, const double *const *U,
+                                                const double *const *gx, const double *const *gy, const double *const *gz, double *out_w)
+{
+    CHECK_M(m);
+    if (!phi_f || !U || !gx || !gy || !gz || !out_w || k < 0 || k > 1 || l < 0 || l > 1) return FFM_ERR_ARG;
+    FL2V a;
+    for (int d = 0; d < 3; d++) {
+        if (!U[d] || !gx[d] || !gy[d] || !gz[d]) return FFM_ERR_ARG;
+        a.U[d] = U[d]; a.gx[d] = gx[d]; a.gy[d] = gy[d]; a.gz[d] = gz[d];
+    }
+    LAUNCH_CELLS(k_filtered_linear2V_weights, mview(m), k, l + 1.0, phi_f, a, m->C[0], m->C[1], m->C[2], out_w);
     DONE();
 }
 extern "C" int ffm_mesh_set_face_centres(ffm_mesh *m, const double *Cf)

@@ -273,6 +273,12 @@ int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double 
                            const double *phi_f, const double *vf, const double *gx,
                            const double *gy, const double *gz, double *out_w_f);
 
+/* filteredLinear2V k l: the face weights of a VECTOR field, one limiter per face for its three components
+ * (`div(phi,U) Gauss filteredLinear2V 0.2 0.05`, cases/wallFireSpread2D/system/fvSchemes:41, cases/pyrolysis1D/system/fvSchemes:39;
+ * solver/UEqn.H:5).  U[3], gx[3], gy[3], gz[3]: host arrays of device pointers, g?[c] = the gradient of component c.        */
+int ffm_fv_filtered_linear2V_weights(ffm_mesh *m, double k, double l, const double *phi_f, const double *const *U,
+                                     const double *const *gx, const double *const *gy, const double *const *gz, double *out_w_f);
+
 /* LUST<Type>::correction(vf) for one scalar component, internal faces: 0.25*(Cf - C_c) & grad(vf)_c with c the upwind cell
  * (`div(phi,U) Gauss LUST grad(U)`, cases/steckler/system/fvSchemes:32; solver/UEqn.H:5).  gaussConvectionScheme::fvmDiv
  * then adds fvc::surfaceIntegrate(phi*correction) to the matrix: source -= V * ffm_fvc_surface_integrate(phi_f*corr_f, 0). */

@@ -304,6 +304,34 @@ def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
     return lim * w + (1.0 - lim) * pos0(phi)
 
 
+def filtered_linear2V_weights(mesh, phi, U, gradU, k, l):
+    """filteredLinear2V k l for a vector field (cases/wallFireSpread2D/system/fvSchemes:41 `div(phi,U) Gauss filteredLinear2V
+    0.2 0.05`; OpenFOAM-dev .../limitedSchemes/filteredLinear2/filteredLinear2V.H, LimitedScheme<vector, ..., null>): ONE limiter per
+    face for all components, from the face difference of the vector and twice the cell gradients projected on it,
+        gradfV = U_N - U_P;  df = gradfV & gradfV;  tcP = 2*(gradfV & (d & gradU_P));  tcN = 2*(gradfV & (d & gradU_N))
+        limiter = (l+1) - k*min(max(df - tcP, 0), max(df - tcN, 0))/(max(|tcP|, |tcN|) + SMALL)      (df > 0)
+                = (l+1) - k*min(max(tcP - df, 0), max(tcN - df, 0))/(max(|tcP|, |tcN|) + SMALL)      (otherwise)
+        limiter = max(min(limiter, 1), 0);  weight = limiter*w_linear + (1 - limiter)*pos0(phi)
+    U[nCells][3]; gradU[nCells][3][3] with gradU[c][i][j] = d_i U_j (fvc::grad(U)); d = C_N - C_P.  The upstream source is not
+    in the reference tree: 'parity unpinned' by reference data (no golden log of the two cases that select it exists)."""
+    SMALL = 1.0e-15
+    l1 = l + 1.0
+    gradfV = U[mesh.u] - U[mesh.l]
+    df = (gradfV[:, 0] * gradfV[:, 0] + gradfV[:, 1] * gradfV[:, 1]) + gradfV[:, 2] * gradfV[:, 2]
+    d = mesh.C[mesh.u] - mesh.C[mesh.l]
+
+    def tc(g):                                       # 2*(gradfV & (d & g)),  (d & g)_j = d_x g_xj + d_y g_yj + d_z g_zj
+        dg = [(d[:, 0] * g[:, 0, j] + d[:, 1] * g[:, 1, j]) + d[:, 2] * g[:, 2, j] for j in range(3)]
+        return 2.0 * ((gradfV[:, 0] * dg[0] + gradfV[:, 1] * dg[1]) + gradfV[:, 2] * dg[2])
+    tcP, tcN = tc(gradU[mesh.l]), tc(gradU[mesh.u])
+    den = np.maximum(np.abs(tcP), np.abs(tcN)) + SMALL
+    lim = np.where(df > 0,
+                   l1 - k * np.minimum(np.maximum(df - tcP, 0.0), np.maximum(df - tcN, 0.0)) / den,
+                   l1 - k * np.minimum(np.maximum(tcP - df, 0.0), np.maximum(tcN - df, 0.0)) / den)
+    lim = np.maximum(np.minimum(lim, 1.0), 0.0)
+    return lim * mesh.weights + (1.0 - lim) * pos0(phi)
+
+
 def lust_weights(mesh, phi):
     """LUST<Type>::weights (OpenFOAM-dev src/finiteVolume/interpolation/surfaceInterpolation/schemes/LUST/LUST.H):
     0.75*linear weights + 0.25*upwind weights; reference selection cases/steckler/system/fvSchemes:32."""

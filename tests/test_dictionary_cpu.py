@@ -65,7 +65,7 @@ def test_steckler_dictionaries():
 def test_wallFireSpread2D_dictionaries():
     out, _ = _read("wallFireSpread2D", ["p_rgh", "U", "Yi"], ["div(phi,U)"], [])
     assert out[0] in (IDS["PCG"], -1)                     # PCG or GAMG depending on the case variant
-    assert out[6 * 3 + 6] == -1                           # div(phi,U) Gauss filteredLinear2V 0.2 0.05: known, not built
+    assert tuple(out[6 * 3 + 6:6 * 3 + 8]) == (6, 0.2)    # div(phi,U) Gauss filteredLinear2V 0.2 0.05: scheme 6, k = 0.2
     assert out[-3] == 1 and out[-2] == 1                  # Gauss linear corrected / corrected
     assert abs(out[-1] - 0.9) < 1e-12 or out[-1] == 1 or out[-1] == -1      # relaxationFactors::equations (0.9 in this case)
 

@@ -132,6 +132,29 @@ def test_limited_weights_piecewise_constant(setup, O, ctx, scheme, code):
     assert flat.sum() > 0 and np.all(got[flat] == m.weights[flat])
 
 
+def test_filteredLinear2V_weights(setup, O, ctx):
+    """the vector limiter of cases/wallFireSpread2D/system/fvSchemes:41 on the device against oracle/fv.py (hand-computed stencils:
+    tests/test_oracle_cpu.py::test_filteredLinear2V_unit_stencils); smooth and rough fields so that all three outcomes
+    (limiter 1, blended, 0) occur"""
+    s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
+    N, F = s["N"], s["F"]
+    _, phi, _ = fields(s, O)
+    for rough in (0.05, 1.0):
+        U = np.stack([np.sin(1.3 * m.C[:, 0] + d) * np.cos(0.7 * m.C[:, 1] - d) + rough * (O.hash_u(70 + d, np.arange(N)) - 0.5) for d in range(3)], axis=1)
+        Ub = [[0.5 * U[p.faceCells, d] for p in m.patches] for d in range(3)]
+        g = np.stack([fv.grad(m, U[:, d], Ub[d]) for d in range(3)], axis=2)              # g[c][i][j] = d_i U_j
+        ref = fv.filtered_linear2V_weights(m, phi, U, g, 0.2, 0.05)
+        w = ctx.zeros(mesh.nNative)
+        Ud = [cellf(s, ctx, U[:, d]) for d in range(3)]
+        gd = [[cellf(s, ctx, g[:, i, d]) for d in range(3)] for i in range(3)]           # gd[i][d] = d_i U_d
+        mesh.call("fv_filtered_linear2V_weights", 0.2, 0.05, facef(s, phi), Ud, gd[0], gd[1], gd[2], w)
+        got = back_face(s, w)
+        assert np.abs(got - ref).max() < 1e-13
+        lim = np.where(phi >= 0, (1.0 - got) / 0.5, got / 0.5)                             # (1-lim) share of upwind: 1 - lim
+        assert got.min() >= 0.0 and got.max() <= 1.0
+    assert (np.abs(got - 0.5) < 1e-15).any() and (np.abs(got - fv.pos0(phi)) < 1e-15).any()   # rough field: both ends of the limiter
+
+
 def test_fvm_assembly_and_matrix_ops(setup, O, ctx):
     s, fv, m, mesh = setup, setup["fv"], setup["m"], setup["mesh"]
     N, F, B = s["N"], s["F"], s["B"]

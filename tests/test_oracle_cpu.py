@@ -163,3 +163,38 @@ def test_limiter_uniform_zones_are_linear(O):
     g2 = np.zeros((6, 3)); g2[:, 0] = -0.1
     w = fv.limited_weights(m, "limitedLinear", np.ones(5), vf, g2, 1.0)
     assert w[0] == 1.0                                          # gradf = 0, gradcf < 0: r = 2000*(-1)(+1) - 1 < 0 -> upwind
+
+
+def test_filteredLinear2V_unit_stencils(O):
+    """filteredLinear2V k l (cases/wallFireSpread2D/system/fvSchemes:41: 0.2 0.05), hand-computed on a 1-D row of cells, h = 1:
+    * a linear profile U_x = a x: df = a^2, tcP = tcN = 2 a^2 -> nothing to limit, limiter = min(1 + l, 1) = 1: linear weights;
+    * a uniform field: df = tc = 0 -> limiter = l + 1 - k*0/(0 + SMALL) -> 1: linear weights;
+    * a kink: cell gradients (centred) smaller than the face difference -> limiter = 1 + l - k*min(df - tcP, df - tcN)/max|tc|,
+      weights blended towards upwind accordingly; the limiter does not depend on the flux direction, the upwind weight does"""
+    from oracle import fv
+    m = fv.HexMesh((5, 1, 1), (0, 0, 0), (5, 1, 1)).set_patches([])
+    U = np.zeros((5, 3)); g = np.zeros((5, 3, 3))
+    U[:, 0] = 2.0 * np.arange(5); g[:, 0, 0] = 2.0
+    w = fv.filtered_linear2V_weights(m, np.ones(4), U, g, 0.2, 0.05)
+    assert np.array_equal(w, np.full(4, 0.5))
+    w = fv.filtered_linear2V_weights(m, -np.ones(4), np.ones((5, 3)), np.zeros((5, 3, 3)), 0.2, 0.05)
+    assert np.array_equal(w, np.full(4, 0.5))
+    # kink in U_y along x: values 0 0 1 1 1, centred gradients d_x U_y = 0 0.5 0.5 0 0
+    U = np.zeros((5, 3)); U[:, 1] = [0, 0, 1, 1, 1]
+    g = np.zeros((5, 3, 3)); g[:, 0, 1] = [0, 0.5, 0.5, 0, 0]
+    w = fv.filtered_linear2V_weights(m, np.ones(4), U, g, 0.2, 0.05)
+    # face 1|2: gradfV = (0,1,0), df = 1, tcP = tcN = 2*1*0.5 = 1 -> df - tc = 0 -> limiter 1 -> linear
+    assert w[1] == 0.5
+    # strengthen the kink: gradients 0.2 -> tc = 0.4, df - tc = 0.6 -> limiter = 1.05 - 0.2*0.6/0.4 = 0.75
+    g[:, 0, 1] = [0, 0.2, 0.2, 0, 0]
+    w = fv.filtered_linear2V_weights(m, np.ones(4), U, g, 0.2, 0.05)
+    lim = 1.05 - 0.2 * 0.6 / (0.4 + 1e-15)
+    assert abs(w[1] - (lim * 0.5 + (1 - lim) * 1.0)) < 1e-15
+    w2 = fv.filtered_linear2V_weights(m, -np.ones(4), U, g, 0.2, 0.05)
+    assert abs(w2[1] - (lim * 0.5 + (1 - lim) * 0.0)) < 1e-15
+    # the other components' differences enter the same limiter (one limiter per face for the vector)
+    U[:, 2] = [0, 0, 3, 3, 3]
+    w3 = fv.filtered_linear2V_weights(m, np.ones(4), U, g, 0.2, 0.05)
+    df = 1 + 9; tc = 0.4
+    lim3 = max(min(1.05 - 0.2 * (df - tc) / (tc + 1e-15), 1.0), 0.0)
+    assert lim3 == 0.0 and w3[1] == 1.0                   # a large unresolved jump: fully upwind
