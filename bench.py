@@ -86,13 +86,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             if int(t.item()) == 0:
                 transport = "host"
-                sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
-                import gloo_comm
+                gloo_comm = ffm.gloo_comm
                 gloo_comm.GROUP = dist.new_group(backend="gloo")
                 ctx.comm_init_host(rank, world, gloo_comm.allreduce, gloo_comm.exchange)
         else:
-            sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
-            import gloo_comm
+            gloo_comm = ffm.gloo_comm
             ctx.comm_init_host(rank, world, gloo_comm.allreduce, gloo_comm.exchange)
         grid = ffm.hexmesh.grid_for(world)
         lo, hi, nbr = ffm.hexmesh.block_of_rank((n, n, n), grid, rank)

@@ -12,3 +12,5 @@ from .binding import (  # noqa: F401
     renumber_levels, exported_symbols, declared_symbols, Plume, fvMesh,
 )
 from . import hexmesh  # noqa: F401
+from . import decompose  # noqa: F401
+from . import gloo_comm  # noqa: F401  (host transport over torch.distributed/gloo: several ranks on one GPU, CPU rehearsals)

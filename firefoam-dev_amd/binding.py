@@ -132,6 +132,15 @@ def lib():
         "ffm_mesh_destroy": ([vp], C.c_int),
         "ffm_mesh_set_face_centres": ([vp, hp], C.c_int),
         "ffm_mesh_set_nonorth_correction": ([vp, hp], C.c_int),
+        "ffm_partition_rcb": ([C.c_int, hp, C.c_int, ip], C.c_int),
+        "ffm_partition_graph": ([C.c_int, C.c_int, ip, ip, C.c_int, ip], C.c_int),
+        "ffm_subdomain_create": ([C.c_int, C.c_int, ip, ip, ip, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
+        "ffm_subdomain_destroy": ([vp], C.c_int),
+        "ffm_subdomain_sizes": ([vp] + [C.POINTER(C.c_int)] * 6, C.c_int),
+        "ffm_subdomain_cells": ([vp, ip], C.c_int),
+        "ffm_subdomain_faces": ([vp, ip, ip, ip, ip], C.c_int),
+        "ffm_subdomain_exchange": ([vp, ip, ip, ip, ip, ip], C.c_int),
+        "ffm_subdomain_cut_faces": ([vp, ip, ip, ip, ip], C.c_int),
         "ffm_polymesh_read": ([C.c_char_p, C.POINTER(vp)], C.c_int),
         "ffm_polymesh_destroy": ([vp], C.c_int),
         "ffm_polymesh_sizes": ([vp] + [C.POINTER(C.c_int)] * 5, C.c_int),
@@ -339,18 +348,33 @@ class Context:
 class lduMatrix:
     """Device lduMatrix over lduAddressing (lowerAddr, upperAddr)."""
 
-    def __init__(self, ctx, nCells, lowerAddr, upperAddr, groupHint=None):
+    def __init__(self, ctx, nCells, lowerAddr, upperAddr, groupHint=None, nGhost=0):
+        """nGhost > 0: one rank of a decomposed case (ffm_ldu_create_ext): nCells owned cells followed by nGhost ghost cells;
+        cell fields then have nCells + nGhost entries"""
         self.ctx = ctx
         l = np.ascontiguousarray(lowerAddr, np.int32)
         u = np.ascontiguousarray(upperAddr, np.int32)
         h = C.c_void_p()
-        if groupHint is None:
+        if groupHint is None and not nGhost:
             _check(lib().ffm_ldu_create(ctx.h, int(nCells), len(l), _ip(l), _ip(u), C.byref(h)), "ffm_ldu_create")
         else:
-            gh = np.ascontiguousarray(groupHint, np.int32)
-            _check(lib().ffm_ldu_create_hint(ctx.h, int(nCells), 0, len(l), _ip(l), _ip(u), _ip(gh), C.byref(h)), "ffm_ldu_create_hint")
+            gh = None if groupHint is None else np.ascontiguousarray(groupHint, np.int32)
+            _check(lib().ffm_ldu_create_hint(ctx.h, int(nCells), int(nGhost), len(l), _ip(l), _ip(u), None if gh is None else _ip(gh), C.byref(h)),
+                   "ffm_ldu_create_hint")
         self.h = h
-        self.nCells, self.nFaces = int(nCells), len(l)
+        self.nOwned = int(nCells)
+        self.nCells, self.nFaces = int(nCells) + int(nGhost), len(l)
+
+    def set_ghost_exchange(self, nbrRank, sendCount, sendCells, recvCount, tags=None, globalCells=None):
+        """ffm_ldu_set_ghost_exchange (+ pair tags, + the global cell count for gAverage): see firefoam-dev_amd/decompose.py"""
+        a = [np.ascontiguousarray(x, np.int32) for x in (nbrRank, sendCount, sendCells, recvCount)]
+        _check(lib().ffm_ldu_set_ghost_exchange(self.h, len(a[0]), _ip(a[0]), _ip(a[1]), _ip(a[2]), _ip(a[3])), "ffm_ldu_set_ghost_exchange")
+        if tags is not None:
+            t = np.ascontiguousarray(tags, np.int32)
+            _check(lib().ffm_ldu_set_exchange_tags(self.h, 1, len(t), _ip(t)), "ffm_ldu_set_exchange_tags")
+        if globalCells is not None:
+            _check(lib().ffm_ldu_set_global_cells(self.h, int(globalCells)), "ffm_ldu_set_global_cells")
+        return self
 
     def close(self):
         if getattr(self, "h", None):

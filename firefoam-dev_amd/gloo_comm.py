@@ -1,18 +1,24 @@
-"""Host-side communicator over torch.distributed (gloo) for the multi-rank tests: implements the
-callbacks of ffm_comm_init_host / the oracle's ffo_comm with CPU tensors."""
+"""Host-side communicator over torch.distributed (gloo): the callbacks of ffm_comm_init_host (several ranks sharing one GPU,
+the fall-back transport of bench.py when no RCCL communicator can be made) and of the oracle's ffo_comm, on CPU tensors."""
 import numpy as np
-import torch
-import torch.distributed as dist
 
 
 GROUP = None        # process group to use (None: the default group); bench.py sets a gloo group here when it falls back from RCCL
 
 
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
 def init(rank, world, port):
+    dist = _dist()
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
 
 
 def allreduce(vals, op=0):
+    import torch
+    dist = _dist()
     t = torch.from_numpy(np.array(vals, dtype=np.float64, copy=True))
     dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[op], group=GROUP)
     vals[:] = t.numpy()
@@ -20,7 +26,8 @@ def allreduce(vals, op=0):
 
 def exchange(sizes, ranks, offs, send, recv):
     """pairwise exchange, equal counts: lower rank sends first to avoid head-of-line deadlock with blocking ops"""
-    me = dist.get_rank()
+    import torch
+    dist = _dist()
     reqs, bufs = [], []
     for n, r, o in zip(sizes, ranks, offs):
         if n == 0:

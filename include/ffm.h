@@ -421,6 +421,30 @@ int ffm_debug_tile_trace(ffm_ldu *A, unsigned long long *out, int nWords);
  * close to 2^32 must not change any result)                                                                             */
 int ffm_debug_set_sweep_ticket(ffm_ldu *A, unsigned int value);
 
+/* ------------------------------------------------------- decomposition (host) */
+/* decomposePar's job for this path (reference: scotch, cases/steckler/system/decomposeParDict:18-20; `simple`,
+ * cases/wallFireSpread2D/system/decomposeParDict:18-27; BASELINE names METIS -- none of the three libraries is in this image).
+ * part[nCells] = sub-domain of every cell:
+ *   ffm_partition_rcb    recursive coordinate bisection of the cell centres C[3][nCells], any number of parts
+ *   ffm_partition_graph  greedy graph growing on the LDU graph (no geometry needed)                                        */
+int ffm_partition_rcb(int nCells, const double *C, int nParts, int *part);
+int ffm_partition_graph(int nCells, int nFaces, const int *lowerAddr, const int *upperAddr, int nParts, int *part);
+/* The sub-domain of `rank` in the ghost-cell form of ffm_ldu_create_ext: owned cells in their global relative order, then the
+ * ghost cells grouped by neighbour rank (ascending global label inside a group); faces in upper-triangular order, a cut face
+ * owned by its owned cell and flagged `flip` where the global owner is the ghost (its local upper coefficient is the global
+ * lower one).  ffm_subdomain_exchange gives the arguments of ffm_ldu_set_ghost_exchange and the pair tags of
+ * ffm_ldu_set_exchange_tags (kind 1); ffm_subdomain_cut_faces lists the cut faces per neighbour in ascending global face
+ * label -- the processor-patch form (faceCells per patch, same order on both sides) for ffm_ldu_set_interfaces.           */
+typedef struct ffm_subdomain ffm_subdomain;
+int ffm_subdomain_create(int nCells, int nFaces, const int *lowerAddr, const int *upperAddr, const int *part, int nParts,
+                         int rank, ffm_subdomain **out);
+int ffm_subdomain_destroy(ffm_subdomain *s);
+int ffm_subdomain_sizes(const ffm_subdomain *s, int *nOwned, int *nGhost, int *nFaces, int *nNbr, int *nSend, int *nCut);
+int ffm_subdomain_cells(const ffm_subdomain *s, int *globalCell /* [nOwned+nGhost] */);
+int ffm_subdomain_faces(const ffm_subdomain *s, int *lowerAddr, int *upperAddr, int *globalFace, int *flip);
+int ffm_subdomain_exchange(const ffm_subdomain *s, int *nbrRank, int *sendCount, int *sendCells, int *recvCount, int *tags);
+int ffm_subdomain_cut_faces(const ffm_subdomain *s, int *cutStart /* [nNbr+1] */, int *localCell, int *globalFace, int *flip);
+
 /* ------------------------------------------------------- polyMesh (host)    */
 /* SURVEY 8(f) N4, first part: OpenFOAM's on-disk mesh (ascii constant/polyMesh/{points,faces,owner,neighbour,boundary}, as
  * blockMesh / topoSet / createBaffles leave it: reference cases/steckler/mesh.sh:8-21) and the finite-volume geometry

@@ -10,9 +10,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import gloo_comm  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from ffm_import import ffm  # noqa: E402   (host-side decomposition tooling only; no GPU is touched)
+gloo_comm = ffm.gloo_comm
 
 rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 glob = tuple(int(v) for v in sys.argv[4:7]); grid = tuple(int(v) for v in sys.argv[7:10])

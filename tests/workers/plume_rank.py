@@ -8,13 +8,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import gloo_comm  # noqa: E402
 
 rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 glob = tuple(int(v) for v in sys.argv[4:7]); grid = tuple(int(v) for v in sys.argv[7:10])
 nSteps, outdir = int(sys.argv[10]), sys.argv[11]
-gloo_comm.init(rank, world, port)
 from ffm_import import ffm  # noqa: E402
+gloo_comm = ffm.gloo_comm
+gloo_comm.init(rank, world, port)
 ctx = ffm.Context(0)
 ctx.comm_init_host(rank, world, gloo_comm.allreduce, gloo_comm.exchange)
 lo, hi, nbr = ffm.hexmesh.block_of_rank(glob, grid, rank)
