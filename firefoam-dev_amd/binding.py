@@ -293,8 +293,10 @@ class Context:
         _check(lib().ffm_comm_unique_id(buf), "ffm_comm_unique_id")
         return buf.raw
 
-    def comm_init_host(self, rank, nRanks, allreduce, exchange):
-        """allreduce(np_array_inplace, op) / exchange(sizes, ranks, offsets, send_np, recv_np)."""
+    def comm_init_host(self, rank, nRanks, allreduce, exchange, exchange_var=None):
+        """allreduce(np_array_inplace, op) / exchange(sizes, ranks, offsets, send_np, recv_np) / exchange_var(ranks, sends, recvs):
+        the last one moves a different number of values each way per neighbour (general partitions: firefoam-dev_amd/decompose.py);
+        without it the ghost exchange needs equal counts (structured blocks)."""
         def _ar(user, vals, n, op):
             allreduce(np.ctypeslib.as_array(vals, shape=(n,)), op)
 
@@ -312,12 +314,19 @@ class Context:
             sizes_s = [so[i + 1] - so[i] for i in range(nN)]
             sb = np.ctypeslib.as_array(send, shape=(max(so[-1], 1),))
             rb = np.ctypeslib.as_array(recv, shape=(max(ro[-1], 1),))
-            # express the variable-count exchange through the same python callback, one neighbour at a time
+            sends = [np.ascontiguousarray(sb[so[q]:so[q + 1]]) for q in range(nN)]
+            recvs = [np.empty(ro[q + 1] - ro[q]) for q in range(nN)]
+            if exchange_var is not None:
+                exchange_var(ranks, sends, recvs)              # all neighbours at once
+            else:
+                # the equal-count callback, one neighbour at a time
+                for q in range(nN):
+                    if len(sends[q]) != len(recvs[q]):
+                        raise FfmError("ghost exchange with %d values out and %d in for rank %d needs comm_init_host(..., exchange_var=...)"
+                                       % (len(sends[q]), len(recvs[q]), ranks[q]))
+                    exchange([len(sends[q])], [ranks[q]], [0], sends[q], recvs[q])
             for q in range(nN):
-                tmp_s = np.ascontiguousarray(sb[so[q]:so[q + 1]])
-                tmp_r = np.empty(ro[q + 1] - ro[q])
-                exchange([len(tmp_s)], [ranks[q]], [0], tmp_s, tmp_r) if len(tmp_s) == len(tmp_r) else exchange_var(ranks[q], tmp_s, tmp_r)
-                rb[ro[q]:ro[q + 1]] = tmp_r
+                rb[ro[q]:ro[q + 1]] = recvs[q]
         self._cb = (HOST_ALLREDUCE_FN(_ar), HOST_EXCHANGE_FN(_ex), HOST_EXCHANGE2_FN(_ex2))
         _check(lib().ffm_comm_init_host(self.h, rank, nRanks, None, self._cb[0], self._cb[1]), "ffm_comm_init_host")
         _check(lib().ffm_comm_set_host_exchange2(self.h, self._cb[2]), "ffm_comm_set_host_exchange2")

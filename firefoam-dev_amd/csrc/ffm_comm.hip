@@ -281,7 +281,6 @@ extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRa
                                           const int *sendCells, const int *recvCount)
 {
     if (!A || nNbr < 0 || (nNbr && (!nbrRank || !sendCount || !sendCells || !recvCount))) return FFM_ERR_ARG;
-    if (!A->identity) { ffm_set_error("ghost exchange needs the library's cell order"); return FFM_ERR_UNSUPPORTED; }
     hipStreamSynchronize(A->ctx->stream);
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); A->ghSendCells = nullptr; A->ghSendBuf = nullptr;
     if (A->ghSendBuf_h) { hipHostFree(A->ghSendBuf_h); A->ghSendBuf_h = nullptr; }
@@ -294,7 +293,13 @@ extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRa
     for (int i = 0; i < nSend; i++) if (sendCells[i] < 0 || sendCells[i] >= A->nOwned) { ffm_set_error("ghost exchange: send cell out of range"); A->ghNbrRank.clear(); return FFM_ERR_ARG; }
     FFM_HIP(hipMalloc((void **)&A->ghSendCells, sizeof(int) * std::max(nSend, 1)));
     FFM_HIP(hipMalloc((void **)&A->ghSendBuf, sizeof(double) * std::max(nSend, 1)));
-    FFM_HIP(hipMemcpy(A->ghSendCells, sendCells, sizeof(int) * nSend, hipMemcpyHostToDevice));
+    {
+        // the caller's cell labels -> the library's numbering (ghost cells keep their place behind the owned ones in both)
+        std::vector<int> oldToNew(A->nCells), mapped(std::max(nSend, 1));
+        for (int i = 0; i < A->nCells; i++) oldToNew[A->h_newToOldCell[i]] = i;
+        for (int i = 0; i < nSend; i++) mapped[i] = oldToNew[sendCells[i]];
+        FFM_HIP(hipMemcpy(A->ghSendCells, mapped.data(), sizeof(int) * nSend, hipMemcpyHostToDevice));
+    }
     FFM_HIP(hipHostMalloc((void **)&A->ghSendBuf_h, sizeof(double) * std::max(nSend, 1), hipHostMallocDefault));
     FFM_HIP(hipHostMalloc((void **)&A->ghRecvBuf_h, sizeof(double) * std::max(A->ghRecvOff[nNbr], 1), hipHostMallocDefault));
     return FFM_OK;

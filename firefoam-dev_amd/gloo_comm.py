@@ -40,3 +40,22 @@ def exchange(sizes, ranks, offs, send, recv):
         q.wait()
     for o, n, tr, _ in bufs:
         recv[o:o + n] = tr.numpy()
+
+
+def exchange_var(ranks, sends, recvs):
+    """one message each way per neighbour, any counts: all sends and receives posted, then waited for"""
+    import torch
+    dist = _dist()
+    reqs, keep = [], []
+    for r, s, rv in zip(ranks, sends, recvs):
+        if len(s):
+            ts = torch.from_numpy(np.ascontiguousarray(s).copy()); keep.append(ts)
+            reqs.append(dist.isend(ts, r, group=GROUP))
+        if len(rv):
+            tr = torch.empty(len(rv), dtype=torch.float64); keep.append((tr, rv))
+            reqs.append(dist.irecv(tr, r, group=GROUP))
+    for q in reqs:
+        q.wait()
+    for k in keep:
+        if isinstance(k, tuple):
+            k[1][:] = k[0].numpy()

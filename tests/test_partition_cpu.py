@@ -88,3 +88,28 @@ def test_gloo_ranks_on_a_partitioned_mesh_match_the_serial_solve(O, ffm, meshNam
     for p in parts:
         full[p["gcell"]] = p["psi"]
     assert rel_l2(full, ref) < 1e-10
+
+
+def test_gloo_variable_count_exchange(ffm):
+    """the host transport's variable-count exchange (general partitions send and receive different numbers of values per
+    neighbour): 3 ranks, rank r sends r + 1 + q values to every other rank q"""
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from ffm_import import ffm\n"
+        "g = ffm.gloo_comm; r, w, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]); g.init(r, w, port)\n"
+        "others = [q for q in range(w) if q != r]\n"
+        "sends = [100.0 * r + np.arange(r + 1 + q) for q in others]; recvs = [np.empty(q + 1 + r) for q in others]\n"
+        "g.exchange_var(others, sends, recvs)\n"
+        "assert all(np.array_equal(rv, 100.0 * q + np.arange(q + 1 + r)) for q, rv in zip(others, recvs))\n"
+    ) % os.path.dirname(HERE)
+    port = 29800 + os.getpid() % 150
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "3", str(port)], env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""),
+                              stderr=subprocess.PIPE) for r in range(3)]
+    try:
+        outs = [p.communicate(timeout=120) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert [p.returncode for p in procs] == [0, 0, 0], [o[1][-400:] for o in outs]

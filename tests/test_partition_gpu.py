@@ -31,7 +31,12 @@ def test_partitioned_mesh_on_the_device(O, ffm, ctx, meshName, partitioner, worl
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "part_rank.py"), "gpu", str(r), str(world), str(port),
                                    meshName, partitioner, solver, precond, str(asym), tmp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
                  for r in range(world)]
-        outs = [p.communicate(timeout=300) for p in procs]
+        try:
+            outs = [p.communicate(timeout=120) for p in procs]
+        finally:
+            for p in procs:                      # a rank that failed leaves the others waiting in gloo: never leave them behind
+                if p.poll() is None:
+                    p.kill()
         assert [p.returncode for p in procs] == [0] * world, [o[1][-800:] for o in outs]
         parts = [np.load(os.path.join(tmp, "rank%d.npz" % r)) for r in range(world)]
         ys = [np.load(os.path.join(tmp, "amul%d.npy" % r)) for r in range(world)]

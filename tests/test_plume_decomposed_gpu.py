@@ -56,7 +56,12 @@ def _run(ffm, ctx, glob, grid, extraEnv, extraFields=()):
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "plume_rank.py"), str(r), str(world), str(port),
                                    *map(str, glob), *map(str, grid), str(nSteps), tmp],
                                   env=dict(os.environ, FFM_PLUME_TIGHT="1", **extraEnv)) for r in range(world)]
-        rcs = [p.wait(timeout=300) for p in procs]
+        try:
+            rcs = [p.wait(timeout=240) for p in procs]
+        finally:
+            for p in procs:                      # never leave a rank behind (the others wait for it in gloo)
+                if p.poll() is None:
+                    p.kill()
         assert rcs == [0] * world
         parts = [np.load(os.path.join(tmp, "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
     nx, ny, nz = glob

@@ -47,7 +47,7 @@ if mode == "oracle":
     psi, perf = A.solve(getattr(O, solver), getattr(O, precond), np.zeros(sub.nOwned), source[sub.gcell[:sub.nOwned]], tolerance=1e-12)
 else:
     ctx = ffm.Context(0)
-    ctx.comm_init_host(rank, world, gloo.allreduce, gloo.exchange)
+    ctx.comm_init_host(rank, world, gloo.allreduce, gloo.exchange, gloo.exchange_var)
     A = ffm.lduMatrix(ctx, sub.nOwned, sub.l, sub.u, nGhost=sub.nGhost)
     A.set_ghost_exchange(sub.nbrRank, sub.sendCount, sub.sendCells, sub.recvCount, tags=sub.tags, globalCells=N)
     d, upl, lol = sub.coeffs(diag, up, lo)
