@@ -103,6 +103,9 @@ extern "C" int ffm_comm_init_host(ffm_ctx *c, int rank, int nRanks, void *user, 
 
 void ffm_comm_finalize_i(ffm_ctx *c)
 {
+    if (c->commStream) { hipStreamSynchronize(c->commStream); hipStreamDestroy(c->commStream); c->commStream = nullptr; }
+    if (c->evPack) { hipEventDestroy(c->evPack); c->evPack = nullptr; }
+    if (c->evRecv) { hipEventDestroy(c->evRecv); c->evRecv = nullptr; }
     if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
 }
 
@@ -305,6 +308,58 @@ extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRa
     return FFM_OK;
 }
 
+// the send / receive group of one ghost refresh on stream s
+static int ghost_group(ffm_ldu *A, double *ghost, hipStream_t s)
+{
+    ffm_ctx *c = A->ctx;
+    const int nNbr = (int)A->ghNbrRank.size();
+    const std::vector<int> order = posting_order(nNbr, A->ghTags);
+    FFM_NCCL(ncclGroupStart());
+    for (int q : order) {
+        const int ns = A->ghSendOff[q + 1] - A->ghSendOff[q], nr = A->ghRecvOff[q + 1] - A->ghRecvOff[q];
+        if (ns) FFM_NCCL_IN_GROUP(ncclSend(A->ghSendBuf + A->ghSendOff[q], ns, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, s));
+        if (nr) FFM_NCCL_IN_GROUP(ncclRecv(ghost + A->ghRecvOff[q], nr, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, s));
+    }
+    FFM_NCCL(ncclGroupEnd());
+    return FFM_OK;
+}
+
+// Overlapped form for an operator whose interior work does not read the ghost entries (the tiled Amul: its ghost faces are
+// added by a tail kernel): the pack kernel runs on the main stream, the RCCL group on a second stream behind an event, and
+// ffm_ghost_exchange_end() makes the main stream wait for the receives just before the tail.  Same data, same arithmetic as the
+// serial order -- only the interior rows no longer wait for the wire.  Host transport and FFM_NO_OVERLAP: the serial exchange.
+int ffm_ghost_exchange_begin(ffm_ldu *A, double *x)
+{
+    ffm_ctx *c = A->ctx;
+    static const bool noOverlap = getenv("FFM_NO_OVERLAP") != nullptr;
+    const int nNbr = (int)A->ghNbrRank.size();
+    if (!nNbr) return FFM_OK;
+    if (!c->comm || noOverlap) return ffm_ghost_exchange(A, x);
+    if (!c->commStream) {
+        FFM_HIP(hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
+        FFM_HIP(hipEventCreateWithFlags(&c->evPack, hipEventDisableTiming));
+        FFM_HIP(hipEventCreateWithFlags(&c->evRecv, hipEventDisableTiming));
+    }
+    const int nSend = A->ghSendOff[nNbr];
+    if (nSend) hipLaunchKernelGGL(k_halo_pack, dim3(std::max(1, std::min(ffm_grid(nSend, 256), 1024))), dim3(256), 0, c->stream,
+                                  nSend, A->ghSendCells, x, A->ghSendBuf);
+    FFM_HIP(hipGetLastError());
+    FFM_HIP(hipEventRecord(c->evPack, c->stream));
+    FFM_HIP(hipStreamWaitEvent(c->commStream, c->evPack, 0));
+    FFM_TRY(ghost_group(A, x + A->nOwned, c->commStream));
+    FFM_HIP(hipEventRecord(c->evRecv, c->commStream));
+    A->ghPending = true;
+    return FFM_OK;
+}
+
+int ffm_ghost_exchange_end(ffm_ldu *A)
+{
+    if (!A->ghPending) return FFM_OK;
+    FFM_HIP(hipStreamWaitEvent(A->ctx->stream, A->ctx->evRecv, 0));
+    A->ghPending = false;
+    return FFM_OK;
+}
+
 int ffm_ghost_exchange(ffm_ldu *A, double *x)
 {
     ffm_ctx *c = A->ctx;
@@ -315,17 +370,7 @@ int ffm_ghost_exchange(ffm_ldu *A, double *x)
                                   nSend, A->ghSendCells, x, A->ghSendBuf);
     FFM_HIP(hipGetLastError());
     double *ghost = x + A->nOwned;
-    if (c->comm) {
-        const std::vector<int> order = posting_order(nNbr, A->ghTags);
-        FFM_NCCL(ncclGroupStart());
-        for (int q : order) {
-            const int ns = A->ghSendOff[q + 1] - A->ghSendOff[q], nr = A->ghRecvOff[q + 1] - A->ghRecvOff[q];
-            if (ns) FFM_NCCL_IN_GROUP(ncclSend(A->ghSendBuf + A->ghSendOff[q], ns, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
-            if (nr) FFM_NCCL_IN_GROUP(ncclRecv(ghost + A->ghRecvOff[q], nr, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, c->stream));
-        }
-        FFM_NCCL(ncclGroupEnd());
-        return FFM_OK;
-    }
+    if (c->comm) return ghost_group(A, ghost, c->stream);
     if (!c->hostExchange2) { ffm_set_error("ghost cells set but no communicator attached"); return FFM_ERR_COMM; }
     FFM_HIP(hipMemcpyAsync(A->ghSendBuf_h, A->ghSendBuf, sizeof(double) * nSend, hipMemcpyDeviceToHost, c->stream));
     FFM_HIP(hipStreamSynchronize(c->stream));

@@ -65,6 +65,10 @@ struct ffm_ctx {
     ffm_host_exchange_fn hostExchange = nullptr;
     ffm_host_exchange2_fn hostExchange2 = nullptr;
     int cuCount = 256;
+    // second stream for the RCCL ghost exchange of an Amul whose interior rows do not need the ghost values (tiled Amul):
+    // pack (main stream) -> evPack -> send / receive (commStream) -> evRecv -> ghost-face tail (main stream)
+    hipStream_t commStream = nullptr;
+    hipEvent_t evPack = nullptr, evRecv = nullptr;
     // stream-ordered caching allocator behind ffm_malloc / ffm_free (the Foam layer makes one temporary per operator):
     // a freed block goes to the free list of its size class without synchronising -- every consumer runs on `stream`, so a
     // later owner's kernels are ordered after the previous owner's -- and is handed out again by the next ffm_malloc of that
@@ -171,6 +175,7 @@ struct ffm_ldu {
     // straight into x[nOwned + ghRecvOff[q] ..]
     std::vector<int> ghNbrRank, ghSendOff, ghRecvOff;   // offsets have nNbr+1 entries
     int *ghSendCells = nullptr;
+    bool ghPending = false;        // an overlapped exchange is in flight on ctx->commStream (ffm_ghost_exchange_begin / _end)
     double *ghSendBuf = nullptr, *ghSendBuf_h = nullptr, *ghRecvBuf_h = nullptr;
 
     // ---- tiled sweep plan (sweepMode == 2): cells are numbered group-major, level-major inside a group;
@@ -213,6 +218,8 @@ int ffm_tile_calc_rD(ffm_ldu *A);
 bool ffm_tile_gs_usable(const ffm_ldu *A);
 int ffm_tile_gs_ghost_terms(ffm_ldu *A, const double *psi, double *bP);
 int ffm_ghost_exchange(ffm_ldu *A, double *x);
+int ffm_ghost_exchange_begin(ffm_ldu *A, double *x);     // starts the refresh of x[nOwned..nCells); may return with it in flight
+int ffm_ghost_exchange_end(ffm_ldu *A);                  // the main stream waits for it
 int ffm_tile_gs(ffm_ldu *A, bool sym, double *psi, const double *bP, double *bSave, double *prod3);
 bool ffm_tile_amul_usable(const ffm_ldu *A);
 int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot);     // returns 1 if the dot product is left to the caller

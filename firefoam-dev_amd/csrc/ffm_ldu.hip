@@ -812,9 +812,14 @@ static inline int rows_grid(const ffm_ldu *A)
 
 int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
 {
-    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));   // refresh ghost columns
     const double *up = transpose ? A->lower : A->upper, *lo = transpose ? A->upper : A->lower;
-    if (ffm_tile_amul_usable(A) && !getenv("FFM_NO_TILE_AMUL")) { FFM_TRY(ffm_tile_amul(A, x, y, -1)); return FFM_OK; }
+    if (ffm_tile_amul_usable(A) && !getenv("FFM_NO_TILE_AMUL")) {
+        // the tiled kernel computes the rows without their ghost faces: the ghost refresh overlaps it and is waited for by the tail
+        if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange_begin(A, const_cast<double *>(x)));
+        FFM_TRY(ffm_tile_amul(A, x, y, -1));
+        return FFM_OK;
+    }
+    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));   // refresh ghost columns
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
                                                A->diag, up, lo, x, (const double *)nullptr, y, (double *)nullptr));
     FFM_HIP(hipGetLastError());
@@ -824,16 +829,17 @@ int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
 
 int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
 {
-    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));
     if (!A->ifaces.empty()) {  // the halo term changes y after the row kernel: separate dot
         FFM_TRY(ffm_k_spmv(A, x, y, false));
         return ffm_k_dot(A->ctx, y, x, A->nOwned, slot);
     }
     if (ffm_tile_amul_usable(A) && !getenv("FFM_NO_TILE_AMUL")) {
+        if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange_begin(A, const_cast<double *>(x)));
         const int rc = ffm_tile_amul(A, x, y, slot);
         if (rc == 1) return ffm_k_dot(A->ctx, y, x, A->nOwned, slot);      // ghost faces were added after the tiled kernel
         return rc;
     }
+    if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));
     const int g = rows_grid(A);
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, true, W>), dim3(g), dim3(256), 0, A->ctx->stream, ffm_view(A), A->diag,
                                                A->upper, A->lower, x, (const double *)nullptr, y, A->ctx->partials_d));

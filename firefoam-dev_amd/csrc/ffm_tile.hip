@@ -999,10 +999,12 @@ int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot)
     AmulView v; v.G = T->G; v.grpCell = A->grpCell; v.grpEnt = T->f.grpEnt; v.rec = T->arec; v.seg = T->aseg; v.code = T->acode; v.ext = T->aext;
     const bool fusedDot = dotSlot >= 0 && T->nTail == 0 && T->nSeg <= 4 * RED_BLOCKS;
     if (fusedDot) {
+        FFM_TRY(ffm_ghost_exchange_end(A));          // (no ghost faces on this rank: nothing in flight that the kernel would need)
         hipLaunchKernelGGL((k_tile_amul<true>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, A->ctx->partials_d);
         hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->nSeg, (const double *)A->ctx->partials_d, A->ctx->scal_d, dotSlot);
     } else {
         hipLaunchKernelGGL((k_tile_amul<false>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, (double *)nullptr);
+        FFM_TRY(ffm_ghost_exchange_end(A));          // an overlapped ghost refresh (ffm_ghost_exchange_begin) must have landed before the tail
         if (T->nTail > 0)
             hipLaunchKernelGGL(k_amul_tail<false>, dim3((T->nTail + 255) / 256), dim3(256), 0, s, T->nTail, (const int *)T->tailCell, (const int *)T->tailStart,
                                (const int *)T->tailFace, (const int *)T->tailNbr, (const double *)A->upper, x, y);

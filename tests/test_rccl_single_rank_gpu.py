@@ -83,3 +83,52 @@ def test_plume_step_with_every_reduction_through_rccl(O, ffm):
     for name in ("rho", "p", "p_rgh", "T", "Ux", "Uy", "Uz", "C3H8", "O2"):
         assert np.array_equal(a.field(name), b.field(name)), name
     a.close(); b.close(); plain.close(); viaRccl.close()
+
+
+def test_overlapped_ghost_exchange_of_the_tiled_amul(O, ffm):
+    """the tiled Amul computes the rows without their ghost faces while the RCCL send / receive group of the
+    ghost refresh runs on a second stream; the ghost-face tail waits for it.  One rank that is its own neighbour (a box whose +x
+    layer of ghost cells mirrors its x = 0 layer, i.e. a periodic coupling): real ncclSend / ncclRecv on the communication stream,
+    tile numbering with a ghost-face tail.  Amul against the operator written out in numpy, PCG against a sparse direct solve --
+    ghosts hold rubbish before every Amul, so a tail that did not wait for the receive would show."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    os.environ["FFM_FORCE_COMM"] = "1"
+    try:
+        ctx = ffm.Context(0)
+        ctx.comm_init_rccl(0, 1, ffm.Context.comm_unique_id())
+    finally:
+        del os.environ["FFM_FORCE_COMM"]
+    nx, ny, nz = 24, 40, 36
+    N, l, u = O.hex_ldu(nx, ny, nz)
+    c = np.arange(N); i, j, k = c % nx, (c // nx) % ny, c // (nx * ny)
+    last = c[i == nx - 1]; first = c[i == 0]                 # same (j, k) order
+    G = len(last)
+    fl = np.concatenate([l, last]); fu = np.concatenate([u, N + np.arange(G)])
+    order = np.lexsort((fu, fl)); fl, fu = fl[order].astype(np.int32), fu[order].astype(np.int32)
+    hint = (j // 16 + 1000 * (k // 16)).astype(np.int32)
+    cOrd, fOrd = ffm.renumber_levels(N, l, u, groupHint=hint)     # owned cells in tile order; ghosts keep their place behind
+    oldToNew = np.empty(N + G, np.int64); oldToNew[cOrd] = np.arange(N); oldToNew[N:] = N + np.arange(G)
+    l2, u2 = oldToNew[fl], oldToNew[fu]
+    o2 = np.lexsort((u2, l2)); l2, u2 = l2[o2].astype(np.int32), u2[o2].astype(np.int32)
+    A = ffm.lduMatrix(ctx, N, l2, u2, groupHint=hint[cOrd], nGhost=G)
+    assert A.sweep_mode == 2 and A.native_order
+    A.set_ghost_exchange([0], [G], oldToNew[first], [G])
+    nF = len(l2)
+    upper = -(0.5 + O.hash_u(1, np.arange(nF)))
+    diag = np.zeros(N + G); np.add.at(diag, l2, -upper); own = u2 < N; np.add.at(diag, u2[own], -upper[own]); diag[:N] += 0.2
+    A.set_coeffs(diag, upper)
+    src = np.arange(N + G); src[N:] = oldToNew[first]        # ghost column = its source cell
+    M = sp.coo_matrix((np.concatenate([diag[:N], upper, upper[own]]),
+                       (np.concatenate([np.arange(N), l2, u2[own]]), np.concatenate([np.arange(N), src[u2], l2[own]]))), shape=(N, N)).tocsr()
+    x = O.hash_u(2, np.arange(N + G)); x[N:] = 1e300
+    for _ in range(3):                                        # back-to-back launches: send buffer and events are reused
+        y = A.Amul(ctx.to_device(x)).cpu().numpy()
+        assert np.abs(y[:N] - M @ x[:N]).max() <= 1e-13 * np.abs(M @ x[:N]).max()
+    b = np.zeros(N + G); b[:N] = O.hash_u(3, np.arange(N)) - 0.5
+    psi = ctx.zeros(N + G)
+    perf = A.solve(psi, ctx.to_device(b), solver="PCG", preconditioner="DIC", tolerance=1e-12, relTol=0.0)
+    assert perf["converged"]
+    ref = spl.spsolve(M.tocsc(), b[:N])
+    assert np.linalg.norm(psi.cpu().numpy()[:N] - ref) <= 1e-9 * np.linalg.norm(ref)
+    A.close(); ctx.close()
