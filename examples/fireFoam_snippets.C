@@ -296,6 +296,7 @@ extern "C" int firefoam_snippets_step(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh,
 extern "C" int firefoam_snippets_hydrostatic(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, const snippetCase* cs)
 {
     snippetSolver s(ctx, ldu, msh, cs);
+    std::cout.precision(8);              // Time::readDict: IOstream::defaultPrecision(writePrecision 8) (cases/steckler/system/controlDict:36-38)
     s.hydrostatic(cs->totalMaskP, cs->fluxMaskP);
     s.download(cs, false);
     return s.iterations(cs, false);

@@ -219,7 +219,7 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
 
 
 @pytest.mark.parametrize("from_polymesh", [False, True])
-def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx, from_polymesh, tmp_path):
+def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx, capfd, from_polymesh, tmp_path):
     """The reference's solver/phrghEqn.H, included unchanged, run on the reference's steckler case (30 x 15 x 20 cells, the
     compartment baffles and doorway, ph_rgh fixedValue 0 on `top` and fixedFluxPressure elsewhere, the boundary mixtures of the
     case files: oracle/steckler.py) through the Foam layer on the device: every operator of the file (fvc::interpolate, snGrad,
@@ -319,4 +319,27 @@ def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx,
         assert abs(res[2 * k + 1] - g_["finalResidual"]) <= 1e-6 * g_["finalResidual"], (k, res[2 * k + 1], g_["finalResidual"])
     variation = o["p_rgh"].max() - o["p_rgh"].min()
     assert abs(variation - gold[-1]["variation"]) <= 1e-6 * gold[-1]["variation"], variation
+    # the log the Foam layer prints while the reference's phrghEqn.H runs diffs against the golden one: same lines, solver name,
+    # field, iteration count; the 8-digit numbers equal to 1e-6 (SolverPerformance::print)
+    del os.environ["FFM_FOAM_QUIET"]
+    try:
+        capfd.readouterr()
+        assert lib.firefoam_snippets_hydrostatic(ctx.h, A.h, mesh.h, C.byref(cs)) == 5
+        out = capfd.readouterr().out
+    finally:
+        os.environ["FFM_FOAM_QUIET"] = "1"
+    import re
+    pat = re.compile(r"^(\w+):  Solving for (\w+), Initial residual = (\S+), Final residual = (\S+), No Iterations (\d+)$")
+    got = [pat.match(ln).groups() for ln in out.splitlines() if ln.startswith("DICPCG")]
+    golden_lines = ["DICPCG:  Solving for ph_rgh, Initial residual = 1, Final residual = 0.0080439052, No Iterations 29",
+                    "DICPCG:  Solving for ph_rgh, Initial residual = 0.0010688694, Final residual = 9.4376262e-06, No Iterations 32",
+                    "DICPCG:  Solving for ph_rgh, Initial residual = 9.4390676e-06, Final residual = 9.6501e-07, No Iterations 7",
+                    "DICPCG:  Solving for ph_rgh, Initial residual = 9.6507488e-07, Final residual = 9.6507488e-07, No Iterations 0",
+                    "DICPCG:  Solving for ph_rgh, Initial residual = 9.6507488e-07, Final residual = 9.6507488e-07, No Iterations 0"]
+    want = [pat.match(ln).groups() for ln in golden_lines]            # cases/steckler/original/linux64/log.fireFoam:92-100
+    assert len(got) == 5
+    for g_, w_ in zip(got, want):
+        assert (g_[0], g_[1], g_[4]) == (w_[0], w_[1], w_[4])
+        assert abs(float(g_[2]) - float(w_[2])) <= 1e-6 * float(w_[2]) and abs(float(g_[3]) - float(w_[3])) <= 1e-6 * float(w_[3])
+    assert out.splitlines()[0] == golden_lines[0]                      # the first line: every character
     A.close()
