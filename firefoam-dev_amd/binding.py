@@ -132,6 +132,14 @@ def lib():
         "ffm_mesh_destroy": ([vp], C.c_int),
         "ffm_mesh_set_face_centres": ([vp, hp], C.c_int),
         "ffm_mesh_set_nonorth_correction": ([vp, hp], C.c_int),
+        "ffm_pyro_create": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(vp)], C.c_int),
+        "ffm_pyro_set_solids": ([vp, hp, hp], C.c_int),
+        "ffm_pyro_set_reaction": ([vp, C.c_double, C.c_double, C.c_double, C.c_double], C.c_int),
+        "ffm_pyro_step": ([vp, C.c_double, dp, C.c_int, C.c_double], C.c_int),
+        "ffm_pyro_get": ([vp, C.c_char_p, hp], C.c_int),
+        "ffm_pyro_surface_T_d": ([vp], C.c_void_p),
+        "ffm_pyro_phiGas_d": ([vp], C.c_void_p),
+        "ffm_pyro_destroy": ([vp], C.c_int),
         "ffm_partition_rcb": ([C.c_int, hp, C.c_int, ip], C.c_int),
         "ffm_partition_graph": ([C.c_int, C.c_int, ip, ip, C.c_int, ip], C.c_int),
         "ffm_subdomain_create": ([C.c_int, C.c_int, ip, ip, ip, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
@@ -590,6 +598,32 @@ class Plume:
 
     def ldu_handle(self):
         return lib().ffm_plume_ldu(self.h)
+
+
+class PyrolysisPanel:
+    """reactingOneDim for a panel of independent columns (ffm_pyro_*): step(dt, qSurf) advances rho, Y, h, T of every column"""
+
+    def __init__(self, ctx, nCol, nLay=8, thickness=0.0127, area=1.0, T0=298.15, Yw0=1.0):
+        self.ctx, self.nCol, self.nLay = ctx, int(nCol), int(nLay)
+        h = C.c_void_p()
+        _check(lib().ffm_pyro_create(ctx.h, self.nCol, self.nLay, thickness, area, T0, Yw0, C.byref(h)), "ffm_pyro_create")
+        self.h = h
+
+    def step(self, dt, qSurf, Tback=None):
+        """qSurf: torch CUDA fp64 [nCol]"""
+        self.ctx._ready()
+        _check(lib().ffm_pyro_step(self.h, float(dt), C.c_void_p(qSurf.data_ptr()), 0 if Tback is None else 1, 0.0 if Tback is None else float(Tback)), "ffm_pyro_step")
+
+    def field(self, name):
+        n = self.nCol if name in ("Tsurf", "phiGas") else self.nCol * self.nLay
+        out = np.empty(n)
+        _check(lib().ffm_pyro_get(self.h, name.encode(), _hp(out)), "ffm_pyro_get")
+        return out if name in ("Tsurf", "phiGas") else out.reshape(self.nCol, self.nLay)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ffm_pyro_destroy(self.h)
+            self.h = None
 
 
 class fvMesh:

@@ -377,6 +377,25 @@ int ffm_plume_nsolves(const ffm_plume *p);
 int ffm_plume_get_solve(const ffm_plume *p, int i, char *name16, ffm_perf *perf);
 ffm_ldu *ffm_plume_ldu(ffm_plume *p);
 
+/* ------------------------------------------------------- pyrolysis region (N3) */
+/* reactingOneDim::evolveRegion (packages/regionModels/pyrolysisModels/reactingOneDim/reactingOneDim.C:686-721) for a panel of
+ * nCol independent columns of nLay <= 16 layers (the region mesh extruded from a wall patch: cases/wallFireSpread2D/system/
+ * extrudeToRegionMeshDict:17-39; cases/pyrolysis1D: one column, 8 layers): Arrhenius solid reaction, continuity, species and
+ * the tridiagonal enthalpy equation of every column in one kernel, then solidThermo.correct().  Defaults: the solids and the
+ * reaction of cases/pyrolysis1D/constant/panelRegion.  qSurf_d[nCol] (device): heat flux into the exposed face of every column
+ * [W/m2] -- what the coupled wall conditions of lib/fvPatchFieldsPyrolysis hand over; the back face is adiabatic or held at Tback.
+ * Out (device, [nCol]): the exposed cell's temperature and the pyrolysate mass flux phiGas [kg/s] of every column.            */
+typedef struct ffm_pyro ffm_pyro;
+int ffm_pyro_create(ffm_ctx *ctx, int nCol, int nLay, double thickness, double faceArea, double T0, double Yvirgin0, ffm_pyro **out);
+int ffm_pyro_set_solids(ffm_pyro *p, const double *virgin /* rho Cp kappa Hf */, const double *charred);
+int ffm_pyro_set_reaction(ffm_pyro *p, double A, double Ta, double Tcrit, double n);
+int ffm_pyro_step(ffm_pyro *p, double deltaT, const double *qSurf_d, int backFixed, double Tback);
+/* name: rho, Yw, T, h -> host [nCol][nLay]; Tsurf, phiGas -> host [nCol] */
+int ffm_pyro_get(ffm_pyro *p, const char *name, double *out);
+const double *ffm_pyro_surface_T_d(const ffm_pyro *p);
+const double *ffm_pyro_phiGas_d(const ffm_pyro *p);
+int ffm_pyro_destroy(ffm_pyro *p);
+
 /* ---------------------------------------------------------------- reductions */
 /* gSum / gMin / gMax / gSumProd / gSumMag over a device field (solver/YEEqn.H:
  * 73-78,117-118; solver/phrghEqn.H:54-55).  All-reduced when a communicator is
