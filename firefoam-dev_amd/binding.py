@@ -163,7 +163,7 @@ def lib():
         "ffm_fv_filtered_linear2V_weights": ([vp, C.c_double, C.c_double, dp] + [C.POINTER(C.c_void_p)] * 4 + [dp], C.c_int),
         "ffm_fvc_grad_multi": ([vp, C.c_int] + [C.POINTER(C.c_void_p)] * 5, C.c_int),
         "ffm_fvm_scalar_transport_multi": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
-                                           + [C.POINTER(C.c_void_p)] * 14, C.c_int),
+                                           + [C.POINTER(C.c_void_p)] * 16, C.c_int),
         "ffm_fvm_lust_source3": ([vp, C.c_double, dp, dp] + [C.POINTER(C.c_void_p)] * 5, C.c_int),
         "ffm_mesh_nboundary": ([vp], C.c_int),
         "ffm_mesh_nnative": ([vp], C.c_int),
@@ -191,6 +191,7 @@ def lib():
         "ffm_plume_set_tight": ([vp, C.c_int], C.c_int),
         "ffm_plume_set_solvers": ([vp, C.c_int], C.c_int),
         "ffm_plume_set_radiation": ([vp, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
+        "ffm_plume_set_radiation_model": ([vp, C.c_double, C.c_double, C.c_double], C.c_int),
         "ffm_plume_ncells": ([vp], C.c_int),
         "ffm_plume_nfaces": ([vp], C.c_int),
         "ffm_plume_get_field": ([vp, C.c_char_p, hp], C.c_int),
@@ -575,6 +576,10 @@ class Plume:
         if len(o) != 4 * nPhi * nTheta:
             raise ValueError("rays must hold 4*nPhi*nTheta entries")
         _check(lib().ffm_plume_set_radiation(self.h, solverFreq, nPhi, nTheta, d.ctypes.data, o.ctypes.data), "ffm_plume_set_radiation")
+
+    def set_radiation_model(self, absorption, Ehrr1, Ehrr2):
+        """the reference's absorption / emission model and radiation->Sh in the enthalpy equation (ffm_plume_set_radiation_model)"""
+        _check(lib().ffm_plume_set_radiation_model(self.h, float(absorption), float(Ehrr1), float(Ehrr2)), "ffm_plume_set_radiation_model")
 
     def set_tight(self, on=True):
         _check(lib().ffm_plume_set_tight(self.h, 1 if on else 0), "ffm_plume_set_tight")

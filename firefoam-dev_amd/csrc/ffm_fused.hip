@@ -89,6 +89,7 @@ struct ScalarEqns {
     const double *vf[FUSE_MAX], *gx[FUSE_MAX], *gy[FUSE_MAX], *gz[FUSE_MAX], *vf0[FUSE_MAX];
     const double *f[FUSE_MAX], *ref[FUSE_MAX], *refGrad[FUSE_MAX];      // mixed patch condition [B]
     const double *su[FUSE_MAX];                                          // explicit volume source (nullable)
+    const double *su2[FUSE_MAX], *sp[FUSE_MAX];                          // a second explicit source and an implicit one (fvm::Sp): nullable
     const double *expl[FUSE_MAX][3];                                     // explicit LHS volume terms (nullable)
     double *diag[FUSE_MAX], *upper[FUSE_MAX], *lower[FUSE_MAX], *src[FUSE_MAX];
     // shared
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(256) void k_scalar_eqns(MeshView q, ScalarEqns a)
             double sc = a.rdt * rho0c * a.vf0[i][c] * V;
             if (a.expl[i][0]) sc = ((sc - V * a.expl[i][0][c]) - V * a.expl[i][1][c]) - V * a.expl[i][2][c];
             if (a.su[i]) sc = sc + V * a.su[i][c];
+            if (a.sp[i]) d = d + V * a.sp[i][c];
+            if (a.su2[i]) sc = sc + V * a.su2[i][c];
             // boundary coefficients of the mixed condition, added in (patch, face) order
             if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) {
                 const int k = q.bcItem[t];
@@ -244,6 +247,7 @@ extern "C" int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, d
                                               const double *const *vf, const double *const *gx, const double *const *gy,
                                               const double *const *gz, const double *const *vf0, const double *const *f,
                                               const double *const *ref, const double *const *refGrad, const double *const *su,
+                                              const double *const *su2, const double *const *sp,
                                               const double *const *expl3, double *const *diag, double *const *upper,
                                               double *const *lower, double *const *source)
 {
@@ -259,6 +263,7 @@ extern "C" int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, d
         a.vf[i] = vf[q]; a.gx[i] = gx[q]; a.gy[i] = gy[q]; a.gz[i] = gz[q]; a.vf0[i] = vf0[q];
         a.f[i] = f[q]; a.ref[i] = ref[q]; a.refGrad[i] = refGrad[q];
         a.su[i] = su ? su[q] : nullptr;
+        a.su2[i] = su2 ? su2[q] : nullptr; a.sp[i] = sp ? sp[q] : nullptr;
         for (int e = 0; e < 3; e++) a.expl[i][e] = expl3 ? expl3[3 * q + e] : nullptr;
         if (a.expl[i][0] && (!a.expl[i][1] || !a.expl[i][2])) return FFM_ERR_ARG;
         a.diag[i] = diag[q]; a.upper[i] = upper[q]; a.lower[i] = lower[q]; a.src[i] = source[q];

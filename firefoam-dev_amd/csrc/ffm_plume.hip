@@ -45,6 +45,7 @@ int ffm_fvm_scalar_transport_multi(ffm_mesh *, int, int, double, double, double,
                                    const double *, const double *, const double *, const double *const *, const double *const *,
                                    const double *const *, const double *const *, const double *const *, const double *const *,
                                    const double *const *, const double *const *, const double *const *, const double *const *,
+                                   const double *const *, const double *const *,
                                    double *const *, double *const *, double *const *, double *const *);
 int ffm_fvm_lust_source3(ffm_mesh *, double, const double *, const double *, const double *const *, const double *const *,
                          const double *const *, const double *const *, double *const *);
@@ -106,6 +107,10 @@ struct ffm_plume {
     double *radDB = nullptr, *radSB = nullptr, *radPsiB = nullptr, *radUB = nullptr, *radLB = nullptr;
     bool radOrdered = false;
     std::vector<double *> I; double *G = nullptr, *radJ = nullptr, *radW = nullptr, *radJb = nullptr, *radF = nullptr, *radRef = nullptr, *radSrc = nullptr;
+    // the reference's absorption / emission model and radiation->Sh (ffm_plume_set_radiation_model): constant absorption
+    // coefficient, emission E = RadFraction*Qdot with the radScaling of constRadFractionEmission::ECont
+    bool radCoupled = false; double radA = 0.1, Ehrr1 = 0.0, Ehrr2 = 0.0;
+    double *radE = nullptr, *radShSu = nullptr, *radShSp = nullptr; bool radHaveG = false;
     bool stecklerSolvers = false;          // transport equations with smoothSolver + symGaussSeidel, maxIter 10
                                            // (cases/steckler/system/fvSolution:49-62) instead of PBiCGStab + DILU
 };
@@ -249,7 +254,8 @@ static int hydrostatic_init(ffm_plume *P)
 
 // transport equation of a scalar: ddt(rho,vf) + div(phi,vf) - laplacian(gamma,vf) == su (+ explicit LHS terms in `expl`)
 static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *vf, const double *vf0, const double *fBC, const double *ref,
-                            const double *gamma_f, const double *gamma_b, const double *su, const double *const *expl, double tol)
+                            const double *gamma_f, const double *gamma_b, const double *su, const double *const *expl, double tol,
+                            const double *su2 = nullptr, const double *sp = nullptr)
 {
     ffm_mesh *m = P->mesh; const int N = P->N;
     double *vb = P->wB[2], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *w = P->wF[3];
@@ -268,6 +274,8 @@ static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *
     double *s2 = P->wN[4];
     if (su) { forN(P, N, [=] __device__(long i) { s2[i] = s[i] + V[i] * su[i]; }); }
     else s2 = s;
+    if (sp) { double *dg = P->diag; forN(P, N, [=] __device__(long i) { dg[i] = dg[i] + V[i] * sp[i]; }); }      // - fvm::Sp(sp, vf) on the RHS
+    if (su2) { double *s3 = P->src[1]; const double *sIn = s2; forN(P, N, [=] __device__(long i) { s3[i] = sIn[i] + V[i] * su2[i]; }); s2 = s3; }
     FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, s2, nullptr, P->dWork, P->sWork));
     FFM_TRY(solve_named(P, name, FFM_PBICGSTAB, FFM_DILU, tol, 0.0, P->dWork, P->upper, P->lower, vf, P->sWork));
     return HX(P, vf);
@@ -278,7 +286,21 @@ static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *
 //   fvm::div(Ji, Ii) + fvm::Sp(k*omega, Ii) == 1/pi*omega*(k*sigma*T^4),  Ji = dAve & Sf, div scheme upwind
 // (radiativeIntensityRay.C:267-322), inflow faces at the ambient black-body intensity, outflow zero-gradient; then
 // G = sum Ii*omega (fvDOM::updateG).  Constant k, no scattering, no coupling back into the enthalpy equation.
-constexpr double SIGMA_SB = 5.670367e-8, K_ABS = 0.1;
+constexpr double SIGMA_SB = 5.670367e-8;
+extern "C" int ffm_reduce_sum(ffm_ctx *, const double *, long, double *);
+// RadFraction of constRadFractionEmission::ECont with radScaling (reference lib/thermophysicalModels/radiation/submodels/
+// absorptionEmissionModel/constRadFractionEmission/constRadFractionEmission.C): both patch lists name the burner
+// (cases/steckler/constant/radiationProperties:44-52) -> mlr1 = mlr2 = -gSum(phi_burner)
+static int plume_rad_fraction(ffm_plume *P, double *out)
+{
+    const double *kind = P->kind_d, *pb = P->phib; double *t = P->wB[0];
+    forN(P, P->B, [=] __device__(long k) { t[k] = kind[k] < 0.5 ? pb[k] : 0.0; });
+    double sum = 0.0;
+    FFM_TRY(ffm_reduce_sum(P->ctx, t, P->B, &sum));          // gSum: every rank takes part, also one without boundary faces
+    const double mlr = -sum, e1 = P->Ehrr1, e2 = P->Ehrr2;
+    *out = std::max(std::min(e1, e2), (mlr * e1 + mlr * e2) / std::max(1e-15, mlr + mlr));
+    return FFM_OK;
+}
 static int radiation_correct(ffm_plume *P)
 {
     ffm_mesh *m = P->mesh; const int N = P->N, B = P->B; const long nNat = P->nNat;
@@ -290,6 +312,15 @@ static int radiation_correct(ffm_plume *P)
     const double *T = P->T;
     forN(P, N, [=] __device__(long c) { G[c] = 0.0; });
     forN(P, B, [=] __device__(long k) { ref[k] = Ib; });
+    const double KA = P->radA;
+    const double *Ee = nullptr;
+    if (P->radCoupled) {      // absorptionEmission->ECont(): E = RadFraction*Qdot (constRadFractionEmission.C, radScaling)
+        double frac = 0.0;
+        FFM_TRY(plume_rad_fraction(P, &frac));
+        double *E = P->radE; const double *Qd = P->wN[9];
+        forN(P, N, [=] __device__(long c) { E[c] = frac * Qd[c]; });
+        Ee = E;
+    }
     const int nRay = (int)P->rayOmega.size();
     for (int i = 0; i < nRay; i++) {
         const double d0 = P->rayD[3 * i], d1 = P->rayD[3 * i + 1], d2 = P->rayD[3 * i + 2], omega = P->rayOmega[i];
@@ -297,11 +328,12 @@ static int radiation_correct(ffm_plume *P)
         forN(P, B, [=] __device__(long k) { const double j = (d0 * bx[k] + d1 * by[k]) + d2 * bz[k]; Jb[k] = j; f[k] = 1.0 - (j >= 0 ? 1.0 : 0.0); });
         FFM_TRY(ffm_fvm_transport(m, 0.0, nullptr, J, w, nullptr, -1, P->diag, P->upper, P->lower));
         FFM_TRY(ffm_fvm_boundary_coeffs(m, Jb, nullptr, -1, f, ref, P->zeroB, P->ic[0], P->bc[0]));
-        double *dg = P->diag; const double kO = K_ABS * omega, cS = 1.0 / M_PI * omega, kS = K_ABS * SIGMA_SB;
+        double *dg = P->diag; const double kO = KA * omega, cS = 1.0 / M_PI * omega, kS = KA * SIGMA_SB;
         forN(P, N, [=] __device__(long c) {
             dg[c] = dg[c] + V[c] * kO;
             const double t = T[c];
-            su[c] = V[c] * (cS * (kS * ((t * t) * (t * t))));
+            // 1/pi*omega*(k sigma T^4 [+ E/4]) (radiativeIntensityRay.C:286-300)
+            su[c] = Ee ? V[c] * (cS * (kS * ((t * t) * (t * t)) + Ee[c] / 4.0)) : V[c] * (cS * (kS * ((t * t) * (t * t))));
         });
         FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, su, nullptr, P->dWork, P->sWork));
         char nm[16]; snprintf(nm, sizeof(nm), "I%d", i);
@@ -332,6 +364,7 @@ static int radiation_correct(ffm_plume *P)
         const double *Ii = P->I[i];
         forN(P, N, [=] __device__(long c) { G[c] = G[c] + Ii[c] * omega; });
     }
+    P->radHaveG = true;
     return FFM_OK;
 }
 
@@ -544,7 +577,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         FFM_TRY(ffm_fvc_grad_multi(m, ns, vf, vb, ggx, ggy, ggz));
         for (int j = 0; j < ns; j++) { FFM_TRY(HX(P, ggx[j])); FFM_TRY(HX(P, ggy[j])); FFM_TRY(HX(P, ggz[j])); }
         FFM_TRY(ffm_fvm_scalar_transport_multi(m, ns, 3, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
-                                               fq, rq, gq, suq, nullptr, P->spD, P->spU, P->spL, P->spS));
+                                               fq, rq, gq, suq, nullptr, nullptr, nullptr, P->spD, P->spU, P->spL, P->spS));
         for (int j = 0; j < ns; j++) {
             const int i = sp[j];
             FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[j], P->spL[j], P->Y[i], P->spS[j]));
@@ -584,20 +617,36 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         double *ddtK = P->wN[0], *ndpdt = P->wN[5]; const double *rho = P->rho, *rho0 = P->rho0, *K = P->K, *K0 = P->K0, *dpdt = P->dpdt;
         forN(P, N, [=] __device__(long c) { ddtK[c] = rdt * (rho[c] * K[c] - rho0[c] * K0[c]); ndpdt[c] = -dpdt[c]; });
         const double *expl[3] = {ddtK, divK, ndpdt};       // fvc::ddt(rho,K) + fvc::div(phi,K) + (-dpdt), solver/YEEqn.H:89-101
+        // + radiation->Sh(thermo, he) = Ru - fvm::Sp(4 Rp T^3/Cpv, he) - Rp T^3 (T - 4 he/Cpv), Rp = 4 a sigma, Ru = a G - E
+        // (radiationModel.C:229-244, fvDOM.C Rp / Ru), E of the current Qdot
+        const double *shSu = nullptr, *shSp = nullptr;
+        if (P->radCoupled && P->radHaveG) {
+            double frac = 0.0;
+            FFM_TRY(plume_rad_fraction(P, &frac));
+            const double Rp = 4.0 * P->radA * SIGMA_SB, KA = P->radA;
+            double *su2 = P->radShSu, *sp2 = P->radShSp; const double *G = P->G, *T = P->T, *hh = P->hs, *Qd = Qdot;
+            forN(P, N, [=] __device__(long c) {
+                const double t = T[c], T3 = t * t * t;
+                const double Ru = KA * G[c] - frac * Qd[c];
+                sp2[c] = 4.0 * Rp * T3 / CP;
+                su2[c] = Ru - Rp * T3 * (t - 4.0 * hh[c] / CP);
+            });
+            shSu = su2; shSp = sp2;
+        }
         if (P->fused) {
             const double *vf[1] = {P->hs}, *vb[1] = {P->spB[0]}, *vf0[1] = {P->hs0}, *fq[1] = {P->fH}, *rq[1] = {P->refH}, *gq[1] = {P->zeroB}, *suq[1] = {Qdot};
             double *ggx[1] = {P->gM[0][0]}, *ggy[1] = {P->gM[0][1]}, *ggz[1] = {P->gM[0][2]};
-            const double *cgx[1] = {ggx[0]}, *cgy[1] = {ggy[0]}, *cgz[1] = {ggz[0]};
+            const double *cgx[1] = {ggx[0]}, *cgy[1] = {ggy[0]}, *cgz[1] = {ggz[0]}, *su2q[1] = {shSu}, *spq[1] = {shSp};
             double *dd[1] = {P->dWork}, *uu[1] = {P->upper}, *ll[1] = {P->lower}, *ss[1] = {P->sWork};
             FFM_TRY(ffm_bc_values(m, P->fH, P->refH, P->zeroB, P->hs, P->spB[0]));
             FFM_TRY(ffm_fvc_grad_multi(m, 1, vf, vb, ggx, ggy, ggz));
             FFM_TRY(HX(P, ggx[0])); FFM_TRY(HX(P, ggy[0])); FFM_TRY(HX(P, ggz[0]));
             FFM_TRY(ffm_fvm_scalar_transport_multi(m, 1, 2, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
-                                                   fq, rq, gq, suq, expl, dd, uu, ll, ss));
+                                                   fq, rq, gq, suq, su2q, spq, expl, dd, uu, ll, ss));
             FFM_TRY(solve_named(P, "h", FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->dWork, P->upper, P->lower, P->hs, P->sWork));
             FFM_TRY(HX(P, P->hs));
         } else
-        FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8));
+        FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8, shSu, shSp));
     }
     standin_thermo(P);
     { const char *st = getenv("FFM_PLUME_STOP"); if (st && atoi(st) == 2) { PL_HIP(hipStreamSynchronize(P->ctx->stream)); return FFM_OK; } }
@@ -887,6 +936,16 @@ extern "C" int ffm_plume_set_radiation(ffm_plume *P, int solverFreq, int nPhi, i
     return FFM_OK;
 }
 
+// the reference's absorption / emission model + radiation->Sh coupling (see include/ffm.h)
+extern "C" int ffm_plume_set_radiation_model(ffm_plume *P, double absorption, double Ehrr1, double Ehrr2)
+{
+    if (!P || absorption < 0 || Ehrr1 < 0 || Ehrr2 < 0) return FFM_ERR_ARG;
+    PL_HIP(hipSetDevice(P->ctx->device));
+    if (!P->radE) { P->radE = dalloc(P, P->N); P->radShSu = dalloc(P, P->N); P->radShSp = dalloc(P, P->N); }
+    if (!P->radE || !P->radShSu || !P->radShSp) return FFM_ERR_HIP;
+    P->radA = absorption; P->Ehrr1 = Ehrr1; P->Ehrr2 = Ehrr2; P->radCoupled = true;
+    return FFM_OK;
+}
 extern "C" int ffm_plume_set_solvers(ffm_plume *P, int stecklerSelection) { if (!P) return FFM_ERR_ARG; P->stecklerSolvers = stecklerSelection != 0; return FFM_OK; }
 extern "C" int ffm_plume_ncells(const ffm_plume *P) { return P ? P->nOwn : FFM_ERR_ARG; }
 extern "C" int ffm_plume_nfaces(const ffm_plume *P) { return P ? P->F : FFM_ERR_ARG; }

@@ -332,8 +332,9 @@ int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lower, const do
 int ffm_fvc_grad_multi(ffm_mesh *m, int nf, const double *const *vf, const double *const *vb, double *const *gx,
                        double *const *gy, double *const *gz);
 /* per field i: fvm::ddt(rho,vf_i) + fvm::div(phi,vf_i) [scheme 2 limitedLinear k | 3 limitedLinear01 k in [lo,hi], limiter from
- * vf_i and its gradient] - fvm::laplacian(gamma,vf_i) == su_i, minus the explicit volume terms expl3[3*i+0..2] (all three or
- * none; NULL array: none), with the boundary coefficients of the mixed condition (f_i, ref_i, refGrad_i) added:
+ * vf_i and its gradient] - fvm::laplacian(gamma,vf_i) == su_i + su2_i - fvm::Sp(sp_i, vf_i) (each nullable: a NULL array or a NULL
+ * entry), minus the explicit volume terms expl3[3*i+0..2] (all three or none; NULL array: none), with the boundary coefficients
+ * of the mixed condition (f_i, ref_i, refGrad_i) added:
  * diag_i, upper_i, lower_i, source_i are what fvMatrix::solveSegregated hands to the linear solver                       */
 int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, double k, double lo, double hi, double rDeltaT,
                                    const double *rho, const double *rho0, const double *phi_f, const double *phi_b,
@@ -341,6 +342,7 @@ int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, double k, do
                                    const double *const *vf, const double *const *gx, const double *const *gy,
                                    const double *const *gz, const double *const *vf0, const double *const *f,
                                    const double *const *ref, const double *const *refGrad, const double *const *su,
+                                   const double *const *su2, const double *const *sp,
                                    const double *const *expl3, double *const *diag, double *const *upper,
                                    double *const *lower, double *const *source);
 /* momentum source of solver/UEqn.H:5 with `div(phi,U) Gauss LUST grad(U)`: source_c = rDeltaT*rho0*U0_c*V
@@ -370,6 +372,15 @@ int ffm_plume_set_solvers(ffm_plume *plume, int stecklerSelection);
  * (0 = off, the default).  dAve[3*nRay], omega[nRay]: the rays' mean directions and solid angles as fvDOM.C:55-90 builds
  * them, or both NULL to have them built from nPhi, nTheta.  Fields "G" and "I<n>" become readable with ffm_plume_get_field. */
 int ffm_plume_set_radiation(ffm_plume *plume, int solverFreq, int nPhi, int nTheta, const double *dAve, const double *omega);
+/* The reference's absorption / emission model for those rays and their coupling into the enthalpy equation:
+ * constant absorption coefficient `absorption` [1/m] (constRadFractionEmission has aCont = 0: cases/steckler/constant/
+ * radiationProperties:42; constantAbsorptionEmission: a) and the emission E = RadFraction*Qdot of lib/thermophysicalModels/
+ * radiation/submodels/absorptionEmissionModel/constRadFractionEmission/constRadFractionEmission.C:ECont with radScaling:
+ * RadFraction = max(min(Ehrr1, Ehrr2), (mlr1*Ehrr1 + mlr2*Ehrr2)/max(SMALL, mlr1 + mlr2)), mlr = -gSum(phi) of the burner patch
+ * (cases/steckler: Ehrr1 0.5, Ehrr2 0.22).  Ray source omega/pi*(a sigma T^4 + E/4) (radiativeIntensityRay.C:286-300);
+ * EEqn gets radiation->Sh(thermo, he) = Ru - fvm::Sp(4 Rp T^3/Cpv, he) - Rp T^3 (T - 4 he/Cpv), Rp = 4 a sigma, Ru = a G - E
+ * (radiationModel.C:229-244; solver/YEEqn.H:101).  Without this call the rays keep the round-1 stand-in (a = 0.1, no E, no Sh). */
+int ffm_plume_set_radiation_model(ffm_plume *plume, double absorption, double Ehrr1, double Ehrr2);
 int ffm_plume_ncells(const ffm_plume *p);
 int ffm_plume_nfaces(const ffm_plume *p);
 int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);

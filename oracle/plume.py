@@ -143,6 +143,25 @@ class Plume:
         self.rays, self.I, self.G = [], [], np.zeros(N)
 
     # ---- thermo stand-in -------------------------------------------------------------------
+    def set_radiation_model(self, a, Ehrr1, Ehrr2):
+        """the reference's absorption / emission model and the coupling radiation->Sh(thermo, he) of solver/YEEqn.H:101:
+        constant absorption coefficient a [1/m] (constRadFractionEmission: aCont = 0; constantAbsorptionEmission: a, e) and an
+        emission E = RadFraction*Qdot with the radScaling of lib/.../constRadFractionEmission/constRadFractionEmission.C:ECont:
+        RadFraction = max(min(Ehrr1, Ehrr2), (mlr1*Ehrr1 + mlr2*Ehrr2)/max(SMALL, mlr1 + mlr2)), mlr = -gSum(phi) of the burner
+        patch(es) (both lists name the burner in cases/steckler/constant/radiationProperties:44-52).  Ray equation source
+        omega/pi*(a sigma T^4 + E/4) (radiativeIntensityRay.C:286-300); Sh = Ru - fvm::Sp(4 Rp T^3/Cp, h) - Rp T^3 (T - 4 h/Cp)
+        with Rp = 4 a sigma, Ru = a G - E (fvDOM.C:Rp/Ru, radiationModel.C:229-244)."""
+        self.rad_a, self.Ehrr = float(a), (float(Ehrr1), float(Ehrr2))
+        self.rad_coupled = True
+
+    rad_coupled, rad_a = False, K_ABS
+
+    def rad_fraction(self):
+        q = [p.name for p in self.m.patches].index("inlet")
+        mlr = -float(np.sum(self.phib[q]))
+        e1, e2 = self.Ehrr
+        return max(min(e1, e2), (mlr * e1 + mlr * e2) / max(1e-15, mlr + mlr))
+
     def set_radiation(self, solverFreq=100, nPhi=2, nTheta=4, ordered=True):
         """cases/steckler/constant/radiationProperties:32-40: nPhi 2, nTheta 4 (32 rays), solverFreq 100"""
         self.radFreq = solverFreq
@@ -305,6 +324,7 @@ class Plume:
         fuel, o2 = self.Y[2], self.Y[0]
         wFuel = self.rho * np.minimum(fuel, o2 / S_O2) / TAU            # combustion->correct()
         Qdot = wFuel * HC
+        self.Qdot_field = Qdot
         Yt = np.zeros(m.nCells)
         for i in range(len(SPECIES)):
             if i == INERT:
@@ -338,6 +358,13 @@ class Plume:
         E.add_vol(fv.surface_integrate(m, self.phi * Kf, [pb * kb for pb, kb in zip(self.phib, Kb)]))
         E.add_vol(-self.dpdt)
         E.add_su(Qdot)
+        if self.rad_coupled and self.rays and hasattr(self, "radE"):
+            # + radiation->Sh(thermo, he): Ru - fvm::Sp(4 Rp T^3/Cpv, he) - Rp T^3 (T - 4 he/Cpv)
+            Rp = 4.0 * self.rad_a * SIGMA_SB
+            T3 = self.T * self.T * self.T
+            Ru = self.rad_a * self.G - self.rad_fraction() * Qdot
+            E.diag += m.V * (4.0 * Rp * T3 / CP)
+            E.add_su(Ru - Rp * T3 * (self.T - 4.0 * self.h / CP))
         d, s = E.solve_system()
         self.h = self.sol.solve("h", "h", m, d, E.upper, E.lower, s, self.h)
         self.thermo_correct()
@@ -356,13 +383,18 @@ class Plume:
         Ib = SIGMA_SB * ((TREF * TREF) * (TREF * TREF)) / np.pi
         T4 = (self.T * self.T) * (self.T * self.T)
         self.G = np.zeros(m.nCells)
+        if self.rad_coupled:
+            self.radE = self.rad_fraction() * self.Qdot_field        # absorptionEmission->ECont(): RadFraction*Qdot
         for i, (dAve, omega) in enumerate(self.rays):
             Ji = (dAve[0] * m.Sf[:, 0] + dAve[1] * m.Sf[:, 1]) + dAve[2] * m.Sf[:, 2]
             Jib = [(dAve[0] * p.Sf[:, 0] + dAve[1] * p.Sf[:, 1]) + dAve[2] * p.Sf[:, 2] for p in m.patches]
             bc = fv.MixedBC(m, f=[1.0 - fv.pos0(jb) for jb in Jib], ref=[np.full(p.size, Ib) for p in m.patches])
             E = fv.fvm_div(m, Ji, Jib, fv.pos0(Ji), [bc])
-            E.diag += m.V * (K_ABS * omega)                              # fvm::Sp(k*omega, Ii)
-            E.add_su(1.0 / np.pi * omega * (K_ABS * SIGMA_SB * T4))
+            E.diag += m.V * (self.rad_a * omega)                         # fvm::Sp(k*omega, Ii)
+            if self.rad_coupled:
+                E.add_su(1.0 / np.pi * omega * (self.rad_a * SIGMA_SB * T4 + self.radE / 4.0))
+            else:
+                E.add_su(1.0 / np.pi * omega * (self.rad_a * SIGMA_SB * T4))
             d, s = E.solve_system()
             # direction-ordered solve: a ray whose direction has one component of the other sign is solved in the cell order of
             # the box mirrored in that axis, where its upwind matrix is triangular and DILU is exact (1 PBiCGStab iteration)

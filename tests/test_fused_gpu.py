@@ -66,6 +66,9 @@ def test_scalar_transport_multi_equals_the_operator_chain(setup, O, ctx, nf, sch
     rg = [dev(O.hash_u(88 + i, np.arange(B)) - 0.5) for i in range(nf)]
     su = [dev(O.hash_u(90 + i, np.arange(N)) - 0.3) if i % 2 == 0 else None for i in range(nf)]
     expl = [dev(O.hash_u(95 + e, np.arange(N)) - 0.5) for e in range(3)] if with_expl else None
+    # a second explicit source and an implicit one (radiation->Sh in the enthalpy equation): on the first field when expl is on
+    su2 = [dev(O.hash_u(98, np.arange(N)) - 0.2) if (with_expl and i == 0) else None for i in range(nf)]
+    sp = [dev(O.hash_u(99, np.arange(N))) if (with_expl and i == 0) else None for i in range(nf)]
     rdt = 1000.0
     # gradients of the fields (the limiter's input)
     g = [[ctx.zeros(N) for _ in range(3)] for _ in range(nf)]
@@ -74,7 +77,7 @@ def test_scalar_transport_multi_equals_the_operator_chain(setup, O, ctx, nf, sch
     D = [ctx.zeros(N) for _ in range(nf)]; S = [ctx.zeros(N) for _ in range(nf)]
     Up = [ctx.zeros(mesh.nNative) for _ in range(nf)]; Lo = [ctx.zeros(mesh.nNative) for _ in range(nf)]
     mesh.call("fvm_scalar_transport_multi", nf, scheme, 1.0, 0.0, 1.0, rdt, rho, rho0, phi, phib, gam, gamb,
-              vf, [x[0] for x in g], [x[1] for x in g], [x[2] for x in g], vf0, f, ref, rg, su,
+              vf, [x[0] for x in g], [x[1] for x in g], [x[2] for x in g], vf0, f, ref, rg, su, su2, sp,
               (expl + [None] * (3 * (nf - 1))) if with_expl else None, D, Up, Lo, S)
     V = dev(s["m"].V[s["cOrd"]])
     for i in range(nf):
@@ -89,6 +92,10 @@ def test_scalar_transport_multi_equals_the_operator_chain(setup, O, ctx, nf, sch
             src = ((src - V * expl[0]) - V * expl[1]) - V * expl[2]
         if su[i] is not None:
             src = src + V * su[i]
+        if sp[i] is not None:
+            d = d + V * sp[i]
+        if su2[i] is not None:
+            src = src + V * su2[i]
         dO, sO = ctx.zeros(N), ctx.zeros(N)
         mesh.call("fvm_add_boundary", ic, bc, d, src, None, dO, sO)
         assert np.array_equal(Up[i].cpu().numpy(), up.cpu().numpy()), i

@@ -90,3 +90,35 @@ def test_plume_with_the_fvdom_ray_sweep(O, ffm, ctx):
     own = ffm.Plume(ctx, n); own.set_radiation(solverFreq=1); own.step()
     assert rel_l2(own.field("G"), gpu.field("G")) < 1e-3          # one step vs two: the flame has barely moved
     gpu.close(); own.close()
+
+
+@pytest.mark.parametrize("a,e1,e2", [(0.0, 0.5, 0.22), (0.08, 0.3, 0.3)])
+def test_plume_with_the_reference_radiation_model_coupled_into_h(O, ffm, ctx, a, e1, e2):
+    """SURVEY 8(f) N1 with the reference's own formulas: absorption / emission of constRadFractionEmission (a = 0, E = RadFraction*Qdot
+    with radScaling over the burner's mass flow; cases/steckler/constant/radiationProperties:42-52: Ehrr1 0.5, Ehrr2 0.22) and of a
+    grey absorbing medium (a > 0), the ray source omega/pi*(a sigma T^4 + E/4) and radiation->Sh(thermo, he) in the enthalpy equation
+    (solver/YEEqn.H:101).  Every ray, G and the fields against the oracle; and the coupling is live: h differs from the uncoupled run."""
+    from oracle import plume
+    n = (12, 16, 12)
+    ref = plume.Plume(n); ref.set_radiation(solverFreq=1); ref.set_radiation_model(a, e1, e2)
+    gpu = ffm.Plume(ctx, n); gpu.set_radiation(solverFreq=1, rays=ref.rays); gpu.set_radiation_model(a, e1, e2)
+    plain = ffm.Plume(ctx, n); plain.set_radiation(solverFreq=1, rays=ref.rays)
+    for step in range(3):
+        ref.step(); gpu.step(); plain.step()
+        it_ref = [(nme, pf["nIterations"]) for nme, pf in ref.sol.log]
+        it_gpu = [(nme, pf["nIterations"]) for nme, pf in gpu.solves()]
+        assert it_ref == it_gpu, (step, it_ref, it_gpu)
+        for i in range(32):
+            assert rel_l2(gpu.field("I%d" % i), ref.I[i]) < 1e-11, (step, i)
+        assert rel_l2(gpu.field("G"), ref.G) < 1e-11
+        f = ref.fields()
+        for name in FIELDS:
+            b = f[name]
+            if np.linalg.norm(b) > 1e-30:
+                assert rel_l2(gpu.field(name), b) < 1e-8, (step, name, rel_l2(gpu.field(name), b))
+    hc, hp = gpu.field("h"), plain.field("h")
+    flame = np.abs(hp) > 0.01 * np.abs(hp).max()
+    assert np.abs(hc - hp)[flame].max() > 1e-4 * np.abs(hp).max()            # the radiative loss / gain reaches the enthalpy
+    if a == 0.0:
+        assert hc.sum() < hp.sum()                                           # Sh = -RadFraction*Qdot: a pure sink where it burns
+    gpu.close(); plain.close()
