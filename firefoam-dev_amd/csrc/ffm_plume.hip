@@ -959,7 +959,7 @@ extern "C" int ffm_plume_get_field(ffm_plume *P, const char *name, double *out)
     if (n == "rho") src = P->rho; else if (n == "p") src = P->p; else if (n == "p_rgh") src = P->p_rgh; else if (n == "T") src = P->T;
     else if (n == "h") src = P->hs; else if (n == "K") src = P->K; else if (n == "Ux") src = P->U[0]; else if (n == "Uy") src = P->U[1];
     else if (n == "Uz") src = P->U[2]; else if (n == "psi") src = P->psi; else if (n == "ph_rgh") src = P->ph_rgh;
-    else if (n == "G") src = P->G;
+    else if (n == "G") src = P->G; else if (n == "ShSu") src = P->radShSu; else if (n == "ShSp") src = P->radShSp; else if (n == "radE") src = P->radE;
     else if (n.size() > 1 && n[0] == 'I' && isdigit((unsigned char)n[1])) { const int i = atoi(n.c_str() + 1); if (i < (int)P->I.size()) src = P->I[i]; }
     else for (int i = 0; i < NSP; i++) if (n == SPN[i]) src = P->Y[i];
     if (!src) { ffm_set_error("unknown field %s", name); return FFM_ERR_ARG; }

@@ -363,8 +363,10 @@ class Plume:
             Rp = 4.0 * self.rad_a * SIGMA_SB
             T3 = self.T * self.T * self.T
             Ru = self.rad_a * self.G - self.rad_fraction() * Qdot
-            E.diag += m.V * (4.0 * Rp * T3 / CP)
-            E.add_su(Ru - Rp * T3 * (self.T - 4.0 * self.h / CP))
+            self.ShSp = 4.0 * Rp * T3 / CP
+            self.ShSu = Ru - Rp * T3 * (self.T - 4.0 * self.h / CP)
+            E.diag += m.V * self.ShSp
+            E.add_su(self.ShSu)
         d, s = E.solve_system()
         self.h = self.sol.solve("h", "h", m, d, E.upper, E.lower, s, self.h)
         self.thermo_correct()

@@ -97,7 +97,13 @@ def test_plume_with_the_reference_radiation_model_coupled_into_h(O, ffm, ctx, a,
     """SURVEY 8(f) N1 with the reference's own formulas: absorption / emission of constRadFractionEmission (a = 0, E = RadFraction*Qdot
     with radScaling over the burner's mass flow; cases/steckler/constant/radiationProperties:42-52: Ehrr1 0.5, Ehrr2 0.22) and of a
     grey absorbing medium (a > 0), the ray source omega/pi*(a sigma T^4 + E/4) and radiation->Sh(thermo, he) in the enthalpy equation
-    (solver/YEEqn.H:101).  Every ray, G and the fields against the oracle; and the coupling is live: h differs from the uncoupled run."""
+    (solver/YEEqn.H:101).  Every ray, G, the two Sh terms and the fields against the oracle; and the coupling is live: h differs from
+    the uncoupled run.
+    Tolerance of the fields: 1e-8 in the first step and for a = 0.  With absorption the ambient cells are heated from an enthalpy that
+    is rounding noise (|h| ~ 1e-17 J/kg after the first step) and limitedLinear's r = 2 (d.gradc)/(h_N - h_P) - 1 of that old field
+    sets the implicit weights that then multiply the new, O(1) J/kg enthalpies: a 1e-19 J/kg perturbation of the oracle's own h
+    moves its next step by 7e-7 (tests/test_plume_cpu.py::test_limited_weights_of_a_noise_field_are_ill_conditioned), so later
+    steps are compared at 1e-5 there -- the reference's own scheme has this sensitivity, it is not a property of either code."""
     from oracle import plume
     n = (12, 16, 12)
     ref = plume.Plume(n); ref.set_radiation(solverFreq=1); ref.set_radiation_model(a, e1, e2)
@@ -108,14 +114,20 @@ def test_plume_with_the_reference_radiation_model_coupled_into_h(O, ffm, ctx, a,
         it_ref = [(nme, pf["nIterations"]) for nme, pf in ref.sol.log]
         it_gpu = [(nme, pf["nIterations"]) for nme, pf in gpu.solves()]
         assert it_ref == it_gpu, (step, it_ref, it_gpu)
+        tol = 1e-8 if (a == 0.0 or step == 0) else 1e-5
+        rtol = 1e-11 if (a == 0.0 or step < 2) else 1e-3 * tol         # the rays see T^4 of the step before
         for i in range(32):
-            assert rel_l2(gpu.field("I%d" % i), ref.I[i]) < 1e-11, (step, i)
-        assert rel_l2(gpu.field("G"), ref.G) < 1e-11
+            assert rel_l2(gpu.field("I%d" % i), ref.I[i]) < rtol, (step, i)
+        assert rel_l2(gpu.field("G"), ref.G) < rtol
         f = ref.fields()
+        # the Sh terms are formed from the fields of the step before; the explicit one is a difference of terms of size a G
+        scale = max(np.abs(ref.ShSu).max(), a * np.abs(ref.G).max())
+        assert np.abs(gpu.field("ShSu") - ref.ShSu).max() <= (1e-12 if step < 2 else tol) * scale, step
+        assert a == 0.0 or rel_l2(gpu.field("ShSp"), ref.ShSp) < (1e-14 if step < 2 else tol), step
         for name in FIELDS:
             b = f[name]
             if np.linalg.norm(b) > 1e-30:
-                assert rel_l2(gpu.field(name), b) < 1e-8, (step, name, rel_l2(gpu.field(name), b))
+                assert rel_l2(gpu.field(name), b) < tol, (step, name, rel_l2(gpu.field(name), b))
     hc, hp = gpu.field("h"), plain.field("h")
     flame = np.abs(hp) > 0.01 * np.abs(hp).max()
     assert np.abs(hc - hp)[flame].max() > 1e-4 * np.abs(hp).max()            # the radiative loss / gain reaches the enthalpy
