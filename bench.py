@@ -51,6 +51,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     ndev = torch.cuda.device_count()
+    requested_transport = args.transport
     dev = local % max(ndev, 1)
     torch.cuda.set_device(dev)
     if world > 1 and args.transport == "rccl" and world > max(ndev, 1):
@@ -100,6 +101,9 @@ def main():
     if args.radiation_freq > 0:
         case.set_radiation(solverFreq=args.radiation_freq)
     setup_s = time.time() - t0
+    # machine-readable: what carried the halo exchange and the reductions of this run ("none": one rank), and whether that is
+    # what was asked for -- an RCCL -> host degradation must not pass for a scaling number
+    used_transport = "none" if world == 1 else transport
     N, F = n ** 3, 3 * n * n * (n - 1)          # global cells / faces
     Nloc, Floc = case.nCells, case.nFaces
 
@@ -211,8 +215,10 @@ def main():
             t1 = time.perf_counter()
             _, pf1 = Ao.solve(OO.PCG, OO.DIC, np.zeros(blk.nCells), sy["source"], tolerance=1e-6, relTol=0.0)      # p_rghFinal controls
             t1core = time.perf_counter() - t1
-            P = 8 if (os.cpu_count() or 1) >= 8 else (4 if (os.cpu_count() or 1) >= 4 else 2)
-            grid_c = {8: (2, 2, 2), 4: (2, 2, 1), 2: (2, 1, 1)}[P]
+            # P = the largest power of two <= the host's cores (at most 64 blocks: 160^3 in 40^3 blocks), one thread per block
+            hc = os.cpu_count() or 1
+            P = max(p for p in (2, 4, 8, 16, 32, 64) if p <= max(hc, 2))
+            grid_c = {64: (4, 4, 4), 32: (4, 4, 2), 16: (4, 2, 2), 8: (2, 2, 2), 4: (2, 2, 1), 2: (2, 1, 1)}[P]
             blocks, nbrRank, nbrPatch, ldus, srcs = multi.decomposed_case(H, (sn, sn, sn), grid_c)
             t1 = time.perf_counter()
             _, pfP = OO.solve_multi(ldus, nbrRank, nbrPatch, OO.PCG, OO.DIC, [np.zeros(b.nCells) for b in blocks], srcs, tolerance=1e-6, relTol=0.0)
@@ -235,6 +241,8 @@ def main():
                                       + ("RCCL halo + all-reduce" if transport == "rccl" else "halo + all-reduce through the host (gloo)"),
                        "radiation": radiation, "p_rgh_iterations_last_step": pIters, "setup_s": round(setup_s, 1),
                        "transport_solvers": "PBiCGStab+DILU" if args.solvers == "krylov" else "smoothSolver+symGaussSeidel maxIter 10"},
+            "transport": used_transport, "transport_requested": "none" if world == 1 else requested_transport,
+            "transport_degraded": bool(world > 1 and used_transport != requested_transport),
             "roofline": roofline, "roofline_dic_sweeps": sweeps, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -225,6 +225,9 @@ bool ffm_tile_amul_usable(const ffm_ldu *A);
 int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot);     // returns 1 if the dot product is left to the caller
 void ffm_tile_free(ffm_ldu *A);
 bool ffm_tile_usable(const ffm_ldu *A);
+bool ffm_tile_pcg_fusable(const ffm_ldu *A);
+int ffm_tile_pcg_fwd(ffm_ldu *A, double *rA, double *wA, int slot);
+int ffm_tile_pcg_bwd(ffm_ldu *A, const double *rA, double *wA, int slot);
 int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
 int ffm_tile_check_abort(ffm_ldu *A);
 int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b);

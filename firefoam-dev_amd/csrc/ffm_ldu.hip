@@ -226,12 +226,31 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         a.grpCell.assign(G + 1, 0);
         for (int c = 0; c < nOwn; c++) a.grpCell[grpOfOld[c] + 1]++;
         for (int g = 0; g < G; g++) a.grpCell[g + 1] += a.grpCell[g];
-        // new numbering: group-major, then level, then caller index (two stable counting passes: by level, then by group)
+        // new numbering: group-major, then level, then "edge class", then caller index (stable counting passes, least
+        // significant key first).  Edge class: the cells of a level that have a neighbour in another group come first, grouped
+        // by the lowest-ranked such group, so that the values a neighbouring tile gathers from this one (Amul, the FV row
+        // kernels) are runs of consecutive cells instead of one 128-byte line per value (a 16 x 16 column tile: the two
+        // y-edges of a level were 16 cells with stride 16)
         {
+            std::vector<int> first(nOwn);
+            std::iota(first.begin(), first.end(), 0);
+            static const bool edgeOrder = !(getenv("FFM_TILE_EDGE_ORDER") && atoi(getenv("FFM_TILE_EDGE_ORDER")) == 0);
+            if (edgeOrder && G > 1) {
+                std::vector<int> key(nOwn, G), cntK(G + 2, 0);
+                for (int f = 0; f < F; f++) {
+                    if (u[f] >= nOwn) continue;
+                    const int gl = grpOfOld[l[f]], gu = grpOfOld[u[f]];
+                    if (gl != gu) { key[l[f]] = std::min(key[l[f]], gu); key[u[f]] = std::min(key[u[f]], gl); }
+                }
+                for (int c = 0; c < nOwn; c++) cntK[key[c] + 1]++;
+                for (int i = 0; i <= G; i++) cntK[i + 1] += cntK[i];
+                for (int c = 0; c < nOwn; c++) first[cntK[key[c]]++] = c;
+            }
             std::vector<int> byLevel(nOwn), cnt(nLev + 1, 0);
             for (int c = 0; c < nOwn; c++) cnt[lev[c] + 1]++;
             for (int i = 0; i < nLev; i++) cnt[i + 1] += cnt[i];
-            for (int c = 0; c < nOwn; c++) byLevel[cnt[lev[c]]++] = c;
+            for (int i = 0; i < nOwn; i++) { const int c = first[i]; byLevel[cnt[lev[c]]++] = c; }
+            std::vector<int>().swap(first);
             std::vector<int> pos(a.grpCell.begin(), a.grpCell.end() - (G ? 1 : 0));
             if (!G) pos.clear();
             for (int i = 0; i < nOwn; i++) { const int c = byLevel[i]; const int p = pos[grpOfOld[c]]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }

@@ -123,6 +123,14 @@ __global__ void k_p_update(long n, double *__restrict__ p, const double *__restr
     else { GRID_STRIDE(i, n) p[i] = w[i] + beta * p[i]; }
 }
 
+// fused PCG: psi += alpha*pA (the update left over from the iteration before), then pA = wA + beta*pA
+__global__ void k_p_psi(long n, double *__restrict__ psi, double *__restrict__ p, const double *__restrict__ w, const double *__restrict__ scal)
+{
+    if (scal[S_SING] != 0.0) return;
+    const double alpha = scal[S_ALPHA], beta = scal[S_BETA];
+    GRID_STRIDE(i, n) { const double pi = p[i]; psi[i] += alpha * pi; p[i] = w[i] + beta * pi; }
+}
+
 // psi += alpha*pA; rA -= alpha*wA; partial sum |rA|      (PCG)
 __global__ __launch_bounds__(256) void k_pcg_xr(long n, double *__restrict__ psi, double *__restrict__ r,
                                                 const double *__restrict__ p, const double *__restrict__ w,
@@ -544,6 +552,31 @@ static int pcg(ffm_ldu *A, int precond, const Controls &k, double *psi, const do
     FFM_TRY(norm_and_initial(A, psi, source, wA, pA, rA, perf));
     if (k.minIter > 0 || !check_convergence(perf, k)) {
         FFM_TRY(ffm_precond_setup_i(A, precond));
+        if (precond == FFM_DIC && A->sweepMode == 2 && ffm_tile_pcg_fusable(A)) {
+            // The same iteration with the vector updates carried by the sweeps (ffm_tile.hip, k_tile<.., FUSE>): the residual
+            // update and its norm ride on the forward sweep of the NEXT preconditioner application (which is therefore started
+            // before the convergence check: one unused forward sweep per solve), wA.rA on the backward sweep, and psi += alpha pA
+            // is deferred into the next search-direction update.  Per-cell arithmetic unchanged.
+            do {
+                if (perf->nIterations == 0) {
+                    FFM_TRY(ffm_precond_apply_i(A, precond, false, rA, wA));
+                    FFM_TRY(ffm_k_dot(c, wA, rA, N, S_TMP0));
+                } else FFM_TRY(ffm_tile_pcg_bwd(A, rA, wA, S_TMP0));
+                FFM_TRY(finish_dot(c, OP_PCG_BETA));
+                if (perf->nIterations == 0) hipLaunchKernelGGL(k_p_update, dim3(g), dim3(256), 0, s, N, pA, wA, c->scal_d, 1);
+                else hipLaunchKernelGGL(k_p_psi, dim3(g), dim3(256), 0, s, N, psi, pA, wA, c->scal_d);
+                FFM_TRY(ffm_k_spmv_dot(A, pA, wA, S_TMP0));
+                FFM_TRY(finish_dot(c, OP_PCG_ALPHA));
+                FFM_TRY(ffm_tile_pcg_fwd(A, rA, wA, S_TMP0));
+                FFM_TRY(finish_dot(c, OP_RES));
+                FFM_TRY(ffm_read_scalars(c));
+                if (c->scal_h[S_SING] != 0.0) { perf->singular = 1; break; }
+                perf->finalResidual = c->scal_h[S_RES];
+            } while ((++perf->nIterations < k.maxIter && !check_convergence(perf, k)) || perf->nIterations < k.minIter);
+            if (!perf->singular) hipLaunchKernelGGL(k_axpy_alpha, dim3(g), dim3(256), 0, s, N, psi, pA, c->scal_d);
+            FFM_HIP(hipGetLastError());
+            return FFM_OK;
+        }
         do {
             FFM_TRY(ffm_precond_apply_i(A, precond, false, rA, wA));
             FFM_TRY(ffm_k_dot(c, wA, rA, N, S_TMP0));

@@ -481,10 +481,18 @@ __device__ __noinline__ double t_wait_value(const double *addr, unsigned int *ti
 //     list -> mailbox values, each stage read ahead, re-loading a value while it still reads the sentinel.  Its few loads
 //     have a vmcnt stream of their own, so waiting for a mailbox value never waits for the compute waves' read-ahead.
 // Every wave executes the same number of workgroup barriers: one after the prologue, one per entry of the padded loop.
-template <int MODE, bool TRACE, bool POSB = false>
+// FUSE (PCG, DIC): the vector updates on either side of the preconditioner ride on the sweeps' own streams --
+//   TM_FWD: aux = the residual, updated in place first: rA -= alpha*wA (w holds A pA on entry; PCG.C "rA[cell] -= alpha*wA[cell]"),
+//           partials[group] = sum |rA| (the residual norm of the iteration that just ended);
+//   TM_BWD: partials[group] = sum wA*rA of the finished preconditioned residual (PCG.C wArA = gSumProd(wA, rA)).
+// The per-cell arithmetic is that of k_pcg_xr / the unfused sweep; only the order of the two sums differs (as in any reduction).
+template <int MODE, bool TRACE, bool POSB = false, bool FUSE = false>
 __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const double *__restrict__ ca, const double *__restrict__ cb,
-                                                         const double *__restrict__ dg, const double *__restrict__ r, double *w, double *aux)
+                                                         const double *__restrict__ dg, const double *__restrict__ r, double *w, double *aux,
+                                                         const double *__restrict__ scal = nullptr, double *__restrict__ partials = nullptr)
 {
+    static_assert(!FUSE || MODE == TM_FWD || MODE == TM_BWD, "fused vector updates: DIC/DILU application only");
+    __shared__ double shSum[4];
     constexpr bool ASC = MODE != TM_BWD && MODE != TM_GSB;
     constexpr bool TWO = MODE == TM_RD || MODE == TM_GSF;       // a second triple of per-cell doubles (cb)
     constexpr int W = T_W;
@@ -504,7 +512,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
     const int g = __builtin_amdgcn_readfirstlane(shG);
     const unsigned gs = (unsigned)__builtin_amdgcn_readfirstlane(t.grpCell[g]);
     const int e0 = __builtin_amdgcn_readfirstlane(t.grpEnt[g]), e1 = __builtin_amdgcn_readfirstlane(t.grpEnt[g + 1]);
-    if (e0 >= e1) return;
+    if (e0 >= e1) { if (FUSE && tid == 0) partials[g] = 0.0; return; }
     if (TRACE && tid == 0) { t.trace[4 * g] = wall_clock64(); t.trace[4 * g + 3] = 0; }
 
     if (tid >= (unsigned)T_THREADS) {
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
 #undef Q_IDX
 #undef Q_MAIL
 #undef Q_PUT
-        return;
+        return;             // (the fused sums are reduced by the compute waves alone)
     }
 
     // ---------------------------------------------------------------------- compute waves
@@ -556,7 +564,10 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
     unsigned pc[T_PF], ppb[T_PF];
     bool pok[T_PF];
     uint2 pq[T_PF];
-    double pa[T_PF][W], pb[T_PF][TWO ? W : 1], pd[T_PF], pv[T_PF];
+    double pa[T_PF][W], pb[T_PF][TWO ? W : 1], pd[T_PF], pv[T_PF], pv2[FUSE ? T_PF : 1];
+    double fsum = 0.0;
+    const double fAlpha = (FUSE && MODE == TM_FWD) ? scal[S_ALPHA] : 0.0;
+    const bool fSing = (FUSE && MODE == TM_FWD) ? (scal[S_SING] != 0.0) : false;
 #define T_FETCH(k, e, R_) {                                                                             \
         const unsigned cnt_ = ((e) < e1) ? ((unsigned)R_.y & 0xFFFFu) : 0u;                              \
         const bool ok_ = tid < cnt_;                                                                     \
@@ -566,7 +577,8 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
         { const T3 v_ = *(const T3 *)((const char *)ca + o24_); pa[k][0] = v_.a; pa[k][1] = v_.b; pa[k][2] = v_.c; }     \
         if (TWO) { const T3 v_ = *(const T3 *)((const char *)cb + o24_); pb[k][0] = v_.a; pb[k][TWO ? 1 : 0] = v_.b; pb[k][TWO ? 2 : 0] = v_.c; } \
         pd[k] = *(const double *)((const char *)dg + o8_);                                               \
-        pv[k] = (MODE == TM_FWD || MODE == TM_GSF || MODE == TM_GSB) ? *(const double *)((const char *)r + o8_) : (MODE == TM_BWD ? *(const double *)((const char *)w + o8_) : 0.0); \
+        pv[k] = (FUSE && MODE == TM_FWD) ? *(const double *)((const char *)aux + o8_) : (MODE == TM_FWD || MODE == TM_GSF || MODE == TM_GSB) ? *(const double *)((const char *)r + o8_) : (MODE == TM_BWD ? *(const double *)((const char *)w + o8_) : 0.0); \
+        if (FUSE) pv2[FUSE ? k : 0] = (MODE == TM_FWD) ? *(const double *)((const char *)w + o8_) : *(const double *)((const char *)r + o8_); \
         pc[k] = cc_; pok[k] = ok_; ppb[k] = (unsigned)R_.z;                                              \
     }
 #pragma unroll
@@ -588,7 +600,12 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
                 const double d = pd[k];
                 double val;
                 if (MODE == TM_FWD) {
-                    val = d * pv[k];
+                    double ri = pv[k];
+                    if (FUSE) {
+                        if (!fSing) { ri -= fAlpha * pv2[FUSE ? k : 0]; if (pok[k]) *(double *)((char *)aux + c * 8u) = ri; }
+                        fsum += pok[k] ? fabs(ri) : 0.0;
+                    }
+                    val = d * ri;
 #pragma unroll
                     for (int s = 0; s < W; s++) { const double nv = val - d * pa[k][s] * x[s]; val = (cd[s] != T_NONE) ? nv : val; }
                 } else if (MODE == TM_BWD) {
@@ -614,6 +631,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
                     val = val / d;
                 }
                 if (pok[k]) { *(double *)((char *)w + c * 8u) = val; ring[(c - gs) & (unsigned)(T_RING - 1)] = val; }
+                if (FUSE && MODE == TM_BWD) fsum += pok[k] ? val * pv2[FUSE ? k : 0] : 0.0;
                 if (pok[k] && cd[3] != T_NONE) t_st(&t.mail[ppb[k] + cd[3]], val);
             }
             // ---- refill slot k with entry ee + T_PF
@@ -623,6 +641,14 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
     }
     if (TRACE && tid == 0) t.trace[4 * g + 2] = wall_clock64();
 #undef T_FETCH
+    if (FUSE) {             // the four compute waves (the mail wave has left): wave sums through LDS, lane 0 adds them in wave order
+        double v = fsum;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((tid & 63u) == 0u) shSum[tid >> 6] = v;
+        t_barrier();
+        if (tid == 0) partials[g] = ((shSum[0] + shSum[1]) + shSum[2]) + shSum[3];
+    }
 }
 
 // out[i] = native[src[i]] (0 where a cell has fewer than T_W neighbours): coefficients in the kernel's cell-major layout
@@ -734,6 +760,42 @@ int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, d
     return FFM_OK;
 }
 
+__global__ void k_tile_sum_partials(int n, const double *__restrict__ partials, double *__restrict__ scal, int slot);
+// PCG with DIC on a mirror-ordered tile plan: the two halves of the preconditioner application with the neighbouring vector
+// updates fused in (k_tile<.., FUSE>).  Forward: rA -= scal[S_ALPHA]*wA, scal[slot] = sum |rA| (local), wA = forward sweep of rA.
+// Backward: finishes wA, scal[slot] = sum wA*rA (local).
+bool ffm_tile_pcg_fusable(const ffm_ldu *A)
+{
+    const char *e = getenv("FFM_PCG_UNFUSED");
+    const bool off = e && atoi(e) != 0;
+    return !off && ffm_tile_usable(A) && A->tile->mirror && !A->tile->trace && A->tile->G <= 4 * RED_BLOCKS;
+}
+int ffm_tile_pcg_fwd(ffm_ldu *A, double *rA, double *wA, int slot)
+{
+    ffm_tile_plan *T = A->tile;
+    hipStream_t s = A->ctx->stream;
+    const double *cf, *cb;
+    FFM_TRY(tile_coef(A, T->f, true, &cf));
+    FFM_TRY(tile_coef(A, T->b, true, &cb));
+    tile_fill(A, T->mailAll, T->nMail);
+    hipLaunchKernelGGL((k_tile<TM_FWD, false, false, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr,
+                       (const double *)A->rD, (const double *)nullptr, wA, rA, (const double *)A->ctx->scal_d, A->ctx->partials_d);
+    hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->G, (const double *)A->ctx->partials_d, A->ctx->scal_d, slot);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+int ffm_tile_pcg_bwd(ffm_ldu *A, const double *rA, double *wA, int slot)
+{
+    ffm_tile_plan *T = A->tile;
+    hipStream_t s = A->ctx->stream;
+    const double *cb;
+    FFM_TRY(tile_coef(A, T->b, true, &cb));
+    hipLaunchKernelGGL((k_tile<TM_BWD, false, false, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr,
+                       (const double *)A->rD, rA, wA, (double *)nullptr, (const double *)A->ctx->scal_d, A->ctx->partials_d);
+    hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->G, (const double *)A->ctx->partials_d, A->ctx->scal_d, slot);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
 
 // upper*psi_old of the (owned) upper neighbours of every cell, slot by slot; +0.0 where a cell has fewer than three
 __global__ void k_tile_gs_products(long n3, const int *__restrict__ nbrCell, const double *__restrict__ coef, const double *__restrict__ psi,

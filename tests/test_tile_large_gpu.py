@@ -11,21 +11,23 @@ pytestmark = pytest.mark.gpu
 
 
 def _build(ffm, ctx, n, mode, asym):
+    """Both modes get the blockMesh numbering and renumber inside the library, which keeps the caller's face order in every
+    row sum: the two are then bitwise comparable (two ffm_renumber_levels numberings are not -- the public renumbering sorts
+    a cell's faces by the NEW neighbour labels, and the tile numbering's edge-first order within a level differs from the
+    level numbering's)."""
     H = ffm.hexmesh
     os.environ["FFM_SWEEP"] = mode
     try:
         blk = H.HexBlock((n, n, n))
         s = H.synth_p_rgh(blk)
-        cOrd, fOrd = ffm.renumber_levels(blk.nCells, blk.l, blk.u)
-        l2, u2, _ = H.apply_renumbering(blk.nCells, blk.l, blk.u, cOrd, fOrd)
-        A = ffm.lduMatrix(ctx, blk.nCells, l2, u2)
+        A = ffm.lduMatrix(ctx, blk.nCells, blk.l, blk.u)
     finally:
         os.environ.pop("FFM_SWEEP", None)
-    assert A.native_order and A.sweep_mode == (2 if mode == "tile" else 0)
+    assert A.sweep_mode == (2 if mode == "tile" else 0)
     up = s["upper"]
     lo = up * (1.0 + 0.3 * (H.hash_u(0xA1, blk.gface) - 0.5)) if asym else None
-    A.set_coeffs(s["diag"][cOrd], up[fOrd], None if lo is None else lo[fOrd])
-    return blk, s, cOrd, A
+    A.set_coeffs(s["diag"], up, lo)
+    return blk, s, np.arange(blk.nCells), A
 
 
 @pytest.mark.parametrize("asym", [False, True])
@@ -95,4 +97,37 @@ def test_tiled_sweeps_on_a_baffled_box_equal_the_serial_loops(O, ffm, ctx):
     # the baffled synthetic matrix is not diagonally dominant enough for Gauss-Seidel to contract; bitwise equality is the point
     got = A.smooth(ctx.to_device(psi0), rd, nSweeps=2, smoother="symGaussSeidel")
     assert np.array_equal(got.cpu().numpy(), Ao.gs_smooth(psi0, r, nSweeps=2, sym=True))
+    A.close()
+
+
+def test_pcg_with_the_vector_updates_fused_into_the_sweeps(O, ffm, ctx):
+    """PCG + DIC in tile mode carries rA -= alpha wA, sum|rA| (forward sweep), wA.rA (backward sweep) and psi += alpha pA (next
+    direction update) inside other kernels (ffm_solve.hip pcg(), k_tile<.., FUSE>).  Same per-cell arithmetic: the iteration
+    count and every residual equal the unfused loop's and the oracle's (PCG.C), the solutions agree to the rounding of the
+    reductions; a maxIter stop and a one-iteration solve leave psi complete (the deferred update is applied)."""
+    H = ffm.hexmesh
+    n = 96
+    blk = H.HexBlock((n, n, n)); s = H.synth_p_rgh(blk)
+    A = ffm.lduMatrix(ctx, blk.nCells, blk.l, blk.u)
+    assert A.sweep_mode == 2
+    A.set_coeffs(s["diag"], s["upper"])
+    Ao = O.Ldu(blk.nCells, blk.l, blk.u).set_coeffs(s["diag"], s["upper"])
+    src = ctx.to_device(s["source"])
+    for kw in (dict(tolerance=1e-9), dict(tolerance=1e-30, maxIter=7), dict(tolerance=1e-30, maxIter=1)):
+        res = {}
+        for unfused in ("1", "0"):
+            os.environ["FFM_PCG_UNFUSED"] = unfused
+            try:
+                psi = ctx.to_device(np.zeros(blk.nCells))
+                pf = A.solve(psi, src, "PCG", "DIC", **kw)
+            finally:
+                os.environ.pop("FFM_PCG_UNFUSED", None)
+            res[unfused] = (psi.cpu().numpy(), pf)
+        psi_o, pf_o = Ao.solve(O.PCG, O.DIC, np.zeros(blk.nCells), s["source"], **kw)
+        (xu, pu), (xf, pff) = res["1"], res["0"]
+        assert pu["nIterations"] == pff["nIterations"] == pf_o["nIterations"], (kw, pu, pff, pf_o)
+        assert abs(pff["finalResidual"] - pu["finalResidual"]) <= 1e-9 * pu["finalResidual"]
+        assert abs(pff["initialResidual"] - pu["initialResidual"]) <= 1e-12 * pu["initialResidual"]
+        assert np.linalg.norm(xf - xu) <= 1e-11 * np.linalg.norm(xu)
+        assert np.linalg.norm(xf - psi_o) <= 1e-10 * np.linalg.norm(psi_o)
     A.close()
