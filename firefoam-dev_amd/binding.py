@@ -140,6 +140,17 @@ def lib():
         "ffm_pyro_surface_T_d": ([vp], C.c_void_p),
         "ffm_pyro_phiGas_d": ([vp], C.c_void_p),
         "ffm_pyro_destroy": ([vp], C.c_int),
+        "ffm_gamg_face_area_pair_weights": ([C.c_int, hp, hp], C.c_int),
+        "ffm_gamg_create": ([vp, vp, C.c_int, C.c_int, ip, ip, hp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
+        "ffm_gamg_set_sweeps": ([vp, C.c_int, C.c_int, C.c_int], C.c_int),
+        "ffm_gamg_set_matrix_d": ([vp, dp, dp, dp], C.c_int),
+        "ffm_gamg_solve_d": ([vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.POINTER(Perf)], C.c_int),
+        "ffm_gamg_nlevels": ([vp], C.c_int),
+        "ffm_gamg_level_size": ([vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "ffm_gamg_get_level_addressing": ([vp, C.c_int, ip, ip], C.c_int),
+        "ffm_gamg_get_level_coeffs": ([vp, C.c_int, hp, hp, hp], C.c_int),
+        "ffm_gamg_coarsest_solves": ([vp, C.c_int, C.POINTER(Perf)], C.c_int),
+        "ffm_gamg_destroy": ([vp], C.c_int),
         "ffm_partition_rcb": ([C.c_int, hp, C.c_int, ip], C.c_int),
         "ffm_partition_graph": ([C.c_int, C.c_int, ip, ip, C.c_int, ip], C.c_int),
         "ffm_subdomain_create": ([C.c_int, C.c_int, ip, ip, ip, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
@@ -603,6 +614,75 @@ class Plume:
 
     def ldu_handle(self):
         return lib().ffm_plume_ldu(self.h)
+
+
+class GAMG:
+    """GAMGSolver for an lduMatrix (ffm_gamg_*): the agglomeration is built once from the addressing and the face weights
+    (faceAreaPair: weights=None and Sf given), set_matrix() agglomerates the coefficients, solve() runs V-cycles."""
+
+    def __init__(self, ctx, A, l, u, Sf=None, weights=None, nCellsInCoarsestLevel=10, mergeLevels=1):
+        self.ctx, self.A = ctx, A
+        l = np.ascontiguousarray(l, np.int32); u = np.ascontiguousarray(u, np.int32)
+        if weights is None:
+            Sf = np.ascontiguousarray(Sf, np.float64).reshape(-1, 3)
+            weights = np.empty(len(l))
+            _check(lib().ffm_gamg_face_area_pair_weights(len(l), _hp(Sf), _hp(weights)), "ffm_gamg_face_area_pair_weights")
+        weights = np.ascontiguousarray(weights, np.float64)
+        h = C.c_void_p()
+        _check(lib().ffm_gamg_create(ctx.h, A.h, A.nCells, len(l), _ip(l), _ip(u), _hp(weights), int(nCellsInCoarsestLevel), int(mergeLevels),
+                                     C.byref(h)), "ffm_gamg_create")
+        self.h = h
+        self.weights = weights
+
+    @property
+    def nLevels(self):
+        return lib().ffm_gamg_nlevels(self.h)
+
+    def level_size(self, level):
+        a, b = C.c_int(), C.c_int()
+        _check(lib().ffm_gamg_level_size(self.h, level, C.byref(a), C.byref(b)), "ffm_gamg_level_size")
+        return a.value, b.value
+
+    def level_addressing(self, level):
+        n, f = self.level_size(level)
+        l = np.empty(f, np.int32); u = np.empty(f, np.int32)
+        _check(lib().ffm_gamg_get_level_addressing(self.h, level, _ip(l), _ip(u)), "ffm_gamg_get_level_addressing")
+        return l, u
+
+    def level_coeffs(self, level):
+        n, f = self.level_size(level)
+        d = np.empty(n); up = np.empty(f); lo = np.empty(f)
+        _check(lib().ffm_gamg_get_level_coeffs(self.h, level, _hp(d), _hp(up), _hp(lo)), "ffm_gamg_get_level_coeffs")
+        return d, up, lo
+
+    def set_sweeps(self, nPreSweeps=0, nPostSweeps=2, nFinestSweeps=2):
+        _check(lib().ffm_gamg_set_sweeps(self.h, nPreSweeps, nPostSweeps, nFinestSweeps), "ffm_gamg_set_sweeps")
+
+    def set_matrix(self, diag, upper, lower=None):
+        """torch CUDA fp64 tensors in the caller's cell / face order (kept alive here)"""
+        self.ctx._ready()
+        self._coef = (diag, upper, lower)
+        _check(lib().ffm_gamg_set_matrix_d(self.h, C.c_void_p(diag.data_ptr()), C.c_void_p(upper.data_ptr()),
+                                           None if lower is None else C.c_void_p(lower.data_ptr())), "ffm_gamg_set_matrix_d")
+        return self
+
+    def solve(self, psi, source, smoother="GaussSeidel", tolerance=1e-6, relTol=0.0, minIter=0, maxIter=1000):
+        self.ctx._ready()
+        pf = Perf()
+        _check(lib().ffm_gamg_solve_d(self.h, PRECONDS[smoother], tolerance, relTol, minIter, maxIter, C.c_void_p(psi.data_ptr()),
+                                      C.c_void_p(source.data_ptr()), C.byref(pf)), "ffm_gamg_solve_d")
+        return pf.as_dict()
+
+    def coarsest_solves(self):
+        n = lib().ffm_gamg_coarsest_solves(self.h, 0, None)
+        buf = (Perf * max(n, 1))()
+        lib().ffm_gamg_coarsest_solves(self.h, n, buf)
+        return [buf[i].as_dict() for i in range(n)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ffm_gamg_destroy(self.h)
+            self.h = None
 
 
 class PyrolysisPanel:

@@ -730,6 +730,15 @@ static int solve_internal(ffm_ldu *A, int solver, int precond, const Controls &k
     return FFM_ERR_UNSUPPORTED;
 }
 
+// library-internal: vectors in the matrix's internal cell order, no final synchronisation (ffm_gamg.hip: coarsest level)
+extern "C" int ffm_solve_internal_i(ffm_ldu *A, int solver, int precond, double tol, double relTol, int minIter, int maxIter, int nSweeps,
+                                    double *psi, const double *source, ffm_perf *perf)
+{
+    memset(perf, 0, sizeof(*perf));
+    Controls k{tol, relTol, minIter, maxIter, nSweeps};
+    return solve_internal(A, solver, precond, k, psi, source, perf);
+}
+
 extern "C" int ffm_solve_d(ffm_ldu *A, int solver, int precond, double tol, double relTol, int minIter, int maxIter,
                            int nSweeps, double *psi_d, const double *source_d, ffm_perf *out)
 {

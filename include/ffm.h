@@ -407,6 +407,35 @@ const double *ffm_pyro_surface_T_d(const ffm_pyro *p);
 const double *ffm_pyro_phiGas_d(const ffm_pyro *p);
 int ffm_pyro_destroy(ffm_pyro *p);
 
+/* ------------------------------------------------------------------------ GAMG */
+/* lduMatrix::solver::New(... solver GAMG ...) as the reference's dictionaries select it: agglomerator faceAreaPair,
+ * mergeLevels 1, nCellsInCoarsestLevel 10, cacheAgglomeration true, smoother GaussSeidel for p_rgh / ph_rgh
+ * (cases/wallFireSpread2D/system/fvSolution:36-60, cases/pyrolysis1D/system/fvSolution) and DILU for Ii
+ * (cases/steckler/system/fvSolution:63-73).  Replaces OpenFOAM-dev's GAMGSolver::solve + pairGAMGAgglomeration (the
+ * algorithm is restated with its sources in oracle/gamg.py).  One rank.
+ * ffm_gamg_create: the agglomeration of the mesh behind `finest` (created from the same lowerAddr / upperAddr), built once
+ *   (cacheAgglomeration); faceWeights [nFaces] host, e.g. from ffm_gamg_face_area_pair_weights(Sf [nFaces][3]).
+ * ffm_gamg_set_matrix_d: GAMGSolver::agglomerateMatrix for every level, from device coefficient arrays in the caller's
+ *   cell / face order (lower_d null: symmetric); also sets the coefficients of `finest`.  The arrays must stay alive until
+ *   the next call.
+ * ffm_gamg_solve_d: GAMGSolver::solve; smoother FFM_GS (GaussSeidel), FFM_SYMGS, FFM_DIC or FFM_DILU; nPreSweeps 0,
+ *   nPostSweeps 2 (+1 per level, at most 4), nFinestSweeps 2 (ffm_gamg_set_sweeps), scaleCorrection on symmetric matrices,
+ *   coarsest level by PCG+DIC / PBiCGStab+DILU to the same tolerance and relTol.  psi_d / source_d: device, caller order. */
+typedef struct ffm_gamg ffm_gamg;
+int ffm_gamg_face_area_pair_weights(int nFaces, const double *Sf, double *weights);
+int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nFaces, const int *lowerAddr, const int *upperAddr,
+                    const double *faceWeights, int nCellsInCoarsestLevel, int mergeLevels, ffm_gamg **out);
+int ffm_gamg_set_sweeps(ffm_gamg *g, int nPreSweeps, int nPostSweeps, int nFinestSweeps);
+int ffm_gamg_set_matrix_d(ffm_gamg *g, const double *diag_d, const double *upper_d, const double *lower_d);
+int ffm_gamg_solve_d(ffm_gamg *g, int smoother, double tolerance, double relTol, int minIter, int maxIter,
+                     double *psi_d, const double *source_d, ffm_perf *out);
+int ffm_gamg_nlevels(const ffm_gamg *g);                                     /* coarse levels                              */
+int ffm_gamg_level_size(const ffm_gamg *g, int level, int *nCells, int *nFaces);          /* level 0: the caller's matrix */
+int ffm_gamg_get_level_addressing(const ffm_gamg *g, int level, int *lowerAddr, int *upperAddr);
+int ffm_gamg_get_level_coeffs(ffm_gamg *g, int level, double *diag, double *upper, double *lower);   /* host, level order */
+int ffm_gamg_coarsest_solves(const ffm_gamg *g, int maxN, ffm_perf *out);    /* of the last solve; returns their number    */
+int ffm_gamg_destroy(ffm_gamg *g);
+
 /* ---------------------------------------------------------------- reductions */
 /* gSum / gMin / gMax / gSumProd / gSumMag over a device field (solver/YEEqn.H:
  * 73-78,117-118; solver/phrghEqn.H:54-55).  All-reduced when a communicator is
