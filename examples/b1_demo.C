@@ -364,3 +364,36 @@ extern "C" int b1_read_function1(const char* path, const char* patch, const char
     if (massFluxFraction) *massFluxFraction = ff.massFluxFraction(patch);
     return n;
 }
+
+// `solver GAMG` through the Foam layer (cases/wallFireSpread2D/system/fvSolution:36-60): a p_rgh-shaped equation
+//     fvm::ddt(psi, p) - fvm::laplacian(gamma, p) == S        with a mixed condition on p
+// solved by fvMatrix::solve() from the dictionary entry {solver GAMG; smoother <smoother>; tolerance; relTol}; the mesh carries
+// the cached agglomeration (`gamg`, ffm_gamg_create on the same addressing).  Host arrays as in b1_demo.  Returns nIterations.
+extern "C" int b1_gamg_solve(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, ffm_gamg* gamg, double deltaT, int smoother, double tolerance, double relTol,
+                             const double* psiC, const double* gammaC, const double* p0, const double* const* bcP, const double* SC,
+                             double* pOut, double* residualsOut)
+{
+    fvMesh mesh(ctx, ldu, msh, deltaT);
+    mesh.gamg = gamg;
+    solverControls sc; sc.solver = FFM_GAMG; sc.preconditioner = smoother; sc.tolerance = tolerance; sc.relTol = relTol;
+    mesh.solvers["p_rgh"] = sc;
+    std::vector<double> zero(mesh.nBoundary, 0.0);
+    volScalarField psi("psi", mesh); psi.v.assignHost(psiC); psi.bc = makeBC(mesh, zero.data(), zero.data(), zero.data()); psi.correctBoundaryConditions();
+    psi.storeOldTime();
+    volScalarField gamma("gamma", mesh); gamma.v.assignHost(gammaC); gamma.bc = makeBC(mesh, zero.data(), zero.data(), zero.data()); gamma.correctBoundaryConditions();
+    volScalarField p_rgh("p_rgh", mesh); p_rgh.v.assignHost(p0); p_rgh.bc = makeBC(mesh, bcP[0], bcP[1], bcP[2]);
+    p_rgh.correctBoundaryConditions(); p_rgh.storeOldTime();
+    volScalarField S("S", mesh); S.v.assignHost(SC);
+    fvScalarMatrix p_rghEqn
+    (
+        fvm::ddt(psi, p_rgh) - fvm::laplacian(gamma, p_rgh)
+     ==
+        S
+    );
+    const solverPerformance sp = p_rghEqn.solve();
+    FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    p_rgh.v.toHost(pOut);
+    residualsOut[0] = sp.initialResidual; residualsOut[1] = sp.finalResidual;
+    if (sp.solverName != "GAMG") FatalError("solverName " + sp.solverName);
+    return sp.nIterations;
+}

@@ -144,6 +144,7 @@ def lib():
         "ffm_gamg_create": ([vp, vp, C.c_int, C.c_int, ip, ip, hp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
         "ffm_gamg_set_sweeps": ([vp, C.c_int, C.c_int, C.c_int], C.c_int),
         "ffm_gamg_set_matrix_d": ([vp, dp, dp, dp], C.c_int),
+        "ffm_gamg_set_matrix_native_d": ([vp, dp, dp, dp], C.c_int),
         "ffm_gamg_solve_d": ([vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, C.POINTER(Perf)], C.c_int),
         "ffm_gamg_nlevels": ([vp], C.c_int),
         "ffm_gamg_level_size": ([vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),

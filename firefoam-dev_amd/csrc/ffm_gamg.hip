@@ -228,6 +228,8 @@ struct ffm_gamg {
     bool symmetric = true, haveMatrix = false;
     int nPre = 0, nPost = 2, nFinest = 2, preMul = 1, maxPre = 4, postMul = 1, maxPost = 4;
     double *fRes = nullptr, *fCorr = nullptr, *fApsi = nullptr, *fSumA = nullptr;      // finest-level work (internal order)
+    int *faceToNative = nullptr;            // [nFaces] caller face -> native coefficient index (ffm_gamg_set_matrix_native_d)
+    double *upC = nullptr, *loC = nullptr;  // the finest coefficients gathered back to caller face order
     std::vector<ffm_perf> coarsestLog;
 };
 
@@ -243,6 +245,7 @@ extern "C" int ffm_gamg_destroy(ffm_gamg *G)
     if (!G) return FFM_OK;
     for (auto &L : G->lev) free_level(L);
     hipFree(G->fRes); hipFree(G->fCorr); hipFree(G->fApsi); hipFree(G->fSumA);
+    hipFree(G->faceToNative); hipFree(G->upC); hipFree(G->loC);
     delete G;
     return FFM_OK;
 }
@@ -370,17 +373,10 @@ extern "C" int ffm_gamg_set_sweeps(ffm_gamg *G, int nPreSweeps, int nPostSweeps,
     return FFM_OK;
 }
 
-// GAMGSolver::agglomerateMatrix for every level.  diag / upper / lower: device arrays in the caller's cell / face order (lower
-// null: symmetric); they are also handed to the finest ffm_ldu.  The caller keeps them alive until the next call.
-extern "C" int ffm_gamg_set_matrix_d(ffm_gamg *G, const double *diag_d, const double *upper_d, const double *lower_d)
+// GAMGSolver::agglomerateMatrix for every coarse level from the finest coefficients in caller order (G->lev[0].diag/upper/lower)
+static int agglomerate_levels(ffm_gamg *G)
 {
-    if (!G || !diag_d || !upper_d) return FFM_ERR_ARG;
     hipStream_t s = G->ctx->stream;
-    FFM_HIP(hipSetDevice(G->ctx->device));
-    G->symmetric = lower_d == nullptr;
-    Level &L0 = G->lev[0];
-    L0.diag = const_cast<double *>(diag_d); L0.upper = const_cast<double *>(upper_d); L0.lower = const_cast<double *>(lower_d);
-    FFM_TRY(ffm_ldu_set_coeffs_d(L0.A, diag_d, upper_d, lower_d));
     for (size_t k = 0; k + 1 < G->lev.size(); k++) {
         Level &Lf = G->lev[k], &Lc = G->lev[k + 1];
         const double *fl = G->symmetric ? nullptr : Lf.lower;
@@ -398,6 +394,43 @@ extern "C" int ffm_gamg_set_matrix_d(ffm_gamg *G, const double *diag_d, const do
     FFM_HIP(hipGetLastError());
     G->haveMatrix = true;
     return FFM_OK;
+}
+
+// diag / upper / lower: device arrays in the caller's cell / face order (lower null: symmetric); they are also handed to the
+// finest ffm_ldu.  The caller keeps them alive until the next call.
+extern "C" int ffm_gamg_set_matrix_d(ffm_gamg *G, const double *diag_d, const double *upper_d, const double *lower_d)
+{
+    if (!G || !diag_d || !upper_d) return FFM_ERR_ARG;
+    FFM_HIP(hipSetDevice(G->ctx->device));
+    G->symmetric = lower_d == nullptr;
+    Level &L0 = G->lev[0];
+    L0.diag = const_cast<double *>(diag_d); L0.upper = const_cast<double *>(upper_d); L0.lower = const_cast<double *>(lower_d);
+    FFM_TRY(ffm_ldu_set_coeffs_d(L0.A, diag_d, upper_d, lower_d));
+    return agglomerate_levels(G);
+}
+
+// The same from coefficients in the library's NATIVE layout (what fvMatrix of include/ffmFoam.H and the compiled time step
+// assemble: diag in the library's cell order, upper / lower by native face index; ffm_ldu_set_coeffs_native_d): the finest
+// matrix takes them as they are, the agglomeration reads them through the caller-face -> native map.  Needs a matrix in the
+// library's own cell order (ffm_renumber_levels).
+extern "C" int ffm_gamg_set_matrix_native_d(ffm_gamg *G, const double *diag_d, const double *upperNative_d, const double *lowerNative_d)
+{
+    if (!G || !diag_d || !upperNative_d) return FFM_ERR_ARG;
+    Level &L0 = G->lev[0];
+    if (!L0.A->identity) { ffm_set_error("GAMG: native coefficient layout needs the library's cell order (ffm_renumber_levels)"); return FFM_ERR_UNSUPPORTED; }
+    FFM_HIP(hipSetDevice(G->ctx->device));
+    hipStream_t s = G->ctx->stream;
+    if (!G->faceToNative) {
+        FFM_TRY(up(&G->faceToNative, L0.A->h_callerToNative));
+        FFM_TRY(dalloc(&G->upC, L0.nFaces)); FFM_TRY(dalloc(&G->loC, L0.nFaces));
+    }
+    G->symmetric = lowerNative_d == nullptr;
+    hipLaunchKernelGGL(k_gather_d, dim3(grid_of(L0.nFaces)), dim3(256), 0, s, (long)L0.nFaces, (const int *)G->faceToNative, upperNative_d, G->upC);
+    if (lowerNative_d) hipLaunchKernelGGL(k_gather_d, dim3(grid_of(L0.nFaces)), dim3(256), 0, s, (long)L0.nFaces, (const int *)G->faceToNative, lowerNative_d, G->loC);
+    FFM_HIP(hipGetLastError());
+    L0.diag = const_cast<double *>(diag_d); L0.upper = G->upC; L0.lower = lowerNative_d ? G->loC : nullptr;
+    FFM_TRY(ffm_ldu_set_coeffs_native_d(L0.A, diag_d, upperNative_d, lowerNative_d));
+    return agglomerate_levels(G);
 }
 
 // smoothers[k].smooth(psi, source, nSweeps) on matrix k: GaussSeidel, symGaussSeidel, DIC or DILU (psi += M^-1 (source - A psi))

@@ -45,7 +45,8 @@ typedef enum ffm_status {
 /* lduMatrix::solver run-time table keys (fvSolution `solver`), reference
  * cases/steckler/system/fvSolution:21-81, cases/wallFireSpread2D/system/fvSolution:115-152 */
 typedef enum ffm_solver {
-    FFM_PCG = 0, FFM_PBICGSTAB = 1, FFM_PBICG = 2, FFM_DIAGONAL = 3, FFM_SMOOTH = 4
+    FFM_PCG = 0, FFM_PBICGSTAB = 1, FFM_PBICG = 2, FFM_DIAGONAL = 3, FFM_SMOOTH = 4,
+    FFM_GAMG = 5      /* through ffm_gamg_* only (an agglomeration object per mesh); ffm_solve_d refuses it */
 } ffm_solver;
 /* fvSolution `preconditioner` / `smoother` */
 typedef enum ffm_precond {
@@ -427,6 +428,8 @@ int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nFaces, const
                     const double *faceWeights, int nCellsInCoarsestLevel, int mergeLevels, ffm_gamg **out);
 int ffm_gamg_set_sweeps(ffm_gamg *g, int nPreSweeps, int nPostSweeps, int nFinestSweeps);
 int ffm_gamg_set_matrix_d(ffm_gamg *g, const double *diag_d, const double *upper_d, const double *lower_d);
+/* the same from the library's native coefficient layout (ffm_ldu_set_coeffs_native_d; the fvMatrix of include/ffmFoam.H) */
+int ffm_gamg_set_matrix_native_d(ffm_gamg *g, const double *diag_d, const double *upperNative_d, const double *lowerNative_d);
 int ffm_gamg_solve_d(ffm_gamg *g, int smoother, double tolerance, double relTol, int minIter, int maxIter,
                      double *psi_d, const double *source_d, ffm_perf *out);
 int ffm_gamg_nlevels(const ffm_gamg *g);                                     /* coarse levels                              */

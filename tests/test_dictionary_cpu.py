@@ -49,7 +49,7 @@ def test_steckler_dictionaries():
         assert tuple(r[name][:5]) == (IDS["SMOOTH"], IDS["SYMGS"], 1e-6, 0.0, 10)
     for name in ("Yi", "h", "kFinal"):                                                  # "(Yi|h|k).*": $U; tolerance 1e-8;
         assert tuple(r[name][:5]) == (IDS["SMOOTH"], IDS["SYMGS"], 1e-8, 0.0, 10)
-    assert r["Ii"][0] == -1 and r["Ii"][2] == 1e-4                                      # GAMG: read, not built
+    assert tuple(r["Ii"][:4]) == (5, IDS["DILU"], 1e-4, 0.0)                            # solver GAMG (FFM_GAMG = 5); smoother DILU
     assert tuple(r["G"][:2]) == (IDS["PCG"], IDS["DIC"])
     o = 6 * len(fields)
     assert tuple(out[o:o + 6]) == (1, 2, 0, 1, 1, 5)                                     # PIMPLE 1/2/0, hydrostaticInitialization yes, 5
@@ -64,7 +64,7 @@ def test_steckler_dictionaries():
 
 def test_wallFireSpread2D_dictionaries():
     out, _ = _read("wallFireSpread2D", ["p_rgh", "U", "Yi"], ["div(phi,U)"], [])
-    assert out[0] in (IDS["PCG"], -1)                     # PCG or GAMG depending on the case variant
+    assert tuple(out[:4]) == (5, 3, 1e-5, 0.01)           # p_rgh: solver GAMG; smoother GaussSeidel (FFM_GS = 3); tolerance 1e-5; relTol 0.01
     assert tuple(out[6 * 3 + 6:6 * 3 + 8]) == (6, 0.2)    # div(phi,U) Gauss filteredLinear2V 0.2 0.05: scheme 6, k = 0.2
     assert out[-3] == 1 and out[-2] == 1                  # Gauss linear corrected / corrected
     assert abs(out[-1] - 0.9) < 1e-12 or out[-1] == 1 or out[-1] == -1      # relaxationFactors::equations (0.9 in this case)

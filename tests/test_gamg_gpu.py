@@ -92,3 +92,54 @@ def test_gamg_on_a_large_box_in_tile_mode(O, ffm, ctx):
     assert pk["nIterations"] > 3 * pf["nIterations"]
     assert rel_l2(psi.cpu().numpy(), ref.cpu().numpy()) < 1e-5
     G.close(); A.close(); B.close()
+
+
+@pytest.mark.parametrize("smoother", ["GaussSeidel", "DIC"])
+def test_solver_GAMG_through_the_foam_layer(O, ffm, ctx, smoother):
+    """fvMatrix::solve() with {solver GAMG; smoother ...; agglomerator faceAreaPair} (cases/wallFireSpread2D/system/fvSolution:36-60)
+    on a p_rgh-shaped equation written against include/ffmFoam.H (examples/b1_demo.C b1_gamg_solve): the matrix reaches the
+    multigrid in the library's native coefficient layout; iteration count, residuals and the field against the oracle's
+    assembly (oracle/fv.py) + GAMG (oracle/gamg.py) on the same numbering."""
+    import ctypes as C
+    import os
+    from oracle import fv, plume, gamg
+    m = plume.make_mesh((16, 14, 12), h=0.1)
+    N, F = m.nCells, m.nFaces
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    G = ffm.GAMG(ctx, A, l2, u2, Sf=m.Sf[fOrd])
+    hu = lambda seed, n: O.hash_u(seed, np.arange(n))
+    dt = 1e-3
+    psi = 1.17e-5 * (0.9 + 0.2 * hu(1, N)); gam = 1e-3 * (0.5 + hu(2, N)); p0 = 10.0 * (hu(3, N) - 0.5); S = 2.0 * hu(4, N) - 1.0
+    bc = fv.MixedBC(m, f=[np.full(p.size, 1.0 if p.name == "top" else 0.0) for p in m.patches],
+                    ref=[2.0 * hu(40 + q, p.size) - 1.0 for q, p in enumerate(m.patches)])
+    # the oracle's evaluation
+    gb = [gam[p.faceCells] for p in m.patches]
+    gf, gfb = fv.interpolate(m, gam, gb)
+    E = fv.fvm_ddt(m, 1.0 / dt, psi, psi, p0)
+    E -= fv.fvm_laplacian(m, gf, gfb, [bc])
+    E.add_su(S)
+    d, s = E.solve_system()
+    agg = gamg.Agglomeration(N, l2, u2, gamg.face_area_pair_weights(m.Sf[fOrd]))
+    ref = gamg.GAMGSolver(agg, d[cOrd], E.upper[fOrd], None, smoother=smoother)
+    xr, pr = ref.solve(p0[cOrd], s[cOrd], tolerance=1e-8, relTol=0.0)
+    # the Foam layer
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.__file__), "lib", "libffm_b1demo.so"))
+    dp = C.POINTER(C.c_double)
+    h = lambda a: np.ascontiguousarray(a, np.float64)
+    keep = [h(psi[cOrd]), h(gam[cOrd]), h(p0[cOrd]), h(S[cOrd])] + [h(np.concatenate(x)) for x in (bc.f, bc.ref, bc.refGrad)]
+    P = lambda a: a.ctypes.data_as(dp)
+    bcp = (dp * 3)(P(keep[4]), P(keep[5]), P(keep[6]))
+    out = np.empty(N); res = np.empty(2)
+    lib.b1_gamg_solve.restype = C.c_int
+    lib.b1_gamg_solve.argtypes = [C.c_void_p] * 4 + [C.c_double, C.c_int, C.c_double, C.c_double] + [dp] * 3 + [C.POINTER(dp)] + [dp] * 3
+    sm = {"GaussSeidel": 3, "DIC": 1}[smoother]
+    nit = lib.b1_gamg_solve(ctx.h, A.h, mesh.h, G.h, dt, sm, 1e-8, 0.0, P(keep[0]), P(keep[1]), P(keep[2]), bcp, P(keep[3]), P(out), P(res))
+    assert nit == pr["nIterations"] and nit >= 2, (nit, pr)
+    assert abs(res[0] - pr["initialResidual"]) <= 1e-10 * pr["initialResidual"]
+    assert abs(res[1] - pr["finalResidual"]) <= 1e-5 * pr["finalResidual"]
+    assert rel_l2(out, xr) < 1e-10
+    G.close(); A.close()
