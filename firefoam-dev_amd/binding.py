@@ -139,6 +139,8 @@ def lib():
         "ffm_pyro_get": ([vp, C.c_char_p, hp], C.c_int),
         "ffm_pyro_surface_T_d": ([vp], C.c_void_p),
         "ffm_pyro_phiGas_d": ([vp], C.c_void_p),
+        "ffm_pyro_couple_d": ([vp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp], C.c_int),
+        "ffm_pyro_qSurf_d": ([vp], C.c_void_p),
         "ffm_pyro_destroy": ([vp], C.c_int),
         "ffm_gamg_face_area_pair_weights": ([C.c_int, hp, hp], C.c_int),
         "ffm_gamg_create": ([vp, vp, C.c_int, C.c_int, ip, ip, hp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
@@ -701,10 +703,22 @@ class PyrolysisPanel:
         _check(lib().ffm_pyro_step(self.h, float(dt), C.c_void_p(qSurf.data_ptr()), 0 if Tback is None else 1, 0.0 if Tback is None else float(Tback)), "ffm_pyro_step")
 
     def field(self, name):
-        n = self.nCol if name in ("Tsurf", "phiGas") else self.nCol * self.nLay
-        out = np.empty(n)
+        col = name in ("Tsurf", "phiGas", "qSurf", "Twall")
+        out = np.empty(self.nCol if col else self.nCol * self.nLay)
         _check(lib().ffm_pyro_get(self.h, name.encode(), _hp(out)), "ffm_pyro_get")
-        return out if name in ("Tsurf", "phiGas") else out.reshape(self.nCol, self.nLay)
+        return out if col else out.reshape(self.nCol, self.nLay)
+
+    def couple(self, Tgas_cell, kappaDelta, qin, emissivity, absorptivity, rho_b, magSf, nf, hocSolid, qFuel, refT, U, map=None):
+        """the mapped patch conditions (ffm_pyro_couple_d); all torch CUDA tensors (nf, U: lists of three); map: int32 tensor or None"""
+        self.ctx._ready()
+        P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _check(lib().ffm_pyro_couple_d(self.h, P(map), P(Tgas_cell), P(kappaDelta), P(qin), float(emissivity), float(absorptivity), P(rho_b), P(magSf),
+                                       P(nf[0]), P(nf[1]), P(nf[2]), float(hocSolid), float(qFuel), P(refT), P(U[0]), P(U[1]), P(U[2])), "ffm_pyro_couple_d")
+
+    def step_coupled(self, dt, Tback=None):
+        """one step with the heat flux of the last couple()"""
+        self.ctx._ready()
+        _check(lib().ffm_pyro_step(self.h, float(dt), C.c_void_p(lib().ffm_pyro_qSurf_d(self.h)), 0 if Tback is None else 1, 0.0 if Tback is None else float(Tback)), "ffm_pyro_step")
 
     def close(self):
         if getattr(self, "h", None):

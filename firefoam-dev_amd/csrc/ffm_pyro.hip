@@ -27,6 +27,7 @@ struct ffm_pyro {
     PyroConst k;
     double *rho = nullptr, *Yw = nullptr, *T = nullptr, *h = nullptr;      // [nLay][nCol]
     double *Tsurf = nullptr, *phiGas = nullptr;                               // [nCol]
+    double *qSurf = nullptr, *Twall = nullptr;                                // [nCol] coupled heat flux / wall temperature (ffm_pyro_couple_d)
 };
 
 template <int NL>
@@ -117,6 +118,9 @@ extern "C" int ffm_pyro_create(ffm_ctx *ctx, int nCol, int nLay, double thicknes
     FFM_HIP(hipMemset(P->phiGas, 0, sizeof(double) * nCol));
     std::vector<double> ts(nCol, T0);
     FFM_HIP(hipMemcpy(P->Tsurf, ts.data(), sizeof(double) * nCol, hipMemcpyHostToDevice));
+    FFM_HIP(hipMalloc((void **)&P->qSurf, sizeof(double) * nCol)); FFM_HIP(hipMalloc((void **)&P->Twall, sizeof(double) * nCol));
+    FFM_HIP(hipMemset(P->qSurf, 0, sizeof(double) * nCol));
+    FFM_HIP(hipMemcpy(P->Twall, ts.data(), sizeof(double) * nCol, hipMemcpyHostToDevice));
     *out = P;
     return FFM_OK;
 }
@@ -159,18 +163,66 @@ extern "C" int ffm_pyro_get(ffm_pyro *P, const char *name, double *out)
         for (int c = 0; c < P->nCol; c++) for (int i = 0; i < P->nLay; i++) out[(size_t)c * P->nLay + i] = v[(size_t)i * P->nCol + c];
         return FFM_OK;
     }
-    const double *col = n == "Tsurf" ? P->Tsurf : n == "phiGas" ? P->phiGas : nullptr;
+    const double *col = n == "Tsurf" ? P->Tsurf : n == "phiGas" ? P->phiGas : n == "qSurf" ? P->qSurf : n == "Twall" ? P->Twall : nullptr;
     if (!col) { ffm_set_error("ffm_pyro_get: unknown field %s", name); return FFM_ERR_ARG; }
     FFM_HIP(hipMemcpy(out, col, sizeof(double) * P->nCol, hipMemcpyDeviceToHost));
     return FFM_OK;
 }
+// The mapped patch conditions between the gas region's wall patch and the panel (lib/fvPatchFieldsPyrolysis), one thread per
+// column; column i is coupled to gas boundary face map[i] (mappedPatchBase::distribute of an extruded region: a permutation).
+//   solid side, T  turbulentTemperatureRadiationQinCoupledMixedFvPatchScalarField::updateCoeffs (:176-283, radiative branch):
+//                  nbrTotalFlux = nbrKDelta (T_s,cell - T_g,cell) - a qin + e sigma T_w^4; refGrad = -nbrTotalFlux/kappa_s, f = 0
+//                  -> qSurf = -nbrTotalFlux (what ffm_pyro_step takes), T_w = T_s,cell + refGrad dx/2 (T_w^4 from the previous T_w)
+//   gas side, T    the same class, fluid branch (:285-292): refValue = T_s,cell, valueFraction 1
+//   gas side, U    flowRateInletVelocityPyrolysisCoupledFvPatchVectorField::updateCoeffs (:127-248):
+//                  phi = phiGas (hocSolid rho_v - hocChar rho_char)/(rho_v - rho_char)/qFuel; U_b = n (-phi/magSf)/rho_b
+__global__ void k_pyro_couple(int nCol, PyroConst k, const int *__restrict__ map, const double *__restrict__ Ts_, const double *__restrict__ Yw_,
+                              const double *__restrict__ phiGas, double *__restrict__ Twall, double *__restrict__ qSurf,
+                              const double *__restrict__ Tg, const double *__restrict__ kDelta, const double *qin, double emis, double absorp,
+                              const double *__restrict__ rhob, const double *__restrict__ magSf, const double *__restrict__ nx,
+                              const double *__restrict__ ny, const double *__restrict__ nz, double hocPyr, double qFuel,
+                              double *__restrict__ refT, double *__restrict__ Ux, double *__restrict__ Uy, double *__restrict__ Uz)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nCol) return;
+    const int b = map ? map[c] : c;
+    const double Ts = Ts_[c], Yw = Yw_[c];                      // layer 0
+    const double kap = Yw * k.kW + (1.0 - Yw) * k.kC;
+    const double tw = Twall[c];
+    const double conv = kDelta[b] * (Ts - Tg[b]);
+    const double total = conv - absorp * (qin ? qin[b] : 0.0) + emis * 5.670367e-08 * ((tw * tw) * (tw * tw));
+    const double refGrad = -total / kap;
+    qSurf[c] = -total;
+    Twall[c] = Ts + refGrad / (2.0 / k.dx);
+    refT[b] = Ts;
+    const double phi = phiGas[c] * hocPyr / qFuel;
+    const double U = (-phi / magSf[b]) / rhob[b];
+    Ux[b] = nx[b] * U; Uy[b] = ny[b] * U; Uz[b] = nz[b] * U;
+}
+
+extern "C" int ffm_pyro_couple_d(ffm_pyro *P, const int *map_d, const double *TgasCell_d, const double *kappaDelta_d, const double *qin_d,
+                                 double emissivity, double absorptivity, const double *rho_b_d, const double *magSf_d, const double *nfx_d,
+                                 const double *nfy_d, const double *nfz_d, double hocSolid, double qFuel, double *refT_d, double *Ux_d, double *Uy_d,
+                                 double *Uz_d)
+{
+    if (!P || !TgasCell_d || !kappaDelta_d || !rho_b_d || !magSf_d || !nfx_d || !nfy_d || !nfz_d || !refT_d || !Ux_d || !Uy_d || !Uz_d || !(qFuel > 0)) return FFM_ERR_ARG;
+    FFM_HIP(hipSetDevice(P->ctx->device));
+    const double hocPyr = (hocSolid * P->k.rhoW - 32.8e6 * P->k.rhoC) / (P->k.rhoW - P->k.rhoC);
+    hipLaunchKernelGGL(k_pyro_couple, dim3((P->nCol + 255) / 256), dim3(256), 0, P->ctx->stream, P->nCol, P->k, map_d, (const double *)P->T,
+                       (const double *)P->Yw, (const double *)P->phiGas, P->Twall, P->qSurf, TgasCell_d, kappaDelta_d, qin_d, emissivity, absorptivity,
+                       rho_b_d, magSf_d, nfx_d, nfy_d, nfz_d, hocPyr, qFuel, refT_d, Ux_d, Uy_d, Uz_d);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+extern "C" const double *ffm_pyro_qSurf_d(const ffm_pyro *P) { return P ? P->qSurf : nullptr; }
+
 extern "C" const double *ffm_pyro_surface_T_d(const ffm_pyro *P) { return P ? P->Tsurf : nullptr; }
 extern "C" const double *ffm_pyro_phiGas_d(const ffm_pyro *P) { return P ? P->phiGas : nullptr; }
 extern "C" int ffm_pyro_destroy(ffm_pyro *P)
 {
     if (!P) return FFM_OK;
     hipStreamSynchronize(P->ctx->stream);
-    hipFree(P->rho); hipFree(P->Yw); hipFree(P->T); hipFree(P->h); hipFree(P->Tsurf); hipFree(P->phiGas);
+    hipFree(P->rho); hipFree(P->Yw); hipFree(P->T); hipFree(P->h); hipFree(P->Tsurf); hipFree(P->phiGas); hipFree(P->qSurf); hipFree(P->Twall);
     delete P;
     return FFM_OK;
 }

@@ -406,6 +406,17 @@ int ffm_pyro_step(ffm_pyro *p, double deltaT, const double *qSurf_d, int backFix
 int ffm_pyro_get(ffm_pyro *p, const char *name, double *out);
 const double *ffm_pyro_surface_T_d(const ffm_pyro *p);
 const double *ffm_pyro_phiGas_d(const ffm_pyro *p);
+/* The mapped patch conditions between the gas region's wall patch and the panel (lib/fvPatchFieldsPyrolysis), column i <->
+ * gas boundary face map_d[i] (null: i).  Replaces turbulentTemperatureRadiationQinCoupledMixedFvPatchScalarField::updateCoeffs
+ * (:176-292; solid side: qSurf = -(kappaDelta_gas (T_s,cell - T_g,cell) - a qin + e sigma T_w^4), wall value from refGrad;
+ * gas side: refValue = T_s,cell, valueFraction 1 -> refT_d) and flowRateInletVelocityPyrolysisCoupledFvPatchVectorField::
+ * updateCoeffs (:127-248; U_b = n (-phiGas hocPyr/qFuel/magSf)/rho_b -> Ux_d, Uy_d, Uz_d).  Gas-side arrays are indexed by
+ * boundary face; only the mapped entries of the outputs are written.  ffm_pyro_qSurf_d is what ffm_pyro_step then takes. */
+int ffm_pyro_couple_d(ffm_pyro *p, const int *map_d, const double *TgasCell_d, const double *kappaDelta_d, const double *qin_d,
+                      double emissivity, double absorptivity, const double *rho_b_d, const double *magSf_d,
+                      const double *nfx_d, const double *nfy_d, const double *nfz_d, double hocSolid, double qFuel,
+                      double *refT_d, double *Ux_d, double *Uy_d, double *Uz_d);
+const double *ffm_pyro_qSurf_d(const ffm_pyro *p);
 int ffm_pyro_destroy(ffm_pyro *p);
 
 /* ------------------------------------------------------------------------ GAMG */

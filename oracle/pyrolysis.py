@@ -104,6 +104,33 @@ class Panel:
         return self.T[:, 0].copy()
 
 
+SIGMA_SB = 5.670367e-08          # constant::physicoChemical::sigma
+HOC_CHAR = 32.8e6               # flowRateInletVelocityPyrolysisCoupledFvPatchVectorField.C:204 "hocChar"
+
+
+def couple(panel, Twall, Tgas_cell, kappaDelta_gas, qin, emissivity, absorptivity, rho_b, magSf, nf, hocSolid, qFuel):
+    """The mapped patch conditions between the gas region's wall patch and the panel (lib/fvPatchFieldsPyrolysis), face by face
+    (column i <-> gas boundary face i; the caller applies its map):
+      solid side, T   turbulentTemperatureRadiationQinCoupledMixedFvPatchScalarField::updateCoeffs (:176-283), radiative branch:
+                      nbrConvFlux = nbrKDelta (T_s,cell - T_g,cell); nbrTotalFlux = nbrConvFlux - a qin + e sigma T_w^4;
+                      refGrad = -nbrTotalFlux/kappa_s, valueFraction 0  ->  heat flux INTO the solid q = -nbrTotalFlux and the new
+                      wall value T_w = T_s,cell + refGrad/deltaCoeffs_s (deltaCoeffs_s = 2/dx), T_w^4 from the previous wall value
+      gas side, T     the same class, fluid branch (:285-292): refValue = the solid's cell temperature, valueFraction 1
+      gas side, U     flowRateInletVelocityPyrolysisCoupledFvPatchVectorField::updateCoeffs (:127-248): hocPyr = (hocSolid rho_v -
+                      hocChar rho_char)/(rho_v - rho_char); phi = phiGas hocPyr/qFuel; U_b = n (-phi/magSf)/rho_b
+    Returns (qSurf [nCol], Twall_new [nCol], refT_gas [nCol], U_b [nCol][3])."""
+    Ts = panel.T[:, 0]
+    kap = panel.kappa()[:, 0]
+    conv = kappaDelta_gas * (Ts - Tgas_cell)
+    total = conv - absorptivity * qin + emissivity * SIGMA_SB * ((Twall * Twall) * (Twall * Twall))
+    refGrad = -total / kap
+    Tw = Ts + refGrad / (2.0 / panel.dx)
+    hocPyr = (hocSolid * WOOD.rho - HOC_CHAR * CHAR.rho) / (WOOD.rho - CHAR.rho)
+    phi = panel.massGas * hocPyr / qFuel
+    U = (-phi / magSf) / rho_b
+    return -total, Tw, Ts.copy(), nf * U[:, None]
+
+
 def thomas(lower, diag, upper, rhs):
     """batched Thomas algorithm along axis 1 (lower[:, 0] and upper[:, -1] unused)"""
     n = diag.shape[1]

@@ -53,3 +53,19 @@ def test_pyrolysis_mass_balance_and_char_front():
         if nCol > 1:
             assert lost[-1] > lost[0]                        # more heat, more pyrolysate
         assert np.isfinite(P.T).all() and P.T.max() < 2000.0 and P.Yw.min() < 0.5
+
+
+def test_coupled_patch_conditions_balance():
+    """oracle couple(): the heat flux handed to the solid is what the mixed condition's gradient carries (q = kappa_s refGrad),
+    the wall value follows from that gradient over half a layer, and with equal gas / solid temperatures, no irradiation and
+    zero emissivity nothing flows."""
+    from oracle import pyrolysis as PY
+    p = PY.Panel(5, 8, thickness=0.0127, area=0.01, T0=400.0)
+    nf = np.tile(np.array([[-1.0, 0.0, 0.0]]), (5, 1))
+    one = np.ones(5)
+    q, Tw, refT, U = PY.couple(p, 400.0 * one, 400.0 * one, 10.0 * one, 0.0 * one, 0.0, 0.0, one, 0.01 * one, nf, 1.66e7, 4.6e7)
+    assert np.all(q == 0) and np.all(Tw == 400.0) and np.all(refT == 400.0) and np.all(U == 0)
+    q, Tw, refT, U = PY.couple(p, 400.0 * one, 900.0 * one, 10.0 * one, 3e4 * one, 0.9, 0.8, one, 0.01 * one, nf, 1.66e7, 4.6e7)
+    expect = 10.0 * (900.0 - 400.0) + 0.8 * 3e4 - 0.9 * PY.SIGMA_SB * 400.0 ** 4
+    assert np.allclose(q, expect, rtol=1e-14)
+    assert np.allclose((Tw - 400.0) * (2.0 / p.dx) * p.kappa()[:, 0], q, rtol=1e-12)

@@ -31,3 +31,50 @@ def test_pyrolysis_panel_matches_oracle(ffm, ctx, nCol, nLay, back):
     lost = m0 - (dev.field("rho") * ref.V).sum(axis=1)
     assert np.allclose(lost, gas, rtol=1e-9)
     dev.close()
+
+
+def test_gas_side_coupling_of_the_pyrolysis_panel(ffm, ctx):
+    """The mapped patch conditions of lib/fvPatchFieldsPyrolysis between a gas wall patch and the panel (ffm_pyro_couple_d):
+    a fire-exposed wall of 300 columns mapped onto a gas patch through a permutation, incident radiation qin and a hot gas cell
+    layer; per step couple() -> step_coupled() on the device against oracle couple() -> step().  Heat flux into the solid, wall
+    temperature, the gas-side reference temperature and inlet velocity against the oracle; the pyrolysate leaves as an inflow of
+    the gas region (U.n < 0, mass flux = phiGas hocPyr/qFuel); only the mapped patch faces are written."""
+    import torch
+    from oracle import pyrolysis as PY
+    nCol, B = 300, 420                                          # the gas patch's faces are a subset of a larger boundary
+    ref = PY.Panel(nCol, 8, thickness=0.0127, area=0.01)
+    dev = ffm.PyrolysisPanel(ctx, nCol, 8, thickness=0.0127, area=0.01)
+    rng = np.random.default_rng(3)
+    fmap = rng.permutation(B)[:nCol].astype(np.int32)
+    i = np.arange(B)
+    Tg = 600.0 + 500.0 * np.sin(0.05 * i) ** 2; kD = 8.0 + 4.0 * np.cos(0.11 * i) ** 2; qin = 4.0e4 * (1.0 + 0.5 * np.sin(0.023 * i))
+    rhob = 0.4 + 0.3 * np.cos(0.07 * i) ** 2; magSf = np.full(B, 0.01)
+    nf = np.stack([np.full(B, -1.0), np.zeros(B), np.zeros(B)], axis=1)
+    e, a, hocSolid, qFuel = 0.9, 0.85, 1.66e7, 4.6e7                       # cases/wallFireSpread2D/0/U:62 hocSolid; propane qFuel
+    D = lambda x: ctx.to_device(np.ascontiguousarray(x, np.float64))
+    d = dict(Tg=D(Tg), kD=D(kD), qin=D(qin), rhob=D(rhob), magSf=D(magSf), nf=[D(nf[:, c]) for c in range(3)],
+             refT=D(np.full(B, -1.0)), U=[D(np.full(B, 7.0)) for _ in range(3)], map=torch.from_numpy(fmap).cuda())
+    Tw = np.full(nCol, 298.15)
+    dt = 0.05
+    for step in range(400):
+        q, Tw, refT, U = PY.couple(ref, Tw, Tg[fmap], kD[fmap], qin[fmap], e, a, rhob[fmap], magSf[fmap], nf[fmap], hocSolid, qFuel)
+        ref.step(dt, q)
+        dev.couple(d["Tg"], d["kD"], d["qin"], e, a, d["rhob"], d["magSf"], d["nf"], hocSolid, qFuel, d["refT"], d["U"], map=d["map"])
+        dev.step_coupled(dt)
+        if step % 50 == 0 or step == 399:
+            assert np.abs(dev.field("qSurf") - q).max() <= 1e-11 * np.abs(q).max(), step
+            assert np.abs(dev.field("Twall") - Tw).max() <= 1e-11 * Tw.max(), step
+            rT = d["refT"].cpu().numpy(); Ud = np.stack([u.cpu().numpy() for u in d["U"]], axis=1)
+            assert np.abs(rT[fmap] - refT).max() <= 1e-11 * refT.max()
+            assert np.abs(Ud[fmap] - U).max() <= 1e-10 * max(np.abs(U).max(), 1e-300)
+            other = np.setdiff1d(np.arange(B), fmap)
+            assert np.all(rT[other] == -1.0) and np.all(Ud[other] == 7.0)
+            assert np.abs(dev.field("T") - ref.T).max() <= 1e-10 * ref.T.max()
+    assert ref.Yw[:, 0].min() < 0.9 and ref.massGas.max() > 0                 # the exposed layer pyrolyses
+    dev.couple(d["Tg"], d["kD"], d["qin"], e, a, d["rhob"], d["magSf"], d["nf"], hocSolid, qFuel, d["refT"], d["U"], map=d["map"])   # of the final state
+    Ud = np.stack([u.cpu().numpy() for u in d["U"]], axis=1)
+    inflow = (Ud[fmap] * nf[fmap]).sum(axis=1)
+    assert inflow.min() < 0 and inflow.max() <= 0                            # into the gas region
+    hocPyr = (hocSolid * PY.WOOD.rho - PY.HOC_CHAR * PY.CHAR.rho) / (PY.WOOD.rho - PY.CHAR.rho)
+    assert np.allclose(-inflow * rhob[fmap] * magSf[fmap], dev.field("phiGas") * hocPyr / qFuel, rtol=1e-12, atol=0)
+    dev.close()
