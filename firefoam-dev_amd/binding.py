@@ -256,17 +256,20 @@ def tile_hint_from_centres(C_, tileCells=0):
     return hint
 
 
-def renumber_levels(nCells, lowerAddr, upperAddr, groupHint=None):
-    """The library's preferred cell order (pure host code in libffm): returns (newToOldCell, newToOldFace)."""
+def renumber_levels(nCells, lowerAddr, upperAddr, groupHint=None, nGhost=0):
+    """The library's preferred cell order (pure host code in libffm): returns (newToOldCell, newToOldFace).
+    nGhost > 0: nCells owned cells followed by nGhost ghost cells (ffm_renumber_levels_ext; the ghosts keep their places)."""
     l = np.ascontiguousarray(lowerAddr, np.int32)
     u = np.ascontiguousarray(upperAddr, np.int32)
-    c2 = np.empty(nCells, np.int32)
+    c2 = np.empty(nCells + nGhost, np.int32)
     f2 = np.empty(len(l), np.int32)
-    if groupHint is None:
+    if nGhost and groupHint is None:
+        _check(lib().ffm_renumber_levels_ext(nCells, nGhost, len(l), _ip(l), _ip(u), _ip(c2), _ip(f2)), "ffm_renumber_levels_ext")
+    elif groupHint is None:
         _check(lib().ffm_renumber_levels(nCells, len(l), _ip(l), _ip(u), _ip(c2), _ip(f2)), "ffm_renumber_levels")
     else:
         gh = np.ascontiguousarray(groupHint, np.int32)
-        _check(lib().ffm_renumber_hint(nCells, 0, len(l), _ip(l), _ip(u), _ip(gh), _ip(c2), _ip(f2)), "ffm_renumber_hint")
+        _check(lib().ffm_renumber_hint(nCells, nGhost, len(l), _ip(l), _ip(u), _ip(gh), _ip(c2), _ip(f2)), "ffm_renumber_hint")
     return c2, f2
 
 

@@ -1,5 +1,8 @@
 // ffm_internal.hpp -- private structures of libffm.so (not part of the C ABI).
 #pragma once
+#include <ctime>
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -193,6 +196,13 @@ struct ffm_ldu {
     std::vector<SweepGraphKey> graphOrder;         // insertion order, for the cap
 };
 
+// FFM_TIMING=1: wall time of the host-side set-up stages to stderr
+struct FfmStageTimer {
+    const char *what; double t0; bool on;
+    static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+    explicit FfmStageTimer(const char *w) : what(w), t0(now()), on(getenv("FFM_TIMING") != nullptr) {}
+    ~FfmStageTimer() { if (on) fprintf(stderr, "ffm timing: %-28s %.2f s\n", what, now() - t0); }
+};
 struct LduView;
 LduView ffm_view(const ffm_ldu *A);
 // ---- internal helpers shared between translation units -------------------

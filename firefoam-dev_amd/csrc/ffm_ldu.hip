@@ -458,7 +458,8 @@ static int ldu_create_impl(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int 
 {
     const int N = nOwn + nGhost;
     LduAnalysis a;
-    FFM_TRY(analyse(N, nOwn, F, l, u, true, false, a, groupHint, forceMode));
+    { FfmStageTimer tm_("ldu_create: analyse"); FFM_TRY(analyse(N, nOwn, F, l, u, true, false, a, groupHint, forceMode)); }
+    FfmStageTimer tmRest_("ldu_create: layout+upload+tile");
     ffm_ldu *A = new ffm_ldu();
     A->ctx = ctx; A->nCells = N; A->nOwned = nOwn; A->nFaces = F; A->globalCells = nOwn;
     A->identity = a.identity; A->bwdContig = a.bwdContig;

@@ -679,6 +679,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
         if ((lo[d] == 0) != (nbrRank[2 * d] < 0) || (hi[d] == G) != (nbrRank[2 * d + 1] < 0)) { ffm_set_error("plume block: neighbour ranks inconsistent with the block position"); return FFM_ERR_ARG; }
     }
     PL_HIP(hipSetDevice(ctx->device));
+    FfmStageTimer tmAll_("plume_create: total");
     ffm_plume *P = new ffm_plume();
     P->ctx = ctx; P->nx = nx; P->ny = ny; P->nz = nz; P->h = h; P->dt = dt; P->rdt = 1.0 / dt;
     P->tight = getenv("FFM_PLUME_TIGHT") != nullptr;      // tests only: see ffm_plume_set_tight
@@ -719,7 +720,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     std::vector<int> hint(nOwn);
     for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) hint[cellOf(i, j, k)] = (j / tileEdge) + 32768 * (k / tileEdge);
     std::vector<int> c2(N), f2(F);
-    FFM_TRY(ffm_renumber_hint((int)nOwn, (int)nGhost, F, l.data(), u.data(), hint.data(), c2.data(), f2.data()));
+    { FfmStageTimer tm_("plume_create: renumber_hint"); FFM_TRY(ffm_renumber_hint((int)nOwn, (int)nGhost, F, l.data(), u.data(), hint.data(), c2.data(), f2.data())); }
     P->newToOld = c2;
     std::vector<int> oldToNew(N);
     for (long c = 0; c < N; c++) oldToNew[c2[c]] = (int)c;
@@ -728,6 +729,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     {
         std::vector<int> hintNew(nOwn);
         for (long c = 0; c < nOwn; c++) hintNew[c] = hint[c2[c]];
+        FfmStageTimer tm_("plume_create: ldu_create");
         FFM_TRY(ffm_ldu_create_hint(ctx, (int)nOwn, (int)nGhost, F, l2.data(), u2.data(), hintNew.data(), &P->A));
     }
     if (!P->A->identity) { ffm_set_error("plume: renumbered mesh is not native"); return FFM_ERR_ADDR; }
@@ -788,7 +790,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
         pD[p].assign(sizes[p], 2.0 / h); pSf[p] = pSflat[p].data(); pDel[p] = pD[p].data();
     }
     P->B = Btot;
-    FFM_TRY(ffm_mesh_create(P->A, V.data(), C.data(), Sf.data(), magSf.data(), wgt.data(), del.data(), 4, sizes, fcs, pSf, pDel, &P->mesh));
+    { FfmStageTimer tm_("plume_create: mesh_create"); FFM_TRY(ffm_mesh_create(P->A, V.data(), C.data(), Sf.data(), magSf.data(), wgt.data(), del.data(), 4, sizes, fcs, pSf, pDel, &P->mesh)); }
     {
         // face centres (LUST correction): owner's centre + half a cell towards the neighbour
         std::vector<double> Cf(3 * (size_t)F);

@@ -410,9 +410,10 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
     for (int g = 0; g < T->G; g++) for (int c = grpCell[g]; c < grpCell[g + 1]; c++) grpOfCell[c] = g;
     bool ok = true;
     std::vector<int4> recF;
-    FFM_TRY(build_dir(A, true, lev, grpCell, grpOfCell, T->f, ok, &recF, &T->grpEntHost));
+    { FfmStageTimer tm_("tile: forward plan"); FFM_TRY(build_dir(A, true, lev, grpCell, grpOfCell, T->f, ok, &recF, &T->grpEntHost)); }
     T->mirror = bwdCells == nullptr;
     if (ok) {
+        FfmStageTimer tm_("tile: backward plan");
         if (T->mirror) FFM_TRY(build_dir(A, false, bl, grpCell, grpOfCell, T->b, ok));
         else { FFM_TRY(build_dir_pos(A, bl, grpCell, grpOfCell, *bwdCells, T->b, ok)); T->cellOf = A->bwdCells; }
     }
@@ -421,6 +422,7 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
         T->nMail = (long)T->f.nPub + T->b.nPub + 2;
         FFM_HIP(hipMalloc((void **)&T->mailAll, sizeof(double) * T->nMail));
         T->f.mail = T->mailAll; T->b.mail = T->mailAll + T->f.nPub + 1;
+        FfmStageTimer tm_("tile: amul plan");
         FFM_TRY(build_amul(A, grpOfCell, recF));
         // the Gauss-Seidel sweeps need the cell-space tables: without them the matrix gets level-scheduled sweeps
         if (!T->gsTables) T->usable = false;

@@ -1,0 +1,59 @@
+"""SURVEY 8(b)+(e): the source-level Foam layer (include/ffmFoam.H) on a DECOMPOSED mesh.  examples/b1_demo.C -- rhoEqn, one
+YiEqn with relax, UEqn with LUST and the reconstructed buoyancy / pressure source, one pEqn corrector with constrainHbyA,
+constrainPressure, ddtCorr, flux and the velocity correction -- runs unchanged on every rank's sub-domain: processor boundaries are
+ghost cells + cut faces (ffm_ldu_create_ext), each operator that gathers neighbour-cell values refreshes the ghost entries of its
+result (fvMesh::haloRefresh, OpenFOAM's processorFvPatchField evaluate), reductions run over owned cells, the solvers exchange
+and all-reduce through the communicator.  2 and 3 ranks (RCB and graph-growing partitions of the product's partitioner, unequal
+message sizes) share cuda:0 through the host (gloo) transport; every field on the owned cells against the single-rank run of the
+same code (which tests/test_foam_layer_gpu.py compares with the oracle): to rounding for what involves no linear solve beyond the
+diagonal one, 1e-8 after the Krylov solves (tolerance 1e-10; block-Jacobi DILU / DIC take a different iteration path)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import foam_case
+from common import rel_l2
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("world,partitioner", [(2, "rcb"), (3, "graph")])
+def test_b1_demo_on_a_decomposed_mesh(O, ffm, ctx, world, partitioner):
+    from oracle import plume
+    n = (9, 8, 7)
+    m = plume.make_mesh(n, h=0.1)
+    I = foam_case.inputs(O, m)
+    ref, cells, nit1 = foam_case.run_b1_demo(ffm, ctx, m, I)
+    assert np.array_equal(cells, np.arange(m.nCells))
+    port = 29500 + (os.getpid() % 150) + 7 * world
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "foam_rank.py"), str(r), str(world), str(port)] + [str(v) for v in n]
+                                  + [partitioner, tmp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in range(world)]
+        try:
+            outs = [p.communicate(timeout=150) for p in procs]
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        assert [p.returncode for p in procs] == [0] * world, [o[1][-1500:] for o in outs]
+        parts = [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(world)]
+    assert sorted(np.concatenate([p["cells"] for p in parts]).tolist()) == list(range(m.nCells))          # a partition
+    assert all(int(p["nGhost"]) > 0 for p in parts)
+    full = {k: np.full_like(v, np.nan) for k, v in ref.items()}
+    for p in parts:
+        for k in full:
+            full[k][..., p["cells"]] = p[k]
+    assert len({tuple(p["nit"].tolist()) for p in parts}) == 1                       # every rank saw the same (global) solver performance
+    assert rel_l2(full["rho"], ref["rho"]) < 1e-15              # diagonal solve; fvc::div(phi) sums a cell's faces in the rank's own face order
+    assert rel_l2(full["rAU"], ref["rAU"]) < 1e-14
+    for k in ("Yi", "K"):
+        assert rel_l2(full[k], ref[k]) < 1e-8, k
+    for k in ("U", "HbyA", "Uc"):
+        for c in range(3):
+            assert rel_l2(full[k][c], ref[k][c]) < (1e-7 if k == "HbyA" else 1e-8), (k, c)
+    assert np.linalg.norm(full["p"] - ref["p"]) / np.linalg.norm(ref["p"] - ref["p"].mean()) < 1e-7
