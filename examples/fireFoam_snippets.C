@@ -44,6 +44,10 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     // time-step control (controlDict adjustTimeStep / maxCo / maxDeltaT) for firefoam_snippets_time_step; dtOut: the deltaT used
     int adjustTimeStep; double maxCo, maxDeltaT; double* dtOut;
     int emptyDirections;        // bit d set: direction d is not solved (a 2-D case's `empty` patches): mesh.solutionD[d] = -1
+    // wallFireSelection != 0: the solver / scheme selection of cases/wallFireSpread2D/system (BASELINE config 5) instead of the
+    // steckler one: p_rgh, ph_rgh GAMG + GaussSeidel (fvSolution:36-60; gamg = the mesh's agglomeration, ffm_gamg_create), U / Yi / h
+    // PBiCG + DILU (:67-75,115-152), div(phi,U) Gauss filteredLinear2V 0.2 0.05 (fvSchemes:41)
+    int wallFireSelection; ffm_gamg* gamg;
 };
 
 // ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
@@ -115,8 +119,17 @@ struct snippetSolver
         mesh.solvers["h"] = mesh.solvers["hFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-8, 0, 0, 1000, 1};
         mesh.solvers["p_rgh"] = mesh.solvers["ph_rgh"] = {FFM_PCG, FFM_DIC, 1e-6, 0.01, 0, 1000, 1};     // fvSolution:29-46
         mesh.solvers["p_rghFinal"] = {FFM_PCG, FFM_DIC, 1e-6, 0, 0, 1000, 1};
+        if (cs->wallFireSelection) {
+            solverControls g; g.solver = FFM_GAMG; g.preconditioner = FFM_GS; g.tolerance = 1e-5; g.relTol = 0.01;
+            mesh.solvers["p_rgh"] = mesh.solvers["ph_rgh"] = g;
+            g.tolerance = 1e-6; g.relTol = 0; mesh.solvers["p_rghFinal"] = g;
+            mesh.solvers["U"] = {FFM_PBICG, FFM_DILU, 1e-6, 0, 0, 1000, 1}; mesh.solvers["UFinal"] = {FFM_PBICG, FFM_DILU, 1e-7, 0, 0, 1000, 1};
+            mesh.solvers["Yi"] = mesh.solvers["YiFinal"] = mesh.solvers["h"] = mesh.solvers["hFinal"] = {FFM_PBICG, FFM_DILU, 1e-8, 0, 0, 1000, 1};
+            mesh.gamg = cs->gamg;
+        }
         if (std::getenv("FFM_PLUME_TIGHT")) for (auto& kv : mesh.solvers) if (kv.second.solver != FFM_DIAGONAL) { kv.second.tolerance = 1e-13; kv.second.relTol = 0; }
         mesh.divSchemes["div(phi,U)"] = {4, 1, 0, 1};                                   // Gauss LUST grad(U)
+        if (cs->wallFireSelection) mesh.divSchemes["div(phi,U)"] = {6, 0.2, 0.05, 1};   // Gauss filteredLinear2V 0.2 0.05
         mesh.divSchemes["div(phi,K)"] = {2, 1, 0, 1};                                   // Gauss limitedLinear 1
         mesh.divSchemes["div(phiv,p)"] = {2, 1, 0, 1};
         mesh.multivariateSelection["div(phi,Yi_h)"]["h"] = {2, 1, 0, 1};                // h limitedLinear 1

@@ -93,6 +93,38 @@ class StecklerSolvers(Solvers):
                     h=dict(solver="SMOOTH", pre="SYMGS", tolerance=1e-8, relTol=0.0, maxIter=10))
 
 
+class WallFireSolvers(Solvers):
+    """the selection of cases/wallFireSpread2D/system/fvSolution (BASELINE config 5): p_rgh / ph_rgh GAMG + GaussSeidel 1e-5 relTol
+    0.01 (:36-47), p_rghFinal 1e-6 relTol 0 (:49-60), U / Yi / h PBiCG + DILU (:67-75,115-152; the momentum solve of a one-outer-
+    corrector PIMPLE step reads UFinal: 1e-7).  The multigrid hierarchy depends on the cell numbering, so the GAMG solves run in
+    the numbering the device uses (cellOrder / faceOrder = its new -> old maps, (l2, u2, Sf2) the addressing and face areas in
+    that numbering): one cached agglomeration per mesh (cacheAgglomeration true)."""
+    CONTROLS = dict(Solvers.CONTROLS,
+                    p_rgh=dict(solver="GAMG", pre="GaussSeidel", tolerance=1e-5, relTol=0.01),
+                    ph_rgh=dict(solver="GAMG", pre="GaussSeidel", tolerance=1e-5, relTol=0.01),
+                    p_rghFinal=dict(solver="GAMG", pre="GaussSeidel", tolerance=1e-6, relTol=0.0),
+                    U=dict(solver="PBICG", pre="DILU", tolerance=1e-7, relTol=0.0),
+                    Yi=dict(solver="PBICG", pre="DILU", tolerance=1e-8, relTol=0.0),
+                    h=dict(solver="PBICG", pre="DILU", tolerance=1e-8, relTol=0.0))
+
+    def __init__(self, cellOrder, faceOrder, l2, u2, Sf2):
+        Solvers.__init__(self)
+        from . import gamg
+        self.cOrd, self.fOrd = np.asarray(cellOrder), np.asarray(faceOrder)
+        self.agg = gamg.Agglomeration(len(self.cOrd), l2, u2, gamg.face_area_pair_weights(Sf2))
+        self.gamg = gamg
+
+    def solve(self, kind, name, mesh, diag, upper, lower, source, psi0):
+        c = self.CONTROLS[kind]
+        if c["solver"] != "GAMG":
+            return Solvers.solve(self, kind, name, mesh, diag, upper, lower, source, psi0)
+        G = self.gamg.GAMGSolver(self.agg, diag[self.cOrd], upper[self.fOrd], None, smoother=c["pre"])
+        x, perf = G.solve(psi0[self.cOrd], source[self.cOrd], tolerance=c["tolerance"], relTol=c["relTol"])
+        psi = np.empty_like(x); psi[self.cOrd] = x
+        self.log.append((name, perf))
+        return psi
+
+
 # ---- fvDOM stand-in (SURVEY 8f N1): the ray set and the per-ray transport equation of the reference's
 # packages/thermophysicalModels/radiation/radiationModels/fvDOM (fvDOM/fvDOM.C:55-90, radiativeIntensityRay/
 # radiativeIntensityRay.C:126-143,267-322), with a constant absorption coefficient, no scattering, no emission term E
@@ -298,12 +330,18 @@ class Plume:
         Ub = [b.values(m, self.U[c]) for c, b in enumerate(bcU)]
         # div(phi,U) Gauss LUST grad(U) (cases/steckler/system/fvSchemes:32): implicit part with the LUST weights, explicit
         # correction fvc::surfaceIntegrate(phi*correction(U)) added to the matrix (gaussConvectionScheme::fvmDiv)
-        wU = fv.lust_weights(m, self.phi)
         UEqn = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.U0)
-        divU = fv.fvm_div(m, self.phi, self.phib, wU, bcU)
         zb = [np.zeros(p.size) for p in m.patches]
-        divU.add_vol(np.stack([fv.surface_integrate(m, self.phi * fv.lust_correction(m, self.phi, fv.grad(m, self.U[c], Ub[c])), zb)
-                               for c in range(3)]))
+        if getattr(self, "divU_scheme", None):
+            # div(phi,U) Gauss filteredLinear2V k l (cases/wallFireSpread2D/system/fvSchemes:41): one limiter per face, no correction
+            _, kk, ll = self.divU_scheme
+            gradU = np.stack([fv.grad(m, self.U[c], Ub[c]) for c in range(3)], axis=2)           # [cell][i][j] = d_i U_j
+            divU = fv.fvm_div(m, self.phi, self.phib, fv.filtered_linear2V_weights(m, self.phi, self.U.T.copy(), gradU, kk, ll), bcU)
+        else:
+            wU = fv.lust_weights(m, self.phi)
+            divU = fv.fvm_div(m, self.phi, self.phib, wU, bcU)
+            divU.add_vol(np.stack([fv.surface_integrate(m, self.phi * fv.lust_correction(m, self.phi, fv.grad(m, self.U[c], Ub[c])), zb)
+                                   for c in range(3)]))
         UEqn += divU
         UEqn -= fv.fvm_laplacian(m, muf, mub, bcU)
         rhob = self.zg(self.rho)

@@ -30,7 +30,8 @@ class SnippetCase(C.Structure):
                 + [("dpdtOut", dp), ("phiOutF", dp), ("phiOutB", dp), ("p_rghBOut", dp), ("nIterOut", C.POINTER(C.c_int)), ("nIterCap", C.c_int)]
                 + [("radiationFreq", C.c_int), ("kAbs", C.c_double), ("sigmaSB", C.c_double), ("dAve", dp), ("omega", dp), ("GOut", dp)]
                 + [("psiB", dp), ("resOut", dp)]
-                + [("adjustTimeStep", C.c_int), ("maxCo", C.c_double), ("maxDeltaT", C.c_double), ("dtOut", dp), ("emptyDirections", C.c_int)])
+                + [("adjustTimeStep", C.c_int), ("maxCo", C.c_double), ("maxDeltaT", C.c_double), ("dtOut", dp), ("emptyDirections", C.c_int)]
+                + [("wallFireSelection", C.c_int), ("gamg", C.c_void_p)])
 
 
 @pytest.mark.parametrize("shape,empty", [((10, 12, 9), ()), ((1, 24, 20), ("xmin", "xmax"))])
@@ -188,6 +189,29 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
     refR.step()
     assert list(nitR[:nR]) == [pf["nIterations"] for _, pf in refR.sol.log] and nR == (9 if empty else 10) + 32
     assert rel_l2(G[inv0], refR.G) < 1e-10 and rel_l2(outR["T"][inv0], refR.T) < 1e-10
+
+    if empty:
+        # ---- BASELINE config 5's selection on this 2-D mesh (cases/wallFireSpread2D/system): p_rgh by GAMG + GaussSeidel on the
+        # mesh's cached faceAreaPair agglomeration, momentum convection by filteredLinear2V 0.2 0.05, U / Yi / h by PBiCG + DILU --
+        # two time steps of the reference's unchanged equation files against the oracle with the same selection
+        G5 = ffm.GAMG(ctx, A, l2, u2, Sf=m.Sf[fOrd])
+        ref5 = plume.Plume(shape, mesh=plume.make_mesh(shape, empty=empty), solvers=plume.WallFireSolvers(cOrd, fOrd, l2, u2, m.Sf[fOrd]))
+        ref5.stored_bc = True; ref5.divU_scheme = ("filteredLinear2V", 0.2, 0.05)
+        out5, nit5 = new_out(), (C.c_int * 32)()
+        cs5 = case_of(ref5, out5, nit5)
+        cs5.wallFireSelection = 1; cs5.gamg = G5.h
+        solver5 = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(cs5))
+        for k in range(2):
+            n5 = lib.firefoam_snippets_advance(solver5, C.byref(cs5), 1 if k == 1 else 0)
+            ref5.step()
+            assert list(nit5[:n5]) == [pf["nIterations"] for _, pf in ref5.sol.log], (k, list(nit5[:n5]), [pf["nIterations"] for _, pf in ref5.sol.log])
+        lib.firefoam_snippets_destroy(solver5)
+        assert max(pf["nIterations"] for nm, pf in ref5.sol.log if nm == "p_rgh") >= 2                 # V-cycles were needed
+        f5 = ref5.fields()
+        for name, a in (("rho", out5["rho"]), ("T", out5["T"]), ("Uy", out5["U"][1]), ("Uz", out5["U"][2]), ("O2", out5["Y"][0]), ("h", out5["h"])):
+            assert rel_l2(a[inv0], f5[name]) < 1e-7, (name, rel_l2(a[inv0], f5[name]))
+        assert np.linalg.norm(out5["p_rgh"][inv0] - f5["p_rgh"]) / np.linalg.norm(f5["p_rgh"] - f5["p_rgh"].mean()) < 1e-4
+        G5.close()
 
     for step in range(2):
         out = new_out()
