@@ -88,6 +88,7 @@ struct ffm_tile_plan {
     unsigned long upCoefEpoch = ~0ul, diagpEpoch = ~0ul;
     int nSeg = 0;                   // workgroups of the tiled Amul: a segment = a run of entries of one group
     int4 *aseg = nullptr;           // [nSeg] {group, first entry, end entry, end entry of the group}
+    double *amulPartials = nullptr; // [nSeg]
     int nTail = 0;                  // cells that own faces towards ghost cells (processed after the tiled kernel, in face order)
     int *tailCell = nullptr, *tailStart = nullptr, *tailFace = nullptr, *tailNbr = nullptr;
 };
@@ -102,7 +103,7 @@ void ffm_tile_free(ffm_ldu *A)
     if (!A->tile) return;
     free_dir(A->tile->f); free_dir(A->tile->b);
     hipFree(A->tile->mailAll); hipFree(A->tile->trace); hipFree(A->tile->wp); hipFree(A->tile->rDp);
-    hipFree(A->tile->arec); hipFree(A->tile->acode); hipFree(A->tile->aext); hipFree(A->tile->aseg);
+    hipFree(A->tile->arec); hipFree(A->tile->acode); hipFree(A->tile->aext); hipFree(A->tile->aseg); hipFree(A->tile->amulPartials);
     hipFree(A->tile->upSrcCell); hipFree(A->tile->upNbrCell); hipFree(A->tile->upCoefCell); hipFree(A->tile->diagp);
     hipFree(A->tile->tailCell); hipFree(A->tile->tailStart); hipFree(A->tile->tailFace); hipFree(A->tile->tailNbr);
     delete A->tile; A->tile = nullptr;
@@ -386,12 +387,15 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
     // segments: enough workgroups to fill the chip, each long enough to amortise the A_WIN entries read twice at either end
     {
         const std::vector<int> &grpEntH = T->grpEntHost;
-        int L = std::min(64, std::max(16, nEnt / 2048));
+        // measured at 400^3 (r02, scripts/tile_probe.py): 16 entries 0.82 ms, 24 0.83, 32 0.84, 64 0.87, a whole tile (430) 0.93, 8 0.94 --
+        // short segments balance the 256 CUs better than their two extra ring entries cost
+        int L = std::min(20, std::max(16, nEnt / 2048));
         if (const char *e = getenv("FFM_AMUL_SEG")) L = std::max(1, atoi(e));
         std::vector<int4> seg;
         for (int g = 0; g < T->G; g++) for (int a = grpEntH[g]; a < grpEntH[g + 1]; a += L) seg.push_back(make_int4(g, a, std::min(a + L, grpEntH[g + 1]), grpEntH[g + 1]));
         T->nSeg = (int)seg.size();
         FFM_TRY(upv(&T->aseg, seg));
+        FFM_HIP(hipMalloc((void **)&T->amulPartials, sizeof(double) * std::max(T->nSeg, 1)));      // x.y of every segment (fused dot)
     }
     T->amulUsable = true;
     return FFM_OK;
@@ -1061,11 +1065,11 @@ int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot)
     const double *bcoef;
     FFM_TRY(tile_up_coef_cell(A, &bcoef));
     AmulView v; v.G = T->G; v.grpCell = A->grpCell; v.grpEnt = T->f.grpEnt; v.rec = T->arec; v.seg = T->aseg; v.code = T->acode; v.ext = T->aext;
-    const bool fusedDot = dotSlot >= 0 && T->nTail == 0 && T->nSeg <= 4 * RED_BLOCKS;
+    const bool fusedDot = dotSlot >= 0 && T->nTail == 0;
     if (fusedDot) {
         FFM_TRY(ffm_ghost_exchange_end(A));          // (no ghost faces on this rank: nothing in flight that the kernel would need)
-        hipLaunchKernelGGL((k_tile_amul<true>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, A->ctx->partials_d);
-        hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->nSeg, (const double *)A->ctx->partials_d, A->ctx->scal_d, dotSlot);
+        hipLaunchKernelGGL((k_tile_amul<true>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, T->amulPartials);
+        hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->nSeg, (const double *)T->amulPartials, A->ctx->scal_d, dotSlot);
     } else {
         hipLaunchKernelGGL((k_tile_amul<false>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y, (double *)nullptr);
         FFM_TRY(ffm_ghost_exchange_end(A));          // an overlapped ghost refresh (ffm_ghost_exchange_begin) must have landed before the tail
