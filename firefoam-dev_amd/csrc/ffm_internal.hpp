@@ -203,6 +203,15 @@ struct FfmStageTimer {
     explicit FfmStageTimer(const char *w) : what(w), t0(now()), on(getenv("FFM_TIMING") != nullptr) {}
     ~FfmStageTimer() { if (on) fprintf(stderr, "ffm timing: %-28s %.2f s\n", what, now() - t0); }
 };
+// label of the 2-D tile (a, b) of cell columns.  Ties between tiles that are ready at the same time are broken by label
+// (ffm_ldu.hip: topological ranking), so the label orders the tickets: anti-diagonal major = the order of the sweep's wavefront
+// (FFM_TILE_ROW_ORDER=1: row-major, the round-1 order)
+static inline int ffm_tile_label(int a, int b)
+{
+    static const bool row = getenv("FFM_TILE_ROW_ORDER") && atoi(getenv("FFM_TILE_ROW_ORDER")) != 0;
+    a = a < 2047 ? a : 2047; b = b < 2047 ? b : 2047;
+    return row ? a + 32768 * b : (a + b) * 4096 + b;
+}
 struct LduView;
 LduView ffm_view(const ffm_ldu *A);
 // ---- internal helpers shared between translation units -------------------

@@ -151,7 +151,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
             } else if (N == nOwn && detect_box(N, F, l, u, bx, by, bz)) {
                 const int T = tile_edge();
                 autoHint.resize(nOwn);
-                for (int c = 0; c < nOwn; c++) autoHint[c] = ((c / bx) % by) / T + 32768 * ((c / (bx * by)) / T);
+                for (int c = 0; c < nOwn; c++) autoHint[c] = ffm_tile_label(((c / bx) % by) / T, (c / (bx * by)) / T);
                 groupHint = autoHint.data(); a.mode = 2;
             }
         }
@@ -386,7 +386,7 @@ extern "C" int ffm_tile_hint_from_centres(int nCells, const double *C /* [3][nCe
     for (int c = 0; c < nCells; c++) {
         const int ta = (int)std::floor((C[(size_t)a * nCells + c] - lo[a]) / (tileCells * ha) + 1e-9);
         const int tb = (int)std::floor((C[(size_t)b * nCells + c] - lo[b]) / (tileCells * hb) + 1e-9);
-        hint[c] = std::min(ta, 32767) + 32768 * std::min(tb, 32767);
+        hint[c] = ffm_tile_label(ta, tb);
     }
     return FFM_OK;
 }

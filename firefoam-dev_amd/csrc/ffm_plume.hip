@@ -718,7 +718,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     int tileEdge = 16;
     if (const char *e = getenv("FFM_TILE")) tileEdge = std::max(1, atoi(e));
     std::vector<int> hint(nOwn);
-    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) hint[cellOf(i, j, k)] = (j / tileEdge) + 32768 * (k / tileEdge);
+    for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) hint[cellOf(i, j, k)] = ffm_tile_label(j / tileEdge, k / tileEdge);
     std::vector<int> c2(N), f2(F);
     { FfmStageTimer tm_("plume_create: renumber_hint"); FFM_TRY(ffm_renumber_hint((int)nOwn, (int)nGhost, F, l.data(), u.data(), hint.data(), c2.data(), f2.data())); }
     P->newToOld = c2;

@@ -1,5 +1,5 @@
 """Time the tiled kernels on an n^3 box: one DIC application (forward + backward sweep) and one symmetric Amul.
-   usage: tile_probe.py n [reps]      env: FFM_TILE, FFM_TILE_EDGE_ORDER"""
+   usage: tile_probe.py n [reps]      env: FFM_TILE, FFM_TILE_EDGE_ORDER, FFM_TILE_ROW_ORDER, FFM_AMUL_SEG"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -10,11 +10,10 @@ ctx = ffm.Context(0)
 n = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 blk = H.HexBlock((n, n, n))
 s = H.synth_p_rgh(blk)
-T = int(os.environ.get("FFM_TILE", "16"))
-hint = (blk.j // T) + 10000 * (blk.k // T)
-cOrd, fOrd = ffm.renumber_levels(blk.nCells, blk.l, blk.u, groupHint=hint)
+cOrd, fOrd = ffm.renumber_levels(blk.nCells, blk.l, blk.u)            # the library's own tiling of a detected box
 l2, u2, _ = H.apply_renumbering(blk.nCells, blk.l, blk.u, cOrd, fOrd)
-A = ffm.lduMatrix(ctx, blk.nCells, l2, u2, groupHint=hint[cOrd])
+A = ffm.lduMatrix(ctx, blk.nCells, l2, u2)
+assert A.native_order and A.sweep_mode == 2
 A.set_coeffs(s["diag"][cOrd], s["upper"][fOrd])
 A.reciprocalD("DIC")
 r = ctx.to_device(s["source"][cOrd]); w = ctx.empty(blk.nCells)
