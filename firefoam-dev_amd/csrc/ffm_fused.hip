@@ -295,3 +295,84 @@ extern "C" int ffm_fvm_lust_source3(ffm_mesh *m, double rDeltaT, const double *p
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
+
+// ---- pressure-corrector passes (solver/pEqn.H:5-20) ---------------------------------------------------------------------------
+// HbyA = rAU*UEqn.H() for the three components in one pass over the rows: the off-diagonal coefficients of the momentum matrix
+// are read once instead of three times (k_matrix_H per component + one product kernel each); per component the arithmetic is
+// that of k_matrix_H followed by the product, bit for bit.
+struct HbyA3 {
+    const double *upper, *lower, *src[3], *ic[3], *bc[3], *psi[3], *rAU;
+    double *out[3];
+};
+template <int W>
+__global__ __launch_bounds__(256) void k_matrix_HbyA3(MeshView q, HbyA3 a)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
+        double al[W], au[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) { al[s] = a.lower[L.f[s]]; au[s] = a.upper[U.f[s]]; }
+        double bd[3] = {0.0, 0.0, 0.0}, bda = 0.0, bs[3] = {0.0, 0.0, 0.0};
+        const int j = q.cellB[c];
+        if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) {
+            const int k = q.bcItem[t];
+            const double i0 = a.ic[0][k], i1 = a.ic[1][k], i2 = a.ic[2][k];
+            bd[0] += i0; bd[1] += i1; bd[2] += i2; bda += (i0 + i1 + i2) / 3.0;
+            bs[0] += a.bc[0][k]; bs[1] += a.bc[1][k]; bs[2] += a.bc[2][k];
+        }
+        const double V = q.V[c], r = a.rAU ? a.rAU[c] : 1.0;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double *psi = a.psi[d];
+            double hl = 0.0;
+#pragma unroll
+            for (int s = 0; s < W; s++) if (L.on[s]) hl -= al[s] * psi[L.nb[s]];
+#pragma unroll
+            for (int s = 0; s < W; s++) if (U.on[s]) hl -= au[s] * psi[U.nb[s]];
+            double h = (bda - bd[d]) * psi[c];
+            h += hl + a.src[d][c];
+            h += bs[d];
+            h = h / V;
+            a.out[d][c] = a.rAU ? r * h : h;
+        }
+    }
+}
+
+// fvMatrix<vector>::H() of the three components, times rAU when given (rAU null: H itself).  Arrays as ffm_fvm_H.
+extern "C" int ffm_fvm_HbyA3(ffm_mesh *m, const double *upper, const double *lower, const double *const *source, const double *const *ic,
+                             const double *const *bc, const double *const *psi, const double *rAU, double *const *out)
+{
+    CHECK_M(m);
+    if (!upper || !lower || !source || !ic || !bc || !psi || !out) return FFM_ERR_ARG;
+    HbyA3 a; a.upper = upper; a.lower = lower; a.rAU = rAU;
+    for (int d = 0; d < 3; d++) {
+        if (!source[d] || !psi[d] || !out[d] || (m->B && (!ic[d] || !bc[d]))) return FFM_ERR_ARG;
+        a.src[d] = source[d]; a.ic[d] = ic[d]; a.bc[d] = bc[d]; a.psi[d] = psi[d]; a.out[d] = out[d];
+    }
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_matrix_HbyA3<W>, mview(m), a));
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+// fvc::flux(rho*v) on the internal faces without the product fields: (w (rho v)_P + (1 - w) (rho v)_N) . Sf, the products formed
+// where they are used (the values k_flux reads from the stored product fields)
+__global__ __launch_bounds__(256) void k_flux_rho(MeshView q, const double *__restrict__ rho, const double *__restrict__ vx,
+                                                  const double *__restrict__ vy, const double *__restrict__ vz, double *__restrict__ out)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci; const double rP = rho[c]; const double Px = rP * vx[c], Py = rP * vy[c], Pz = rP * vz[c];
+        FOR_OWN_FACES(q, c, e, nb) {
+            const double w = q.w[e], rN = rho[nb];
+            out[e] = (w * Px + (1.0 - w) * (rN * vx[nb])) * q.Sfx[e] + (w * Py + (1.0 - w) * (rN * vy[nb])) * q.Sfy[e] + (w * Pz + (1.0 - w) * (rN * vz[nb])) * q.Sfz[e];
+        }
+    }
+}
+extern "C" int ffm_fvc_flux_rho(ffm_mesh *m, const double *rho, const double *vx, const double *vy, const double *vz, double *out_f)
+{
+    CHECK_M(m);
+    if (!rho || !vx || !vy || !vz || !out_f) return FFM_ERR_ARG;
+    LAUNCH_CELLS(k_flux_rho, mview(m), rho, vx, vy, vz, out_f);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}

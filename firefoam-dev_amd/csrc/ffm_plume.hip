@@ -89,6 +89,7 @@ struct ffm_plume {
     // matrix + work
     double *diag, *upper, *lower, *src[3], *ic[3], *bc[3], *dWork, *sWork;
     double *wN[12], *wF[6], *wB[8];
+    double *ddtCorrF = nullptr; bool ddtCorrValid = false;      // coeff*rDeltaT*phiCorr of fvc::ddtCorr(rho, U, phi): old-time fields only, the same in both correctors of a step
     // fused assembly (ffm_fused.hip): gradients of up to 4 fields, the matrices of the 4 transported species, their patch values
     double *gM[4][3], *spD[4], *spU[4], *spL[4], *spS[4], *spB[4], *suM[4];
     bool fused = true;                     // FFM_PLUME_UNFUSED: one kernel per operator (tests compare the two paths)
@@ -384,6 +385,12 @@ static int p_corrector(ffm_plume *P, bool final)
     double *rhorAUf = P->wF[0], *rhorAUfb = P->wB[0];
     FFM_TRY(ffm_fvc_interpolate(m, nullptr, rhorAU, rhorAUf));
     zg(P, rhorAUfb, rhorAU);
+    if (P->fused) {
+        const double *srcs[3] = {P->Usrc[0], P->Usrc[1], P->Usrc[2]}, *ics[3] = {P->Uic[0], P->Uic[1], P->Uic[2]}, *bcs[3] = {P->Ubc[0], P->Ubc[1], P->Ubc[2]};
+        const double *us[3] = {P->U[0], P->U[1], P->U[2]};
+        FFM_TRY(ffm_fvm_HbyA3(m, P->Uupper, P->Ulower, srcs, ics, bcs, us, rAU, HbyA));
+        for (int c = 0; c < 3; c++) FFM_TRY(HX(P, HbyA[c]));
+    } else
     for (int c = 0; c < 3; c++) {
         FFM_TRY(ffm_fvm_H(m, 3, c, P->Uupper, P->Ulower, P->Usrc[c], P->Uic[0], P->Uic[1], P->Uic[2], P->Ubc[c], P->U[c], HbyA[c]));
         double *Hc = HbyA[c];
@@ -401,10 +408,13 @@ static int p_corrector(ffm_plume *P, bool final)
     const double *ghf = P->ghf;
     forN(P, nNat, [=] __device__(long e) { phig[e] = -rhorAUf[e] * ghf[e] * sg[e] * magSf[e]; });
     // fvc::flux(rho*HbyA): interior by linear interpolation; boundary rho_b*HbyA_b.Sf with constrainHbyA
-    double *rH[3] = {P->wN[5], P->wN[6], P->wN[7]};
-    for (int c = 0; c < 3; c++) mul(P, rH[c], rho, HbyA[c], N);
     double *phiHbyA = P->wF[3], *phiHbyAb = P->wB[5];
-    FFM_TRY(ffm_fvc_flux(m, rH[0], rH[1], rH[2], phiHbyA));
+    if (P->fused) FFM_TRY(ffm_fvc_flux_rho(m, rho, HbyA[0], HbyA[1], HbyA[2], phiHbyA));
+    else {
+        double *rH[3] = {P->wN[5], P->wN[6], P->wN[7]};
+        for (int c = 0; c < 3; c++) mul(P, rH[c], rho, HbyA[c], N);
+        FFM_TRY(ffm_fvc_flux(m, rH[0], rH[1], rH[2], phiHbyA));
+    }
     {
         const int *fc = ffm_mesh_bcells(m); const double *kind = P->kind_d;
         const double *h0 = HbyA[0], *h1 = HbyA[1], *h2 = HbyA[2], *u0 = Ub[0], *u1 = Ub[1], *u2 = Ub[2];
@@ -416,16 +426,24 @@ static int p_corrector(ffm_plume *P, bool final)
     }
     // + rhorAUf*ddtCorr(rho,U,phi) + phig
     {
-        double *rU0[3] = {P->wN[8], P->wN[9], P->wN[10]};
-        for (int c = 0; c < 3; c++) mul(P, rU0[c], P->rho0, P->U0[c], N);
-        double *fl0 = P->wF[4];
-        FFM_TRY(ffm_fvc_flux(m, rU0[0], rU0[1], rU0[2], fl0));
-        const double *phi0 = P->phi0;
-        forN(P, nNat, [=] __device__(long e) {
-            const double phiCorr = phi0[e] - fl0[e];
-            const double coeff = 1.0 - fmin(fabs(phiCorr) / (fabs(phi0[e]) + 1e-15), 1.0);
-            phiHbyA[e] = (phiHbyA[e] + rhorAUf[e] * (coeff * rdt * phiCorr)) + phig[e];
-        });
+        double *dc = P->ddtCorrF;
+        if (!P->ddtCorrValid) {         // old-time fields only: evaluated in the first corrector of a step, reused by the second
+            double *fl0 = P->wF[4];
+            if (P->fused) FFM_TRY(ffm_fvc_flux_rho(m, P->rho0, P->U0[0], P->U0[1], P->U0[2], fl0));
+            else {
+                double *rU0[3] = {P->wN[8], P->wN[9], P->wN[10]};
+                for (int c = 0; c < 3; c++) mul(P, rU0[c], P->rho0, P->U0[c], N);
+                FFM_TRY(ffm_fvc_flux(m, rU0[0], rU0[1], rU0[2], fl0));
+            }
+            const double *phi0 = P->phi0;
+            forN(P, nNat, [=] __device__(long e) {
+                const double phiCorr = phi0[e] - fl0[e];
+                const double coeff = 1.0 - fmin(fabs(phiCorr) / (fabs(phi0[e]) + 1e-15), 1.0);
+                dc[e] = coeff * rdt * phiCorr;
+            });
+            P->ddtCorrValid = true;
+        }
+        forN(P, nNat, [=] __device__(long e) { phiHbyA[e] = (phiHbyA[e] + rhorAUf[e] * dc[e]) + phig[e]; });
         (void)Sx; (void)Sy; (void)Sz; (void)wlin;
     }
     // constrainPressure: gradient on fixedFluxPressure patches
@@ -485,6 +503,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
     ffm_mesh *m = P->mesh; const int N = P->N, B = P->B; const long nNat = P->nNat; const double rdt = P->rdt;
     const double *V = ffm_mesh_geom(m, 0), *magSf = ffm_mesh_geom(m, 1);
     P->log.clear();
+    P->ddtCorrValid = false;
     // oldTime fields
     dcopy(P, P->rho0, P->rho, N); dcopy(P, P->hs0, P->hs, N); dcopy(P, P->K0, P->K, N); dcopy(P, P->p0, P->p, N);
     dcopy(P, P->psi0, P->psi, N); dcopy(P, P->p_rgh0, P->p_rgh, N); dcopy(P, P->phi0, P->phi, nNat); dcopy(P, P->phib0, P->phib, B);
@@ -844,6 +863,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     for (int c = 0; c < 3; c++) { P->src[c] = NN(); P->ic[c] = dalloc(P, B); P->bc[c] = dalloc(P, B); P->Usrc[c] = NN(); P->Uic[c] = dalloc(P, B); P->Ubc[c] = dalloc(P, B); }
     for (auto &w : P->wN) w = NN();
     for (auto &w : P->wF) w = dalloc(P, nNat);
+    P->ddtCorrF = dalloc(P, nNat);
     for (auto &w : P->wB) w = dalloc(P, B);
     P->fused = getenv("FFM_PLUME_UNFUSED") == nullptr;
     for (int j = 0; j < 4; j++) {

@@ -321,6 +321,15 @@ int ffm_fvm_A(ffm_mesh *m, int nCmpt, const double *diag, const double *ic0, con
 int ffm_fvm_H(ffm_mesh *m, int nCmpt, int cmpt, const double *upper, const double *lower,
               const double *source, const double *ic0, const double *ic1, const double *ic2,
               const double *bcCmpt, const double *psi, double *out);
+/* the three components of fvMatrix<vector>::H() in one pass, times rAU when given: HbyA = rAU*UEqn.H() (solver/pEqn.H:9);
+ * source / internalCoeffs / boundaryCoeffs / psi / out: arrays of three device pointers; bitwise equal to three ffm_fvm_H
+ * calls followed by the product */
+int ffm_fvm_HbyA3(ffm_mesh *m, const double *upper, const double *lower, const double *const *source,
+                  const double *const *internalCoeffs, const double *const *boundaryCoeffs, const double *const *psi,
+                  const double *rAU, double *const *out);
+/* fvc::flux(rho*v) on the internal faces (solver/pEqn.H:15 fvc::flux(rho*HbyA); the old-time flux of fvc::ddtCorr) without
+ * storing the product fields; bitwise equal to ffm_fvc_flux of the products */
+int ffm_fvc_flux_rho(ffm_mesh *m, const double *rho, const double *vx, const double *vy, const double *vz, double *out_f);
 int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lower, const double *internalCoeffs,
                  const double *boundaryCoeffs, const double *psi, double *out_f, double *out_b);
 
