@@ -376,3 +376,60 @@ extern "C" int ffm_fvc_flux_rho(ffm_mesh *m, const double *rho, const double *vx
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
+
+// p_rghEqn of solver/pEqn.H:28-36 in one pass over the rows:
+//     fvm::ddt(psi, p_rgh) + fvc::ddt(psi, rho)*gh + fvc::ddt(psi)*pRef + fvc::div(phiHbyA) - fvm::laplacian(rhorAUf, p_rgh)
+// i.e. the laplacian coefficients (k_fvm_transport), fvc::div(phiHbyA) (k_face_sum), the three explicit terms (one source
+// update each, in the reference's order) and addBoundaryDiag / addBoundarySource (k_add_boundary), with their arithmetic.
+struct PEqn {
+    const double *psi, *psi0, *p0, *rho, *rho0, *gh, *gamma, *phiHbyA, *phiHbyAb, *ic, *bc;
+    double *upper, *lower, *diag, *src;
+    double rdt, pRef;
+};
+template <int W>
+__global__ __launch_bounds__(256) void k_p_rgh_eqn(MeshView q, PEqn a)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
+        double dLap = 0.0, acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < W; s++) if (L.on[s]) { const int e = L.f[s]; dLap -= a.gamma[e] * q.magSf[e] * q.delta[e]; }
+#pragma unroll
+        for (int s = 0; s < W; s++) if (U.on[s]) {
+            const int e = U.f[s];
+            const double g = a.gamma[e] * q.magSf[e] * q.delta[e];
+            dLap -= g;
+            a.upper[e] = -g; a.lower[e] = -g;
+        }
+#pragma unroll
+        for (int s = 0; s < W; s++) if (L.on[s]) acc = acc - a.phiHbyA[L.f[s]];
+#pragma unroll
+        for (int s = 0; s < W; s++) if (U.on[s]) acc += a.phiHbyA[U.f[s]];
+        const double V = q.V[c];
+        double d = a.rdt * a.psi[c] * V;
+        d = d - dLap;
+        double bd = 0.0, bs = 0.0;      // (the boundary sums are formed in k_add_boundary's order: onto the finished diag / source)
+        const int j = q.cellB[c];
+        if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) acc += a.phiHbyAb[q.bcItem[t]];
+        const double div = acc / V;
+        double s = ((a.rdt * a.psi0[c] * a.p0[c] * V - V * (a.rdt * (a.psi[c] * a.rho[c] - a.psi0[c] * a.rho0[c]) * a.gh[c]))
+                    - V * (a.rdt * (a.psi[c] - a.psi0[c]) * a.pRef)) - V * div;
+        if (j >= 0) for (int t = q.bcStart[j]; t < q.bcStart[j + 1]; t++) { const int k = q.bcItem[t]; d += a.ic[k]; s += a.bc[k]; }
+        (void)bd; (void)bs;
+        a.diag[c] = d; a.src[c] = s;
+    }
+}
+extern "C" int ffm_fvm_pressure_eqn(ffm_mesh *m, double rDeltaT, const double *psi, const double *psi0, const double *p0, const double *rho,
+                                    const double *rho0, const double *gh, double pRef, const double *gamma_f, const double *phiHbyA_f,
+                                    const double *phiHbyA_b, const double *ic, const double *bc, double *upper, double *lower, double *diagOut,
+                                    double *sourceOut)
+{
+    CHECK_M(m);
+    if (!psi || !psi0 || !p0 || !rho || !rho0 || !gh || !gamma_f || !phiHbyA_f || !upper || !lower || !diagOut || !sourceOut ||
+        (m->B && (!phiHbyA_b || !ic || !bc))) return FFM_ERR_ARG;
+    PEqn a{psi, psi0, p0, rho, rho0, gh, gamma_f, phiHbyA_f, phiHbyA_b, ic, bc, upper, lower, diagOut, sourceOut, rDeltaT, pRef};
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_p_rgh_eqn<W>, mview(m), a));
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}

@@ -456,6 +456,11 @@ static int p_corrector(ffm_plume *P, bool final)
     }
     FFM_TRY(bc_p_rgh(P, grads, Ub, rhob));
     // p_rghEqn = fvm::ddt(psi,p_rgh) + fvc::ddt(psi,rho)*gh + fvc::ddt(psi)*pRef + fvc::div(phiHbyA) - fvm::laplacian(rhorAUf,p_rgh)
+    if (P->fused) {
+        FFM_TRY(ffm_fvm_boundary_coeffs(m, nullptr, rhorAUfb, -1, P->fP, P->refP, P->gradP, P->ic[0], P->bc[0]));
+        FFM_TRY(ffm_fvm_pressure_eqn(m, rdt, psi, P->psi0, P->p_rgh0, rho, P->rho0, P->gh, PREF, rhorAUf, phiHbyA, phiHbyAb, P->ic[0], P->bc[0],
+                                     P->upper, P->lower, P->dWork, P->sWork));
+    } else {
     FFM_TRY(ffm_fvm_transport(m, rdt, psi, nullptr, nullptr, rhorAUf, -1, P->diag, P->upper, P->lower));
     FFM_TRY(ffm_fvm_boundary_coeffs(m, nullptr, rhorAUfb, -1, P->fP, P->refP, P->gradP, P->ic[0], P->bc[0]));
     double *div = P->wN[8];
@@ -469,6 +474,7 @@ static int p_corrector(ffm_plume *P, bool final)
         });
     }
     FFM_TRY(ffm_fvm_add_boundary(m, P->ic[0], P->bc[0], P->diag, P->src[0], nullptr, P->dWork, P->sWork));
+    }
     FFM_TRY(solve_named(P, "p_rgh", FFM_PCG, FFM_DIC, 1e-6, final ? 0.0 : 0.01, P->dWork, P->upper, nullptr, P->p_rgh, P->sWork));
     FFM_TRY(HX(P, P->p_rgh));
     // phi = phiHbyA + p_rghEqn.flux(); U = HbyA + rAU*reconstruct((flux + phig)/rhorAUf)

@@ -327,6 +327,14 @@ int ffm_fvm_H(ffm_mesh *m, int nCmpt, int cmpt, const double *upper, const doubl
 int ffm_fvm_HbyA3(ffm_mesh *m, const double *upper, const double *lower, const double *const *source,
                   const double *const *internalCoeffs, const double *const *boundaryCoeffs, const double *const *psi,
                   const double *rAU, double *const *out);
+/* p_rghEqn of solver/pEqn.H:28-36 in one pass: fvm::ddt(psi, p_rgh) + fvc::ddt(psi, rho)*gh + fvc::ddt(psi)*pRef +
+ * fvc::div(phiHbyA) - fvm::laplacian(gamma, p_rgh) with its boundary coefficients (internalCoeffs / boundaryCoeffs from
+ * ffm_fvm_boundary_coeffs) already added: upper / lower [native faces], diagOut / sourceOut [cells] are what the solver takes.
+ * Bitwise equal to ffm_fvm_transport + ffm_fvc_surface_integrate + the three source updates + ffm_fvm_add_boundary. */
+int ffm_fvm_pressure_eqn(ffm_mesh *m, double rDeltaT, const double *psi, const double *psi0, const double *p0,
+                         const double *rho, const double *rho0, const double *gh, double pRef, const double *gamma_f,
+                         const double *phiHbyA_f, const double *phiHbyA_b, const double *internalCoeffs,
+                         const double *boundaryCoeffs, double *upper, double *lower, double *diagOut, double *sourceOut);
 /* fvc::flux(rho*v) on the internal faces (solver/pEqn.H:15 fvc::flux(rho*HbyA); the old-time flux of fvc::ddtCorr) without
  * storing the product fields; bitwise equal to ffm_fvc_flux of the products */
 int ffm_fvc_flux_rho(ffm_mesh *m, const double *rho, const double *vx, const double *vy, const double *vz, double *out_f);
