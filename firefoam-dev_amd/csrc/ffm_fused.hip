@@ -38,7 +38,10 @@ __global__ __launch_bounds__(256) void k_grad_multi(MeshView q, GradMulti a)
         }
         const double V = q.V[c];
         const int j = q.cellB[c];
-#pragma unroll
+#ifndef FFM_SE_UNROLL
+#define FFM_SE_UNROLL 1
+#endif
+#pragma unroll FFM_SE_UNROLL
         for (int i = 0; i < NF; i++) {
             const double *__restrict__ vf = a.vf[i];
             const double P = vf[c];
