@@ -143,3 +143,32 @@ def test_solver_GAMG_through_the_foam_layer(O, ffm, ctx, smoother):
     assert abs(res[1] - pr["finalResidual"]) <= 1e-5 * pr["finalResidual"]
     assert rel_l2(out, xr) < 1e-10
     G.close(); A.close()
+
+
+@pytest.mark.parametrize("meshName,asym,smoother", [("steckler", 0.0, "GaussSeidel"), ("dag_random", 0.0, "DIC"), ("dag_random", 0.3, "DILU")])
+def test_gamg_on_unstructured_addressing(O, ffm, ctx, meshName, asym, smoother):
+    """The baffled steckler room (cases/steckler geometry: cells with fewer than six neighbours around the baffles) and a randomly
+    relabelled box (an LDU graph without any structure in its numbering) with arbitrary face weights: agglomeration, every coarse
+    matrix and the solve against the oracle, as on the hexahedral box."""
+    import part_cases
+    from oracle import gamg
+    N, l, u, centres, diag, up, lo, source = part_cases.build(O, meshName, asym)
+    w = 0.5 + O.hash_u(0x5F, np.arange(len(l)))
+    A = ffm.lduMatrix(ctx, N, l, u)
+    G = ffm.GAMG(ctx, A, l, u, weights=w)
+    agg = gamg.Agglomeration(N, l, u, w)
+    assert G.nLevels == agg.nLevels and agg.nLevels >= 3
+    for lev in range(agg.nLevels + 1):
+        gl, gu = G.level_addressing(lev)
+        assert np.array_equal(gl, agg.l[lev]) and np.array_equal(gu, agg.u[lev]), lev
+    G.set_matrix(ctx.to_device(diag), ctx.to_device(up), None if lo is None else ctx.to_device(lo))
+    ref = gamg.GAMGSolver(agg, diag, up, lo, smoother=smoother)
+    for lev in range(agg.nLevels + 1):
+        d, uu, ll = G.level_coeffs(lev)
+        assert np.array_equal(d, ref.coef[lev][0]) and np.array_equal(uu, ref.coef[lev][1]), lev
+    psi = ctx.to_device(np.zeros(N))
+    pf = G.solve(psi, ctx.to_device(source), smoother=smoother, tolerance=1e-8)
+    xr, pr = ref.solve(np.zeros(N), source, tolerance=1e-8)
+    assert pf["nIterations"] == pr["nIterations"] and pf["converged"], (pf, pr)
+    assert rel_l2(psi.cpu().numpy(), xr) < 1e-9
+    G.close(); A.close()
