@@ -557,17 +557,31 @@ static int pcg(ffm_ldu *A, int precond, const Controls &k, double *psi, const do
             // update and its norm ride on the forward sweep of the NEXT preconditioner application (which is therefore started
             // before the convergence check: one unused forward sweep per solve), wA.rA on the backward sweep, and psi += alpha pA
             // is deferred into the next search-direction update.  Per-cell arithmetic unchanged.
+            // one more fusion where the tiled Amul runs without ghost faces: the direction update and the deferred solution update
+            // ride on the Amul (k_tile_amul<true, true>: pNew = wA + beta*pOld, psi += alpha*pOld, qA = A pNew, pNew.qA), with
+            // two direction buffers and the Amul result in a vector of its own (FFM_PCG_AMUL_UNFUSED=1: separate k_p_psi)
+            const char *ea = getenv("FFM_PCG_AMUL_UNFUSED");
+            const bool fuseP = ffm_tile_amul_pcg_usable(A) && !(ea && atoi(ea) != 0);
+            double *pB = nullptr, *qA = wA;
+            if (fuseP) { FFM_TRY(ffm_ldu_work(A, 4, &pB)); FFM_TRY(ffm_ldu_work(A, 5, &qA)); }
             do {
                 if (perf->nIterations == 0) {
                     FFM_TRY(ffm_precond_apply_i(A, precond, false, rA, wA));
                     FFM_TRY(ffm_k_dot(c, wA, rA, N, S_TMP0));
                 } else FFM_TRY(ffm_tile_pcg_bwd(A, rA, wA, S_TMP0));
                 FFM_TRY(finish_dot(c, OP_PCG_BETA));
-                if (perf->nIterations == 0) hipLaunchKernelGGL(k_p_update, dim3(g), dim3(256), 0, s, N, pA, wA, c->scal_d, 1);
-                else hipLaunchKernelGGL(k_p_psi, dim3(g), dim3(256), 0, s, N, psi, pA, wA, c->scal_d);
-                FFM_TRY(ffm_k_spmv_dot(A, pA, wA, S_TMP0));
+                if (perf->nIterations == 0) {
+                    hipLaunchKernelGGL(k_p_update, dim3(g), dim3(256), 0, s, N, pA, wA, c->scal_d, 1);
+                    FFM_TRY(ffm_k_spmv_dot(A, pA, qA, S_TMP0));
+                } else if (fuseP) {
+                    FFM_TRY(ffm_tile_amul_pcg(A, wA, pA, pB, psi, qA, S_TMP0));
+                    std::swap(pA, pB);
+                } else {
+                    hipLaunchKernelGGL(k_p_psi, dim3(g), dim3(256), 0, s, N, psi, pA, wA, c->scal_d);
+                    FFM_TRY(ffm_k_spmv_dot(A, pA, qA, S_TMP0));
+                }
                 FFM_TRY(finish_dot(c, OP_PCG_ALPHA));
-                FFM_TRY(ffm_tile_pcg_fwd(A, rA, wA, S_TMP0));
+                FFM_TRY(ffm_tile_pcg_fwd(A, rA, wA, S_TMP0, qA == wA ? nullptr : qA));
                 FFM_TRY(finish_dot(c, OP_RES));
                 FFM_TRY(ffm_read_scalars(c));
                 if (c->scal_h[S_SING] != 0.0) { perf->singular = 1; break; }

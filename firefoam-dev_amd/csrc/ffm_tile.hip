@@ -488,7 +488,7 @@ __device__ __noinline__ double t_wait_value(const double *addr, unsigned int *ti
 //     have a vmcnt stream of their own, so waiting for a mailbox value never waits for the compute waves' read-ahead.
 // Every wave executes the same number of workgroup barriers: one after the prologue, one per entry of the padded loop.
 // FUSE (PCG, DIC): the vector updates on either side of the preconditioner ride on the sweeps' own streams --
-//   TM_FWD: aux = the residual, updated in place first: rA -= alpha*wA (w holds A pA on entry; PCG.C "rA[cell] -= alpha*wA[cell]"),
+//   TM_FWD: aux = the residual, updated in place first: rA -= alpha*q (q = A pA: r when given, else w on entry; PCG.C "rA[cell] -= alpha*wA[cell]"),
 //           partials[group] = sum |rA| (the residual norm of the iteration that just ended);
 //   TM_BWD: partials[group] = sum wA*rA of the finished preconditioned residual (PCG.C wArA = gSumProd(wA, rA)).
 // The per-cell arithmetic is that of k_pcg_xr / the unfused sweep; only the order of the two sums differs (as in any reduction).
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile(TileView t, const doubl
         if (TWO) { const T3 v_ = *(const T3 *)((const char *)cb + o24_); pb[k][0] = v_.a; pb[k][TWO ? 1 : 0] = v_.b; pb[k][TWO ? 2 : 0] = v_.c; } \
         pd[k] = *(const double *)((const char *)dg + o8_);                                               \
         pv[k] = (FUSE && MODE == TM_FWD) ? *(const double *)((const char *)aux + o8_) : (MODE == TM_FWD || MODE == TM_GSF || MODE == TM_GSB) ? *(const double *)((const char *)r + o8_) : (MODE == TM_BWD ? *(const double *)((const char *)w + o8_) : 0.0); \
-        if (FUSE) pv2[FUSE ? k : 0] = (MODE == TM_FWD) ? *(const double *)((const char *)w + o8_) : *(const double *)((const char *)r + o8_); \
+        if (FUSE) pv2[FUSE ? k : 0] = (MODE == TM_FWD) ? *(const double *)((const char *)(r ? r : (const double *)w) + o8_) : *(const double *)((const char *)r + o8_); \
         pc[k] = cc_; pok[k] = ok_; ppb[k] = (unsigned)R_.z;                                              \
     }
 #pragma unroll
@@ -776,7 +776,7 @@ bool ffm_tile_pcg_fusable(const ffm_ldu *A)
     const bool off = e && atoi(e) != 0;
     return !off && ffm_tile_usable(A) && A->tile->mirror && !A->tile->trace && A->tile->G <= 4 * RED_BLOCKS;
 }
-int ffm_tile_pcg_fwd(ffm_ldu *A, double *rA, double *wA, int slot)
+int ffm_tile_pcg_fwd(ffm_ldu *A, double *rA, double *wA, int slot, const double *qA)
 {
     ffm_tile_plan *T = A->tile;
     hipStream_t s = A->ctx->stream;
@@ -785,7 +785,7 @@ int ffm_tile_pcg_fwd(ffm_ldu *A, double *rA, double *wA, int slot)
     FFM_TRY(tile_coef(A, T->b, true, &cb));
     tile_fill(A, T->mailAll, T->nMail);
     hipLaunchKernelGGL((k_tile<TM_FWD, false, false, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->f), cf, (const double *)nullptr,
-                       (const double *)A->rD, (const double *)nullptr, wA, rA, (const double *)A->ctx->scal_d, A->ctx->partials_d);
+                       (const double *)A->rD, qA, wA, rA, (const double *)A->ctx->scal_d, A->ctx->partials_d);
     hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->G, (const double *)A->ctx->partials_d, A->ctx->scal_d, slot);
     FFM_HIP(hipGetLastError());
     return FFM_OK;
@@ -892,11 +892,19 @@ struct AmulView {
 };
 
 // y[c] = diag[c]*x[c] + sum_lower coef*x[l] + sum_upper(owned) coef*x[u]   (lduMatrix::Amul row order); DOT: partial of x.y
-template <bool DOT>
+// FUSEP (PCG): x is not read but formed on the way into the rings, x = w + beta*pin (PCG.C "pA = wA + beta*pA"), and stored to pout
+// by the segment that owns the row, together with psi += alpha*pin (the solution update left over from the iteration before);
+// pin / pout are two buffers (a neighbouring workgroup may still need the old direction), y must not alias w.
+template <bool DOT, bool FUSEP = false>
 __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const double *__restrict__ bc, const double *__restrict__ upper,
                                                               const double *__restrict__ diag, const double *__restrict__ x,
-                                                              double *__restrict__ y, double *__restrict__ partials)
+                                                              double *__restrict__ y, double *__restrict__ partials,
+                                                              const double *__restrict__ pin = nullptr, double *__restrict__ pout = nullptr,
+                                                              double *__restrict__ psi = nullptr, const double *__restrict__ scal = nullptr)
 {
+    // FUSEP: x = w on entry.  A singular flag leaves direction and solution as they are (k_p_psi's guard)
+    const bool fSing = FUSEP ? (scal[S_SING] != 0.0) : false;
+    const double fBeta = FUSEP ? scal[S_BETA] : 0.0, fAlpha = FUSEP ? scal[S_ALPHA] : 0.0;
     __shared__ double xring[A_RING + 2 * A_XMAX];           // x of the window, then the two external-x buffers
     __shared__ double cring[3 * A_RING + 2 * A_XMAX];       // upper coefficients of the window, then the external coefficients
     __shared__ int4 shRec[4];
@@ -915,15 +923,18 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
             int4 qrec[A_PF];
             unsigned qne[A_PF];
             int2 qi0[A_PF], qi1[A_PF];
-            double qx0[A_PF], qx1[A_PF], qc0[A_PF], qc1[A_PF];
+            double qx0[A_PF], qx1[A_PF], qc0[A_PF], qc1[A_PF], qp0[FUSEP ? A_PF : 1], qp1[FUSEP ? A_PF : 1];
 #define Q_REC(k, e) { qrec[k] = t.rec[min((e), e1)]; }
 #define Q_IDX(k, e) { const int4 R_ = qrec[k]; qne[k] = ((e) < e1) ? ((unsigned)R_.y >> 16) : 0u;                       \
                       qi0[k] = t.ext[(unsigned)R_.z + (lane < qne[k] ? lane : 0u)];                                     \
                       qi1[k] = t.ext[(unsigned)R_.z + (lane + 64u < qne[k] ? lane + 64u : 0u)]; }
-#define Q_VAL(k) { qx0[k] = x[qi0[k].x]; qx1[k] = x[qi1[k].x]; qc0[k] = upper[max(qi0[k].y, 0)]; qc1[k] = upper[max(qi1[k].y, 0)]; }
+#define Q_VAL(k) { qx0[k] = x[qi0[k].x]; qx1[k] = x[qi1[k].x]; qc0[k] = upper[max(qi0[k].y, 0)]; qc1[k] = upper[max(qi1[k].y, 0)];     \
+                   if (FUSEP) { qp0[FUSEP ? k : 0] = pin[qi0[k].x]; qp1[FUSEP ? k : 0] = pin[qi1[k].x]; } }
+#define Q_X0(k) (FUSEP ? (fSing ? qp0[FUSEP ? k : 0] : qx0[k] + fBeta * qp0[FUSEP ? k : 0]) : qx0[k])
+#define Q_X1(k) (FUSEP ? (fSing ? qp1[FUSEP ? k : 0] : qx1[k] + fBeta * qp1[FUSEP ? k : 0]) : qx1[k])
 #define Q_PUT(k, e) { const unsigned hb_ = (unsigned)((e) & 1) * (unsigned)A_XMAX;                                      \
-                      if (lane < qne[k]) { xring[A_RING + hb_ + lane] = qx0[k]; cring[3 * A_RING + hb_ + lane] = qc0[k]; } \
-                      if (lane + 64u < qne[k]) { xring[A_RING + hb_ + lane + 64u] = qx1[k]; cring[3 * A_RING + hb_ + lane + 64u] = qc1[k]; } }
+                      if (lane < qne[k]) { xring[A_RING + hb_ + lane] = Q_X0(k); cring[3 * A_RING + hb_ + lane] = qc0[k]; } \
+                      if (lane + 64u < qne[k]) { xring[A_RING + hb_ + lane + 64u] = Q_X1(k); cring[3 * A_RING + hb_ + lane + 64u] = qc1[k]; } }
 #pragma unroll
             for (int k = 0; k < A_PF; k++) Q_REC(k, e0 + k);
 #pragma unroll
@@ -949,12 +960,14 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
 #undef Q_IDX
 #undef Q_VAL
 #undef Q_PUT
+#undef Q_X0
+#undef Q_X1
         } else {
             // ---------------------------------------------------------------- compute waves
             unsigned pc[A_PF];
             bool pok[A_PF], pst[A_PF];
             uint4 pq[A_PF];
-            double pb[A_PF][3], pd[A_PF], px[A_PF];
+            double pb[A_PF][3], pd[A_PF], px[A_PF], pp[FUSEP ? A_PF : 1], ps[FUSEP ? A_PF : 1];
 #define A_FETCH(k, e, R_) {                                                                              \
         const unsigned cnt_ = ((e) < e1) ? ((unsigned)(R_).y & 0xFFFFu) : 0u;                            \
         const bool ok_ = tid < cnt_;                                                                     \
@@ -964,9 +977,11 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
         { const T3 v_ = *(const T3 *)((const char *)bc + cc_ * 24u); pb[k][0] = v_.a; pb[k][1] = v_.b; pb[k][2] = v_.c; } \
         pd[k] = *(const double *)((const char *)diag + o8_);                                             \
         px[k] = *(const double *)((const char *)x + o8_);                                                \
+        if (FUSEP) { pp[FUSEP ? k : 0] = *(const double *)((const char *)pin + o8_); ps[FUSEP ? k : 0] = *(const double *)((const char *)psi + o8_); } \
         pc[k] = cc_; pok[k] = ok_; pst[k] = ok_ && (e) >= sa && (e) < sb;                                \
     }
-#define A_FILL(k) { if (pok[k]) { const unsigned i_ = (pc[k] - gs) & (unsigned)(A_RING - 1); xring[i_] = px[k];    \
+#define A_FILL(k) { if (FUSEP) px[k] = fSing ? pp[FUSEP ? k : 0] : px[k] + fBeta * pp[FUSEP ? k : 0];                      \
+                    if (pok[k]) { const unsigned i_ = (pc[k] - gs) & (unsigned)(A_RING - 1); xring[i_] = px[k];    \
                                    cring[3u * i_] = pb[k][0]; cring[3u * i_ + 1u] = pb[k][1]; cring[3u * i_ + 2u] = pb[k][2]; } }
 #pragma unroll
             for (int k = 0; k < A_PF; k++) { const int4 R0 = t.rec[min(e0 + k, e1)]; A_FETCH(k, e0 + k, R0); }
@@ -1004,6 +1019,10 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
                             acc = (u != A_NONE) ? nv : acc;
                         }
                         if (pst[k]) __builtin_nontemporal_store(acc, (double *)((char *)y + c * 8u));
+                        if (FUSEP && pst[k]) {
+                            *(double *)((char *)pout + c * 8u) = xc;
+                            if (!fSing) *(double *)((char *)psi + c * 8u) = ps[FUSEP ? k : 0] + fAlpha * pp[FUSEP ? k : 0];
+                        }
                         if (DOT) dot += pst[k] ? acc * xc : 0.0;
                     }
                     A_FILL((k + A_AHEAD) % A_PF);           // rings: entry ee + A_AHEAD
@@ -1056,6 +1075,25 @@ __global__ __launch_bounds__(1024) void k_tile_sum_partials(int n, const double 
 }
 
 bool ffm_tile_amul_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable && A->symmetric && A->ifaces.empty(); }
+
+// PCG: pout = w + beta*pin, psi += alpha*pin, y = A pout, scal[dotSlot] = pout.y (local), in one pass (k_tile_amul<true, true>)
+bool ffm_tile_amul_pcg_usable(const ffm_ldu *A)
+{
+    return ffm_tile_amul_usable(A) && A->tile->nTail == 0 && A->ghNbrRank.empty();
+}
+int ffm_tile_amul_pcg(ffm_ldu *A, const double *w, const double *pin, double *pout, double *psi, double *y, int dotSlot)
+{
+    ffm_tile_plan *T = A->tile;
+    hipStream_t s = A->ctx->stream;
+    const double *bcoef;
+    FFM_TRY(tile_up_coef_cell(A, &bcoef));
+    AmulView v; v.G = T->G; v.grpCell = A->grpCell; v.grpEnt = T->f.grpEnt; v.rec = T->arec; v.seg = T->aseg; v.code = T->acode; v.ext = T->aext;
+    hipLaunchKernelGGL((k_tile_amul<true, true>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, w, y,
+                       T->amulPartials, pin, pout, psi, (const double *)A->ctx->scal_d);
+    hipLaunchKernelGGL(k_tile_sum_partials, dim3(1), dim3(1024), 0, s, T->nSeg, (const double *)T->amulPartials, A->ctx->scal_d, dotSlot);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
 
 // y = A x (symmetric A); dotSlot >= 0: also scal[dotSlot] = x.y over the owned rows (local part)
 int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot)
