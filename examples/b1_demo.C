@@ -397,3 +397,33 @@ extern "C" int b1_gamg_solve(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, ffm_gamg
     if (sp.solverName != "GAMG") FatalError("solverName " + sp.solverName);
     return sp.nIterations;
 }
+
+// The field writer and the nonuniform-list reader of include/ffmDictionary.H (on-disk formats): writes a field file
+// for nCells cells and the patches `names` (blank-separated; patch q has sizes[q] faces and type types[q]; its `value` entry is
+// the next sizes[q] faces of patchValues), then reads it back into internalOut / patchOut.  Returns the component count read.
+extern "C" int b1_field_roundtrip(const char* path, const char* object, int nCmpt, int nCells, const double* internal, const char* names,
+                                  const char* types, const int* sizes, const double* patchValues, double* internalOut, double* patchOut)
+{
+    std::vector<patchFieldEntry> patches;
+    std::istringstream ns(names), ts(types); word n, t; size_t off = 0; int q = 0;
+    while (ns >> n && ts >> t) {
+        patchFieldEntry p; p.name = n; p.type = t;
+        if (t == "inletOutlet") p.entries.push_back({"inletValue", nCmpt == 1 ? "uniform 298.15" : "uniform (0 0 0)"});
+        if (t != "zeroGradient") p.value.assign(patchValues + off, patchValues + off + (size_t)sizes[q]*nCmpt);
+        off += (size_t)sizes[q]*nCmpt; q++;
+        patches.push_back(p);
+    }
+    writeFieldFile(path, object, "0.066666667", nCmpt == 1 ? "[0 0 0 1 0 0 0]" : "[0 1 -1 0 0 0 0]", nCmpt,
+                   std::vector<scalar>(internal, internal + (size_t)nCells*nCmpt), patches);
+    const fieldFile ff(path);
+    int nc = 0;
+    const std::vector<scalar> in = ff.internalFieldValues(nCells, &nc);
+    std::copy(in.begin(), in.end(), internalOut);
+    off = 0; q = 0;
+    for (const patchFieldEntry& p : patches) {
+        if (ff.patchType(p.name) != p.type) FatalError("patch type read back differs");
+        if (!p.value.empty()) { const std::vector<scalar> v = ff.patchValues(p.name, sizes[q]); std::copy(v.begin(), v.end(), patchOut + off); }
+        off += (size_t)sizes[q]*nCmpt; q++;
+    }
+    return nc;
+}

@@ -139,3 +139,45 @@ def test_burner_patch_entries_of_the_steckler_case():
     for name, want in (("C3H8", 1.0), ("O2", 0.0), ("Ydefault", 0.0), ("N2", 0.0)):
         lib.b1_read_function1(os.path.join(REF, "steckler", "0", name).encode(), b"burner", b"", None, 0, C.byref(mff))
         assert mff.value == want, name
+
+
+@pytest.mark.parametrize("nCmpt", [1, 3])
+def test_field_files_are_written_and_read_back(tmp_path, nCmpt):
+    """SURVEY 8f N4, on-disk formats: include/ffmDictionary.H writes a volScalarField / volVectorField file the way OpenFOAM does
+    with `writeFormat ascii; writePrecision 8` (cases/steckler/system/controlDict:36-38) -- banner, FoamFile header, `uniform v`
+    for a constant list and `nonuniform List<scalar|vector> N ( ... )` otherwise -- and reads such a file back, element by
+    element (8 significant digits).  The reference ships only `uniform` 0/ files, so the nonuniform form is pinned by OpenFOAM's
+    documented layout (parity unpinned by reference data)."""
+    lib, _ = _lib()
+    dp = C.POINTER(C.c_double)
+    nCells = 37
+    rng = np.random.default_rng(11)
+    internal = 300.0 + 50.0 * rng.standard_normal((nCells, nCmpt))
+    names, types, sizes = ["top", "sides", "floor", "burner"], ["inletOutlet", "fixedValue", "zeroGradient", "fixedValue"], [5, 12, 7, 3]
+    pv = [rng.standard_normal((n, nCmpt)) for n in sizes]
+    pv[3][:] = pv[3][0]                                            # a constant list is written `uniform`
+    pvals = np.ascontiguousarray(np.concatenate(pv))
+    iout = np.zeros_like(internal); pout = np.full_like(pvals, np.nan)
+    path = str(tmp_path / "T")
+    lib.b1_field_roundtrip.restype = C.c_int
+    lib.b1_field_roundtrip.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, dp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), dp, dp, dp]
+    nc = lib.b1_field_roundtrip(path.encode(), b"T", nCmpt, nCells, np.ascontiguousarray(internal).ctypes.data_as(dp), " ".join(names).encode(),
+                                " ".join(types).encode(), (C.c_int * 4)(*sizes), pvals.ctypes.data_as(dp), iout.ctypes.data_as(dp), pout.ctypes.data_as(dp))
+    assert nc == nCmpt
+    assert np.abs(iout - internal).max() <= 5e-8 * np.abs(internal).max()
+    off = 0
+    for n, t, v in zip(sizes, types, pv):
+        got = pout[off:off + n]
+        if t == "zeroGradient":
+            assert np.all(np.isnan(got))                               # no value entry written
+        else:
+            assert np.abs(got - v).max() <= 5e-8 * max(np.abs(v).max(), 1.0)
+        off += n
+    text = open(path).read()
+    cls = "volScalarField" if nCmpt == 1 else "volVectorField"
+    assert "class       %s;" % cls in text and 'location    "0.066666667";' in text and "object      T;" in text
+    assert "internalField   nonuniform List<%s> \n%d\n(\n" % ("scalar" if nCmpt == 1 else "vector", nCells) in text
+    first = ("%.8g" % internal[0, 0]) if nCmpt == 1 else "(" + " ".join("%.8g" % x for x in internal[0]) + ")"
+    assert "(\n" + first + "\n" in text
+    assert "    burner\n    {\n        type            fixedValue;\n        value           uniform " in text
+    assert "        inletValue      uniform " in text and text.rstrip().endswith("// ************************************************************************* //")
