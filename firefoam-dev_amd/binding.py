@@ -169,6 +169,7 @@ def lib():
         "ffm_polymesh_addressing": ([vp, ip, ip], C.c_int),
         "ffm_polymesh_geometry": ([vp] + [C.POINTER(C.c_double)] * 8, C.c_int),
         "ffm_polymesh_patch": ([vp, C.c_int, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
+        "ffm_polymesh_patch_processor": ([vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)], C.c_int),
         "ffm_polymesh_patch_geometry": ([vp, C.c_int, ip] + [C.POINTER(C.c_double)] * 3, C.c_int),
         "ffm_fv_lust_correction": ([vp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fvc_snGrad_correction": ([vp, dp, dp, dp, dp], C.c_int),

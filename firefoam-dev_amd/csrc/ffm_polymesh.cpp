@@ -102,7 +102,7 @@ struct Tokens {
     }
 };
 
-struct Patch { std::string name, type; int start = 0, size = 0; };
+struct Patch { std::string name, type; int start = 0, size = 0; int myProcNo = -1, neighbProcNo = -1; };
 }  // namespace
 
 struct ffm_polymesh {
@@ -178,6 +178,9 @@ static bool read_all(const std::string &dir, ffm_polymesh *m)
                 else if (depth == 1 && w == "type") P.type = k.next();
                 else if (depth == 1 && w == "nFaces") { long v; if (!k.label(v) || v < 0 || v > (long)m->faces.size()) return false; P.size = (int)v; }
                 else if (depth == 1 && w == "startFace") { long v; if (!k.label(v) || v < 0 || v > (long)m->faces.size()) return false; P.start = (int)v; }
+                // processorPolyPatch of a processorN/constant/polyMesh/boundary written by decomposePar
+                else if (depth == 1 && w == "myProcNo") { long v; if (!k.label(v) || v < 0) return false; P.myProcNo = (int)v; }
+                else if (depth == 1 && w == "neighbProcNo") { long v; if (!k.label(v) || v < 0) return false; P.neighbProcNo = (int)v; }
             }
             if (P.start < (int)m->neighbour.size() || (long)P.start + P.size > (long)m->faces.size()) { ffm_set_error("polyMesh: patch %s out of range", P.name.c_str()); return false; }
             m->patches.push_back(P);
@@ -285,6 +288,17 @@ extern "C" int ffm_polymesh_geometry(const ffm_polymesh *m, double *V, double *C
         if (nonOrthDeltaCoeffs) nonOrthDeltaCoeffs[f] = m->nonOrthDelta[f];
     }
     return FFM_OK;
+}
+// 1: patch i is a processor patch (`type processor`) and *myProcNo / *neighbProcNo are its entries; 0: it is not
+extern "C" int ffm_polymesh_patch_processor(const ffm_polymesh *m, int i, int *myProcNo, int *neighbProcNo)
+{
+    if (!m || i < 0 || i >= (int)m->patches.size()) return FFM_ERR_ARG;
+    const Patch &P = m->patches[i];
+    if (P.type != "processor") return 0;
+    if (P.myProcNo < 0 || P.neighbProcNo < 0) { ffm_set_error("polyMesh: processor patch %s without myProcNo / neighbProcNo", P.name.c_str()); return FFM_ERR_ARG; }
+    if (myProcNo) *myProcNo = P.myProcNo;
+    if (neighbProcNo) *neighbProcNo = P.neighbProcNo;
+    return 1;
 }
 extern "C" int ffm_polymesh_patch(const ffm_polymesh *m, int i, char *name64, char *type32, int *startFace, int *nFaces)
 {

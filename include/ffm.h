@@ -549,6 +549,10 @@ int ffm_polymesh_addressing(const ffm_polymesh *pm, int *lowerAddr, int *upperAd
 int ffm_polymesh_geometry(const ffm_polymesh *pm, double *V, double *C, double *Sf, double *Cf, double *magSf, double *weights,
                           double *nonOrthDeltaCoeffs, double *nonOrthCorrectionVectors);
 int ffm_polymesh_patch(const ffm_polymesh *pm, int i, char *name64, char *type32, int *startFace, int *nFaces);
+/* processorN/constant/polyMesh of a case decomposed by decomposePar: 1 if patch i is `type processor` (then *myProcNo and
+ * *neighbProcNo hold its entries), 0 if not.  Its faceCells (ffm_polymesh_patch_geometry) and the neighbour rank are the
+ * faceCells / neighbRank of ffm_ldu_set_interfaces; both sides list the faces of a processor patch in the same order. */
+int ffm_polymesh_patch_processor(const ffm_polymesh *pm, int i, int *myProcNo, int *neighbProcNo);
 int ffm_polymesh_patch_geometry(const ffm_polymesh *pm, int i, int *faceCells, double *Sf, double *Cf, double *deltaCoeffs);
 
 #ifdef __cplusplus

@@ -58,7 +58,8 @@ def write_polymesh(path, mesh, lo, M=None, patch_types=None):
             axis = int(np.argmax(np.abs(S)))
             faces.append(_face_vertices(nx, ny, ci[c], cj[c], ck[c], axis, S[axis] > 0))
             owner.append(int(c))
-        bnd.append((p.name, (patch_types or {}).get(p.name, "patch"), p.size, start))
+        t = (patch_types or {}).get(p.name, "patch")
+        bnd.append((p.name,) + (t if isinstance(t, tuple) else (t, {})) + (p.size, start))
     with open(os.path.join(path, "points"), "w") as f:
         f.write(HEADER % ("vectorField", "points"))
         f.write("%d\n(\n" % len(pts))
@@ -81,9 +82,12 @@ def write_polymesh(path, mesh, lo, M=None, patch_types=None):
     with open(os.path.join(path, "boundary"), "w") as f:
         f.write(HEADER % ("polyBoundaryMesh", "boundary"))
         f.write("%d\n(\n" % len(bnd))
-        for name, typ, n, start in bnd:
+        for name, typ, extra, n, start in bnd:           # extra: further keywords (a processor patch's myProcNo / neighbProcNo)
             f.write("    %s\n    {\n        type            %s;\n" % (name, typ))
             if typ == "wall":
                 f.write("        inGroups        1(wall);\n")
-            f.write("        nFaces          %d;\n        startFace       %d;\n    }\n" % (n, start))
+            f.write("        nFaces          %d;\n        startFace       %d;\n" % (n, start))
+            for k, v in extra.items():
+                f.write("        %-15s %s;\n" % (k, v))
+            f.write("    }\n")
         f.write(")\n")
