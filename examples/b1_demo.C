@@ -8,6 +8,7 @@
   tests/test_foam_layer_gpu.py, which evaluates the same equations with oracle/fv.py and compares the fields.
 \*---------------------------------------------------------------------------*/
 #include "ffmFoam.H"
+#include "fireFoamHandles.H"
 
 using namespace Foam;
 
@@ -426,4 +427,30 @@ extern "C" int b1_field_roundtrip(const char* path, const char* object, int nCmp
         off += (size_t)sizes[q]*nCmpt; q++;
     }
     return nc;
+}
+
+// thermo.correct() of the reference's own package through its handle (include/fireFoamHandles.H hePsiThermoJanaf over ffm_thermo_*):
+// host arrays in, T / psi / mu / alpha / he of the cells [N] and of the boundary faces [B] out.  Y: nSpecies cell arrays, Yb: boundary.
+extern "C" int b1_thermo_handle(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, ffm_thermo* th, int nSpecies, const double* const* Y, const double* const* Yb,
+                                const double* heC, const double* heB, const double* pC, const double* pB, const double* TC, const double* TB,
+                                const double* fixesT, double* outC, double* outB)
+{
+    fvMesh mesh(ctx, ldu, msh, 1.0);
+    hePsiThermoJanaf thermo(mesh, th, fixesT);
+    for (int i = 0; i < nSpecies; i++) {
+        thermo.comp_.species_.push_back("Y" + std::to_string(i)); thermo.comp_.active_.push_back(true);
+        thermo.comp_.Y_.append(new volScalarField(thermo.comp_.species_.back(), mesh));
+        thermo.comp_.Y_[i].v.assignHost(Y[i]); thermo.comp_.Y_[i].b.assignHost(Yb[i]);
+    }
+    thermo.he().v.assignHost(heC); thermo.he().b.assignHost(heB);
+    thermo.p().v.assignHost(pC); thermo.p().b.assignHost(pB);
+    thermo.T().v.assignHost(TC); thermo.T().b.assignHost(TB);
+    thermo.correct();
+    FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    const label N = mesh.nCells, B = mesh.nBoundary;
+    const volScalarField* f[5] = {&thermo.T(), &thermo.psi(), &thermo.mu(), &thermo.alpha(), &thermo.he()};
+    for (int k = 0; k < 5; k++) { f[k]->v.toHost(outC + (size_t)k*N); f[k]->b.toHost(outB + (size_t)k*B); }
+    const volScalarField rho(thermo.rho());
+    rho.v.toHost(outC + (size_t)5*N); rho.b.toHost(outB + (size_t)5*B);
+    return 0;
 }

@@ -9,7 +9,7 @@ fallback: every compute entry point needs libffm.so and a GPU.
 """
 from .binding import (  # noqa: F401
     Context, lduMatrix, FfmError, lib, build, libpath, SOLVERS, PRECONDS, tile_hint_from_centres,
-    renumber_levels, exported_symbols, declared_symbols, Plume, fvMesh, PyrolysisPanel, GAMG,
+    renumber_levels, exported_symbols, declared_symbols, Plume, fvMesh, PyrolysisPanel, GAMG, Thermo,
 )
 from . import hexmesh  # noqa: F401
 from . import decompose  # noqa: F401

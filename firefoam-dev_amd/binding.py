@@ -142,6 +142,13 @@ def lib():
         "ffm_pyro_couple_d": ([vp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp], C.c_int),
         "ffm_pyro_qSurf_d": ([vp], C.c_void_p),
         "ffm_pyro_destroy": ([vp], C.c_int),
+        "ffm_thermo_create": ([vp, C.c_int] + [hp] * 8 + [C.c_double, C.POINTER(vp)], C.c_int),
+        "ffm_thermo_correct_d": ([vp, C.c_long, C.POINTER(vp), dp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_thermo_he_d": ([vp, C.c_long, C.POINTER(vp), dp, dp], C.c_int),
+        "ffm_thermo_properties_d": ([vp, C.c_long, C.POINTER(vp), dp, dp, dp, dp], C.c_int),
+        "ffm_thermo_destroy": ([vp], C.c_int),
+        "ffm_edc_correct_d": ([vp, C.c_long] + [dp] * 6 + [C.c_double] * 7 + [dp, dp], C.c_int),
+        "ffm_les_keqn_nut_d": ([vp, C.c_long, C.c_double, C.c_double, dp, dp, dp, dp, dp], C.c_int),
         "ffm_gamg_face_area_pair_weights": ([C.c_int, hp, hp], C.c_int),
         "ffm_gamg_create": ([vp, vp, C.c_int, C.c_int, ip, ip, hp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
         "ffm_gamg_set_sweeps": ([vp, C.c_int, C.c_int, C.c_int], C.c_int),
@@ -621,6 +628,39 @@ class Plume:
 
     def ldu_handle(self):
         return lib().ffm_plume_ldu(self.h)
+
+
+class Thermo:
+    """hePsiThermo of a janaf / sutherland / perfectGas mixture on the device (ffm_thermo_*).  table: {specie: dict(W, Tlow, Thigh,
+    Tcommon, high[7], low[7], As, Ts)} with the thermo file's (molar) coefficients; species: their order"""
+
+    def __init__(self, ctx, species, table, RR):
+        self.ctx, self.n = ctx, len(species)
+        col = lambda k: np.ascontiguousarray([float(table[s][k]) for s in species], np.float64)
+        hi = np.ascontiguousarray([np.asarray(table[s]["high"], float) for s in species]); lo = np.ascontiguousarray([np.asarray(table[s]["low"], float) for s in species])
+        h = C.c_void_p()
+        _check(lib().ffm_thermo_create(ctx.h, self.n, _hp(col("W")), _hp(col("Tlow")), _hp(col("Thigh")), _hp(col("Tcommon")), _hp(hi), _hp(lo),
+                                       _hp(col("As")), _hp(col("Ts")), float(RR), C.byref(h)), "ffm_thermo_create")
+        self.h = h
+
+    def _Y(self, Y):
+        self._keep = Y
+        return (C.c_void_p * self.n)(*[y.data_ptr() for y in Y])
+
+    def correct(self, Y, he, p, T, psi=None, mu=None, alpha=None):
+        """in place: T (start value in, T(he) out), psi, mu, alpha; torch CUDA fp64 tensors, Y a list of nSpecies"""
+        self.ctx._ready()
+        P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _check(lib().ffm_thermo_correct_d(self.h, he.numel(), self._Y(Y), P(he), P(p), P(T), P(psi), P(mu), P(alpha)), "ffm_thermo_correct_d")
+
+    def he(self, Y, T, out):
+        self.ctx._ready()
+        _check(lib().ffm_thermo_he_d(self.h, T.numel(), self._Y(Y), C.c_void_p(T.data_ptr()), C.c_void_p(out.data_ptr())), "ffm_thermo_he_d")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ffm_thermo_destroy(self.h)
+            self.h = None
 
 
 class GAMG:

@@ -436,6 +436,33 @@ int ffm_pyro_couple_d(ffm_pyro *p, const int *map_d, const double *TgasCell_d, c
 const double *ffm_pyro_qSurf_d(const ffm_pyro *p);
 int ffm_pyro_destroy(ffm_pyro *p);
 
+/* ------------------------------------------------------- thermo, combustion, LES (N2) */
+/* The per-cell physics the reference's time step calls between its equations, one streaming kernel each.
+ * ffm_thermo_*: hePsiThermo<reactingMixture<sutherland<janaf<perfectGas<specie>>>>, sensibleEnthalpy> (cases/steckler/constant/
+ *   thermophysicalProperties:18-27, thermo.compressibleGas): replaces thermo.correct() (solver/YEEqn.H:114) = hePsiThermo::
+ *   calculate() -- cell (or patch-face) mixture by mass fractions, T from he by thermo::T's Newton iteration started at the old
+ *   T, psi = 1/(R T), Sutherland mu, alpha = kappa(modified Eucken)/Cp -- and he = Hs(T) where a patch fixes T.  Species table as
+ *   in the thermo file (molar coefficients; highCpCoeffs / lowCpCoeffs [nSpecies][7]); Y_d: nSpecies device pointers.
+ * ffm_edc_correct_d: the reference's eddyDissipationModel::correct (lib/thermophysicalModels/combustionModels/
+ *   eddyDissipationModel/eddyDissipationModel.C:93-149) with kEqn::epsilon = Ce k sqrt(k)/delta: wFuel and Qdot = qFuel wFuel.
+ * ffm_les_keqn_nut_d: kEqn::correctNut (nut = Ck sqrt(k) delta) and alphat = rho nut/Prt (alphat_d null: nut only). */
+typedef struct ffm_thermo ffm_thermo;
+int ffm_thermo_create(ffm_ctx *ctx, int nSpecies, const double *W, const double *Tlow, const double *Thigh, const double *Tcommon,
+                      const double *highCpCoeffs, const double *lowCpCoeffs, const double *As, const double *Ts, double RR,
+                      ffm_thermo **out);
+int ffm_thermo_correct_d(ffm_thermo *th, long n, const double *const *Y_d, const double *he_d, const double *p_d, double *T_d,
+                         double *psi_d, double *mu_d, double *alpha_d);
+int ffm_thermo_he_d(ffm_thermo *th, long n, const double *const *Y_d, const double *T_d, double *he_d);
+/* psi, mu, alpha (each nullable) of the mixture at a given temperature, no iteration (patch faces whose T is fixed) */
+int ffm_thermo_properties_d(ffm_thermo *th, long n, const double *const *Y_d, const double *T_d, double *psi_d, double *mu_d,
+                            double *alpha_d);
+int ffm_thermo_destroy(ffm_thermo *th);
+int ffm_edc_correct_d(ffm_ctx *ctx, long n, const double *rho_d, const double *k_d, const double *delta_d, const double *alpha_d,
+                      const double *Yfuel_d, const double *YO2_d, double s, double deltaT, double Ce, double C_EDC, double C_Diff,
+                      double C_Stiff, double qFuel, double *wFuel_d, double *Qdot_d);
+int ffm_les_keqn_nut_d(ffm_ctx *ctx, long n, double Ck, double Prt, const double *k_d, const double *delta_d, const double *rho_d,
+                       double *nut_d, double *alphat_d);
+
 /* ------------------------------------------------------------------------ GAMG */
 /* lduMatrix::solver::New(... solver GAMG ...) as the reference's dictionaries select it: agglomerator faceAreaPair,
  * mergeLevels 1, nCellsInCoarsestLevel 10, cacheAgglomeration true, smoother GaussSeidel for p_rgh / ph_rgh
