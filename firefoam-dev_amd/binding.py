@@ -187,6 +187,11 @@ def lib():
         "ffm_fvm_scalar_transport_multi": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
                                            + [C.POINTER(C.c_void_p)] * 16, C.c_int),
         "ffm_fvm_lust_source3": ([vp, C.c_double, dp, dp] + [C.POINTER(C.c_void_p)] * 5, C.c_int),
+        "ffm_fvc_div_dev2T_gradU": ([vp, C.POINTER(vp), dp, dp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)], C.c_int),
+        "ffm_les_keqn_G": ([vp, C.POINTER(vp), dp, dp], C.c_int),
+        "ffm_fvm_HbyA3": ([vp, dp, dp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), dp, C.POINTER(vp)], C.c_int),
+        "ffm_fvc_flux_rho": ([vp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fvm_pressure_eqn": ([vp, C.c_double] + [dp] * 6 + [C.c_double] + [dp] * 9, C.c_int),
         "ffm_mesh_nboundary": ([vp], C.c_int),
         "ffm_mesh_nnative": ([vp], C.c_int),
         "ffm_faces_to_native": ([vp, hp, dp], C.c_int),

@@ -463,6 +463,14 @@ int ffm_edc_correct_d(ffm_ctx *ctx, long n, const double *rho_d, const double *k
 int ffm_les_keqn_nut_d(ffm_ctx *ctx, long n, double Ck, double Prt, const double *k_d, const double *delta_d, const double *rho_d,
                        double *nut_d, double *alphat_d);
 
+/* turbulence->divDevRhoReff(U) (solver/UEqn.H:12), explicit part: out[j] = component j of fvc::div(gamma*dev2(T(fvc::grad(U)))),
+ * Gauss linear, from the nine cell gradients g[3*i + j] = d_i U_j (ffm_fvc_grad_multi of the three components), gamma = rho*nuEff
+ * on cells / patch faces, U and its patch values (the boundary gradient is gaussGrad's corrected one).  The implicit part is
+ * ffm_fvm_transport with gamma_f.  ffm_les_keqn_G: G = nut*(gradU && dev(twoSymm(gradU))) of kEqn::correct. */
+int ffm_fvc_div_dev2T_gradU(ffm_mesh *m, const double *const *g, const double *gamma, const double *gamma_b,
+                            const double *const *U, const double *const *U_b, double *const *out);
+int ffm_les_keqn_G(ffm_mesh *m, const double *const *g, const double *nut, double *G);
+
 /* ------------------------------------------------------------------------ GAMG */
 /* lduMatrix::solver::New(... solver GAMG ...) as the reference's dictionaries select it: agglomerator faceAreaPair,
  * mergeLevels 1, nCellsInCoarsestLevel 10, cacheAgglomeration true, smoother GaussSeidel for p_rgh / ph_rgh
