@@ -1,5 +1,6 @@
 // ffm_ctx.hip -- context, error reporting, device-memory helpers, reductions.
 #include "ffm_internal.hpp"
+#include <algorithm>
 #include "ffm_device.hpp"
 #include <cstdarg>
 
@@ -67,6 +68,17 @@ extern "C" int ffm_ctx_trim(ffm_ctx *c)
     c->poolFree.clear(); c->poolCachedBytes = 0;
     return FFM_OK;
 }
+__global__ void k_zero_bytes8(size_t n8, unsigned long long *__restrict__ d)
+{ for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) d[i] = 0ull; }
+// zero-fill on the context's stream by a kernel of this library (size classes are multiples of 8 bytes)
+static int pool_zero(ffm_ctx *c, void *p, size_t bytes)
+{
+    const size_t n8 = bytes / 8;
+    if (n8) hipLaunchKernelGGL(k_zero_bytes8, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n8 + 255) / 256, 4096))), dim3(256), 0, c->stream, n8, (unsigned long long *)p);
+    if (bytes % 8) FFM_HIP(hipMemsetAsync((char *)p + 8 * n8, 0, bytes % 8, c->stream));
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
 extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p)
 {
     if (!c || !p) return FFM_ERR_ARG;
@@ -74,7 +86,7 @@ extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p)
     auto it = c->poolFree.find(cls);
     if (it != c->poolFree.end() && !it->second.empty()) {
         *p = it->second.back(); it->second.pop_back(); c->poolCachedBytes -= cls;
-        FFM_HIP(hipMemsetAsync(*p, 0, cls, c->stream));          // as fresh memory: the padding slots of face arrays must read 0
+        FFM_TRY(pool_zero(c, *p, cls));          // as fresh memory: the padding slots of face arrays must read 0
         return FFM_OK;
     }
     FFM_HIP(hipSetDevice(c->device));
@@ -84,7 +96,7 @@ extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p)
         FFM_HIP(hipMalloc(p, cls));
     }
     c->poolSize[*p] = cls;
-    FFM_HIP(hipMemsetAsync(*p, 0, cls, c->stream));
+    FFM_TRY(pool_zero(c, *p, cls));
     return FFM_OK;
 }
 extern "C" int ffm_free(ffm_ctx *c, void *p)
@@ -100,7 +112,11 @@ extern "C" int ffm_free(ffm_ctx *c, void *p)
     return FFM_OK;
 }
 extern "C" int ffm_memcpy_h2d(ffm_ctx *c, void *d, const void *s, size_t n)
-{ FFM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK; }
+{
+    // Every host <-> device copy of the layer goes through the context's stream and is waited for: blocks handed out by
+    // ffm_malloc carry a zero-fill queued on that (non-blocking) stream, which a null-stream copy does not wait for.
+    FFM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK;
+}
 extern "C" int ffm_memcpy_d2h(ffm_ctx *c, void *d, const void *s, size_t n)
 { FFM_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream)); return FFM_OK; }
 extern "C" int ffm_memcpy_d2d(ffm_ctx *c, void *d, const void *s, size_t n)
@@ -258,3 +274,6 @@ extern "C" int ffm_field_unary(ffm_ctx *c, int op, long n, const double *a, doub
 }
 extern "C" int ffm_field_fill(ffm_ctx *c, long n, double s, double *out)
 { return field_launch(c, n, [=] __device__(long) { return s; }, out); }
+
+// debugging aid of the Foam layer (FFM_SYNC_RANGE): every queue of the device drained
+extern "C" int ffm_device_synchronize(void) { FFM_HIP(hipDeviceSynchronize()); return FFM_OK; }

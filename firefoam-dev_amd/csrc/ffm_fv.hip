@@ -159,15 +159,19 @@ extern "C" int ffm_faces_to_native(const ffm_mesh *m, const double *lduOrder, do
     if (!m || !lduOrder || !native_d) return FFM_ERR_ARG;
     std::vector<double> v(std::max(m->nNat, 1), 0.0);
     for (int f = 0; f < m->F; f++) v[m->A->h_callerToNative[f]] = lduOrder[f];
-    FFM_HIP(hipMemcpy(native_d, v.data(), sizeof(double) * m->nNat, hipMemcpyHostToDevice));
+    // on the context's stream, not the null stream: the destination is usually a block fresh from ffm_malloc, whose zero-fill is
+    // still queued on that (non-blocking) stream -- a null-stream copy can land before it and be wiped (seen with two
+    // processes sharing the GPU: flux fields arriving as zeros, round 2)
+    FFM_HIP(hipMemcpyAsync(native_d, v.data(), sizeof(double) * m->nNat, hipMemcpyHostToDevice, m->ctx->stream));
+    FFM_HIP(hipStreamSynchronize(m->ctx->stream));
     return FFM_OK;
 }
 extern "C" int ffm_faces_from_native(const ffm_mesh *m, const double *native_d, double *lduOrder)
 {
     if (!m || !lduOrder || !native_d) return FFM_ERR_ARG;
-    FFM_HIP(hipStreamSynchronize(m->ctx->stream));
     std::vector<double> v(std::max(m->nNat, 1));
-    FFM_HIP(hipMemcpy(v.data(), native_d, sizeof(double) * m->nNat, hipMemcpyDeviceToHost));
+    FFM_HIP(hipMemcpyAsync(v.data(), native_d, sizeof(double) * m->nNat, hipMemcpyDeviceToHost, m->ctx->stream));
+    FFM_HIP(hipStreamSynchronize(m->ctx->stream));
     for (int f = 0; f < m->F; f++) lduOrder[f] = v[m->A->h_callerToNative[f]];
     return FFM_OK;
 }

@@ -702,6 +702,7 @@ extern "C" int ffm_ldu_set_coeffs(ffm_ldu *A, const double *diag, const double *
     FFM_HIP(hipMemcpy(d, diag, sizeof(double) * A->nCells, hipMemcpyHostToDevice));
     if (A->nFaces) FFM_HIP(hipMemcpy(u, upper, sizeof(double) * A->nFaces, hipMemcpyHostToDevice));
     if (lower && A->nFaces) FFM_HIP(hipMemcpy(l, lower, sizeof(double) * A->nFaces, hipMemcpyHostToDevice));
+    FFM_HIP(hipDeviceSynchronize());           // the null-stream uploads have landed before the context's (non-blocking) stream reads them
     int rc = ffm_ldu_set_coeffs_d(A, d, u, l);
     hipStreamSynchronize(A->ctx->stream);
     hipFree(d); hipFree(u); hipFree(l);

@@ -787,6 +787,7 @@ extern "C" int ffm_solve(ffm_ldu *A, int solver, int precond, double tol, double
     FFM_HIP(hipMalloc((void **)&p, nb)); FFM_HIP(hipMalloc((void **)&b, nb));
     FFM_HIP(hipMemcpy(p, psi, sizeof(double) * A->nOwned, hipMemcpyHostToDevice));
     FFM_HIP(hipMemcpy(b, source, sizeof(double) * A->nOwned, hipMemcpyHostToDevice));
+    FFM_HIP(hipDeviceSynchronize());           // (null-stream uploads vs the context's non-blocking stream)
     int rc = ffm_solve_d(A, solver, precond, tol, relTol, minIter, maxIter, nSweeps, p, b, out);
     if (!rc && hipMemcpy(psi, p, sizeof(double) * A->nOwned, hipMemcpyDeviceToHost) != hipSuccess) rc = FFM_ERR_HIP;
     hipFree(p); hipFree(b);

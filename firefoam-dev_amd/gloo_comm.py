@@ -4,6 +4,14 @@ import numpy as np
 
 
 GROUP = None        # process group to use (None: the default group); bench.py sets a gloo group here when it falls back from RCCL
+_SEQ = [0]          # running message tag: every rank makes the same sequence of exchange calls, so call number k uses tag k on all of
+                    # them (back-to-back exchanges between the same pair -- the ghost refresh of gx, gy, gz -- cannot be confused,
+                    # and a rank that leaves the common sequence blocks instead of silently pairing the wrong messages)
+
+
+def _tag():
+    _SEQ[0] = (_SEQ[0] + 1) % 30000
+    return _SEQ[0]
 
 
 def _dist():
@@ -29,12 +37,13 @@ def exchange(sizes, ranks, offs, send, recv):
     import torch
     dist = _dist()
     reqs, bufs = [], []
+    tag = _tag()
     for n, r, o in zip(sizes, ranks, offs):
         if n == 0:
             continue
         ts = torch.from_numpy(np.ascontiguousarray(send[o:o + n]).copy())
         tr = torch.empty(n, dtype=torch.float64)
-        reqs.append(dist.isend(ts, r, group=GROUP)); reqs.append(dist.irecv(tr, r, group=GROUP))
+        reqs.append(dist.isend(ts, r, group=GROUP, tag=tag)); reqs.append(dist.irecv(tr, r, group=GROUP, tag=tag))
         bufs.append((o, n, tr, ts))
     for q in reqs:
         q.wait()
@@ -47,13 +56,14 @@ def exchange_var(ranks, sends, recvs):
     import torch
     dist = _dist()
     reqs, keep = [], []
+    tag = _tag()
     for r, s, rv in zip(ranks, sends, recvs):
         if len(s):
             ts = torch.from_numpy(np.ascontiguousarray(s).copy()); keep.append(ts)
-            reqs.append(dist.isend(ts, r, group=GROUP))
+            reqs.append(dist.isend(ts, r, group=GROUP, tag=tag))
         if len(rv):
             tr = torch.empty(len(rv), dtype=torch.float64); keep.append((tr, rv))
-            reqs.append(dist.irecv(tr, r, group=GROUP))
+            reqs.append(dist.irecv(tr, r, group=GROUP, tag=tag))
     for q in reqs:
         q.wait()
     for k in keep:

@@ -502,6 +502,8 @@ int ffm_gamg_get_level_coeffs(ffm_gamg *g, int level, double *diag, double *uppe
 int ffm_gamg_coarsest_solves(const ffm_gamg *g, int maxN, ffm_perf *out);    /* of the last solve; returns their number    */
 int ffm_gamg_destroy(ffm_gamg *g);
 
+int ffm_device_synchronize(void);     /* hipDeviceSynchronize (debugging aid of the Foam layer: FFM_SYNC_RANGE) */
+
 /* ---------------------------------------------------------------- reductions */
 /* gSum / gMin / gMax / gSumProd / gSumMag over a device field (solver/YEEqn.H:
  * 73-78,117-118; solver/phrghEqn.H:54-55).  All-reduced when a communicator is
