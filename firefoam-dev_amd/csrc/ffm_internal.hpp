@@ -247,6 +247,8 @@ bool ffm_tile_usable(const ffm_ldu *A);
 bool ffm_tile_pcg_fusable(const ffm_ldu *A);
 int ffm_tile_pcg_fwd(ffm_ldu *A, double *rA, double *wA, int slot, const double *qA = nullptr);
 bool ffm_tile_amul_pcg_usable(const ffm_ldu *A);
+bool ffm_tile_amul_asym_usable(const ffm_ldu *A);
+int ffm_tile_amul_asym(ffm_ldu *A, const double *x, double *y);
 int ffm_tile_amul_pcg(ffm_ldu *A, const double *w, const double *pin, double *pout, double *psi, double *y, int dotSlot);
 int ffm_tile_pcg_bwd(ffm_ldu *A, const double *rA, double *wA, int slot);
 int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);

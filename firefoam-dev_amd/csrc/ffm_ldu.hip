@@ -840,6 +840,10 @@ int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
         FFM_TRY(ffm_tile_amul(A, x, y, -1));
         return FFM_OK;
     }
+    if (!transpose && ffm_tile_amul_asym_usable(A)) {
+        if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange_begin(A, const_cast<double *>(x)));
+        return ffm_tile_amul_asym(A, x, y);
+    }
     if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x)));   // refresh ghost columns
     FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows<0, false, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
                                                A->diag, up, lo, x, (const double *)nullptr, y, (double *)nullptr));

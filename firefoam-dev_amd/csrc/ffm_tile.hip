@@ -895,12 +895,16 @@ struct AmulView {
 // FUSEP (PCG): x is not read but formed on the way into the rings, x = w + beta*pin (PCG.C "pA = wA + beta*pA"), and stored to pout
 // by the segment that owns the row, together with psi += alpha*pin (the solution update left over from the iteration before);
 // pin / pout are two buffers (a neighbouring workgroup may still need the old direction), y must not alias w.
-template <bool DOT, bool FUSEP = false>
+// ASYM (asymmetric matrices: the transport equations): the coefficient of a lower face is not the owner's upper coefficient from
+// the ring but the cell's own triple lc[3c + k] of lower coefficients (the array the forward DILU sweep streams, gathered once
+// per coefficient update); x still comes through the rings / external buffers.
+template <bool DOT, bool FUSEP = false, bool ASYM = false>
 __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const double *__restrict__ bc, const double *__restrict__ upper,
                                                               const double *__restrict__ diag, const double *__restrict__ x,
                                                               double *__restrict__ y, double *__restrict__ partials,
                                                               const double *__restrict__ pin = nullptr, double *__restrict__ pout = nullptr,
-                                                              double *__restrict__ psi = nullptr, const double *__restrict__ scal = nullptr)
+                                                              double *__restrict__ psi = nullptr, const double *__restrict__ scal = nullptr,
+                                                              const double *__restrict__ lc = nullptr)
 {
     // FUSEP: x = w on entry.  A singular flag leaves direction and solution as they are (k_p_psi's guard)
     const bool fSing = FUSEP ? (scal[S_SING] != 0.0) : false;
@@ -967,7 +971,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
             unsigned pc[A_PF];
             bool pok[A_PF], pst[A_PF];
             uint4 pq[A_PF];
-            double pb[A_PF][3], pd[A_PF], px[A_PF], pp[FUSEP ? A_PF : 1], ps[FUSEP ? A_PF : 1];
+            double pb[A_PF][3], pd[A_PF], px[A_PF], pp[FUSEP ? A_PF : 1], ps[FUSEP ? A_PF : 1], pl[ASYM ? A_PF : 1][3];
 #define A_FETCH(k, e, R_) {                                                                              \
         const unsigned cnt_ = ((e) < e1) ? ((unsigned)(R_).y & 0xFFFFu) : 0u;                            \
         const bool ok_ = tid < cnt_;                                                                     \
@@ -978,6 +982,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
         pd[k] = *(const double *)((const char *)diag + o8_);                                             \
         px[k] = *(const double *)((const char *)x + o8_);                                                \
         if (FUSEP) { pp[FUSEP ? k : 0] = *(const double *)((const char *)pin + o8_); ps[FUSEP ? k : 0] = *(const double *)((const char *)psi + o8_); } \
+        if (ASYM) { const T3 v_ = *(const T3 *)((const char *)lc + cc_ * 24u); pl[ASYM ? k : 0][0] = v_.a; pl[ASYM ? k : 0][1] = v_.b; pl[ASYM ? k : 0][2] = v_.c; } \
         pc[k] = cc_; pok[k] = ok_; pst[k] = ok_ && (e) >= sa && (e) < sb;                                \
     }
 #define A_FILL(k) { if (FUSEP) px[k] = fSing ? pp[FUSEP ? k : 0] : px[k] + fBeta * pp[FUSEP ? k : 0];                      \
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(T_THREADS + 64) void k_tile_amul(AmulView t, const 
                             const unsigned hi = hb + (cd[s] & (unsigned)(A_XMAX - 1));
                             const unsigned xi = ri ^ ((ri ^ ((unsigned)A_RING + hi)) & m);
                             const unsigned ci = (3u * ri + ((cd[s] >> 12) & 3u)) ^ (((3u * ri + ((cd[s] >> 12) & 3u)) ^ (3u * (unsigned)A_RING + hi)) & m);
-                            const double nv = acc + cring[ci] * xring[xi];
+                            const double nv = acc + (ASYM ? pl[ASYM ? k : 0][s] : cring[ci]) * xring[xi];
                             acc = (cd[s] != A_NONE) ? nv : acc;
                         }
 #pragma unroll
@@ -1075,6 +1080,30 @@ __global__ __launch_bounds__(1024) void k_tile_sum_partials(int n, const double 
 }
 
 bool ffm_tile_amul_usable(const ffm_ldu *A) { return ffm_tile_usable(A) && A->tile->amulUsable && A->symmetric && A->ifaces.empty(); }
+
+// y = A x for an asymmetric matrix on the tile plan (transport equations): upper coefficients from the cell-space upper table,
+// lower coefficients from the forward sweep's gathered array; ghost faces by the tail kernel as in the symmetric case
+bool ffm_tile_amul_asym_usable(const ffm_ldu *A)
+{
+    return ffm_tile_usable(A) && A->tile->amulUsable && !A->symmetric && A->ifaces.empty() && !getenv("FFM_NO_TILE_AMUL_ASYM");
+}
+int ffm_tile_amul_asym(ffm_ldu *A, const double *x, double *y)
+{
+    ffm_tile_plan *T = A->tile;
+    hipStream_t s = A->ctx->stream;
+    const double *bcoef, *lcoef;
+    FFM_TRY(tile_up_coef_cell(A, &bcoef));
+    FFM_TRY(tile_coef(A, T->f, false, &lcoef));
+    AmulView v; v.G = T->G; v.grpCell = A->grpCell; v.grpEnt = T->f.grpEnt; v.rec = T->arec; v.seg = T->aseg; v.code = T->acode; v.ext = T->aext;
+    hipLaunchKernelGGL((k_tile_amul<false, false, true>), dim3(T->nSeg), dim3(T_THREADS + 64), 0, s, v, bcoef, (const double *)A->upper, (const double *)A->diag, x, y,
+                       (double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const double *)nullptr, lcoef);
+    FFM_TRY(ffm_ghost_exchange_end(A));
+    if (T->nTail > 0)
+        hipLaunchKernelGGL(k_amul_tail<false>, dim3((T->nTail + 255) / 256), dim3(256), 0, s, T->nTail, (const int *)T->tailCell, (const int *)T->tailStart,
+                           (const int *)T->tailFace, (const int *)T->tailNbr, (const double *)A->upper, x, y);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
 
 // PCG: pout = w + beta*pin, psi += alpha*pin, y = A pout, scal[dotSlot] = pout.y (local), in one pass (k_tile_amul<true, true>)
 bool ffm_tile_amul_pcg_usable(const ffm_ldu *A)
