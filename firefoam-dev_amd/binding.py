@@ -146,6 +146,7 @@ def lib():
         "ffm_thermo_correct_d": ([vp, C.c_long, C.POINTER(vp), dp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_thermo_he_d": ([vp, C.c_long, C.POINTER(vp), dp, dp], C.c_int),
         "ffm_thermo_properties_d": ([vp, C.c_long, C.POINTER(vp), dp, dp, dp, dp], C.c_int),
+        "ffm_thermo_Cp_d": ([vp, C.c_long, C.POINTER(vp), dp, dp], C.c_int),
         "ffm_thermo_destroy": ([vp], C.c_int),
         "ffm_edc_correct_d": ([vp, C.c_long] + [dp] * 6 + [C.c_double] * 7 + [dp, dp], C.c_int),
         "ffm_les_keqn_nut_d": ([vp, C.c_long, C.c_double, C.c_double, dp, dp, dp, dp, dp], C.c_int),
@@ -661,6 +662,10 @@ class Thermo:
     def he(self, Y, T, out):
         self.ctx._ready()
         _check(lib().ffm_thermo_he_d(self.h, T.numel(), self._Y(Y), C.c_void_p(T.data_ptr()), C.c_void_p(out.data_ptr())), "ffm_thermo_he_d")
+
+    def Cp(self, Y, T, out):
+        self.ctx._ready()
+        _check(lib().ffm_thermo_Cp_d(self.h, T.numel(), self._Y(Y), C.c_void_p(T.data_ptr()), C.c_void_p(out.data_ptr())), "ffm_thermo_Cp_d")
 
     def close(self):
         if getattr(self, "h", None):

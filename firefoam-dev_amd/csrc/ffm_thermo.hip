@@ -101,6 +101,15 @@ __global__ void k_thermo_he(long n, ThermoTable t, ThermoPtrs y, const double *_
         he[i] = th_Hs(m, T[i]);
     }
 }
+// Cp of the mixture at a given temperature (heThermo::Cp(p, T, patchi): the kappa of compressible::thermalBaffle1D, the gradient
+// term of mixedEnergy)
+__global__ void k_thermo_cp(long n, ThermoTable t, ThermoPtrs y, const double *__restrict__ T, double *__restrict__ cp)
+{
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        Mix m; cell_mixture(t, y, i, m);
+        cp[i] = th_Cp(m, T[i]);
+    }
+}
 // eddyDissipationModel::correct: rtTurb = C_EDC*epsilon/max(k, SMALL), rtDiff = C_Diff*alpha/rho/delta^2, rt = max of the two;
 // wFuel = rho*min(Y_fuel, Y_O2/s)/deltaT/C_Stiff*(1 - exp(-C_Stiff*deltaT*rt)); Qdot = qFuel*wFuel; epsilon = Ce*k*sqrt(k)/delta
 __global__ void k_edc(long n, const double *__restrict__ rho, const double *__restrict__ k, const double *__restrict__ delta,
@@ -191,6 +200,15 @@ extern "C" int ffm_thermo_he_d(ffm_thermo *th, long n, const double *const *Y_d,
     ThermoPtrs y; FFM_TRY(ptrs_of(th, Y_d, y));
     FFM_HIP(hipSetDevice(th->ctx->device));
     if (n) hipLaunchKernelGGL(k_thermo_he, dim3(tgrid(n)), dim3(256), 0, th->ctx->stream, n, th->t, y, T_d, he_d);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+extern "C" int ffm_thermo_Cp_d(ffm_thermo *th, long n, const double *const *Y_d, const double *T_d, double *Cp_d)
+{
+    if (!th || n < 0 || !Y_d || !T_d || !Cp_d) return FFM_ERR_ARG;
+    ThermoPtrs y; FFM_TRY(ptrs_of(th, Y_d, y));
+    FFM_HIP(hipSetDevice(th->ctx->device));
+    if (n) hipLaunchKernelGGL(k_thermo_cp, dim3(tgrid(n)), dim3(256), 0, th->ctx->stream, n, th->t, y, T_d, Cp_d);
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }

@@ -456,6 +456,9 @@ int ffm_thermo_he_d(ffm_thermo *th, long n, const double *const *Y_d, const doub
 /* psi, mu, alpha (each nullable) of the mixture at a given temperature, no iteration (patch faces whose T is fixed) */
 int ffm_thermo_properties_d(ffm_thermo *th, long n, const double *const *Y_d, const double *T_d, double *psi_d, double *mu_d,
                             double *alpha_d);
+/* Cp of the mixture at T (heThermo::Cp(p, T, patchi): kappaEff of compressible::thermalBaffle1D -- cases/steckler/0/T:51-82 --
+ * and the gradient term of mixedEnergy::updateCoeffs) */
+int ffm_thermo_Cp_d(ffm_thermo *th, long n, const double *const *Y_d, const double *T_d, double *Cp_d);
 int ffm_thermo_destroy(ffm_thermo *th);
 int ffm_edc_correct_d(ffm_ctx *ctx, long n, const double *rho_d, const double *k_d, const double *delta_d, const double *alpha_d,
                       const double *Yfuel_d, const double *YO2_d, double s, double deltaT, double Ce, double C_EDC, double C_Diff,

@@ -47,3 +47,22 @@ def test_the_library_built_from_them_exports_the_step():
     assert os.path.exists(so), "run firefoam-dev_amd/csrc/Makefile (or __graft_entry__.build())"
     lib = ctypes.CDLL(so)
     assert hasattr(lib, "firefoam_snippets_step") and hasattr(lib, "firefoam_snippets_hydrostatic")
+
+
+def test_the_steckler_case_driver_uses_the_references_files_too():
+    """examples/fireFoam_steckler.C (the real case: janaf thermo, LES kEqn, EDC behind the handles): the same five equation files,
+    the reference's, and the library built from it exports its entry points"""
+    src = os.path.join(ROOT, "examples", "fireFoam_steckler.C")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-H", "-I", os.path.join(ROOT, "include"), "-I", REF, src], capture_output=True, text=True)
+    assert r.returncode == 0 and "error:" not in r.stderr, r.stderr[-3000:]
+    included = [ln.strip(". \n") for ln in r.stderr.splitlines() if ln.startswith(".")]
+    for name in ("rhoEqn.H", "UEqn.H", "YEEqn.H", "pEqn.H", "phrghEqn.H"):
+        assert os.path.join(REF, name) in included, name
+    import ctypes
+    import torch  # noqa: F401
+    from ffm_import import ffm
+    ffm.lib()
+    so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_steckler.so")
+    assert os.path.exists(so), "run firefoam-dev_amd/csrc/Makefile (or __graft_entry__.build())"
+    lib = ctypes.CDLL(so)
+    assert hasattr(lib, "firefoam_steckler_create") and hasattr(lib, "firefoam_steckler_advance") and hasattr(lib, "firefoam_steckler_destroy")
