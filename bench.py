@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--edge", dest="n", type=int, default=400, help="cells per box edge (400 -> 64 M cells, BASELINE.json config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=96)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="replicas of the CPU baseline run side by side (0: all cores, at most 16)")
     ap.add_argument("--solvers", choices=["krylov", "steckler"], default="krylov",
                     help="transport equations: PBiCGStab+DILU (default) or smoothSolver+symGaussSeidel maxIter 10 (cases/steckler/system/fvSolution:49-62)")
     ap.add_argument("--radiation-freq", type=int, default=100,
@@ -193,9 +194,27 @@ def main():
             ref.step()
         cdt = (time.perf_counter() - t1) / nst
         cell_steps = cn ** 3 / cdt
-        cpu = {"value": round(cell_steps / N, 6), "unit": "outer-iterations/s", "cores": 1, "kind": "port",
-               "sample": "oracle/plume.py (numpy assembly + C solvers, 1 core): %d^3 cells, %d steps, %.2f s/step = %.3g cell-steps/s, "
-                         "scaled by cell count to %d cells" % (cn, nst, cdt, cell_steps, N)}
+        del ref
+        # all host cores of this GPU's share: P single-core replicas of the same sample side by side (no halo exchange, so an
+        # upper bound for a domain-decomposed CPU run of the reference; they do contend for the memory bandwidth, as its ranks would)
+        import subprocess
+        P = max(1, min(args.cpu_procs if args.cpu_procs > 0 else (os.cpu_count() or 1), 16))
+        code = ("import sys, time; sys.path.insert(0, %r); from oracle import plume as P_\n"
+                "c = P_.Plume((%d, %d, %d)); c.step(); t = time.perf_counter(); c.step(); print(time.perf_counter() - t)" % (os.path.dirname(os.path.abspath(__file__)), cn, cn, cn))
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for _ in range(P)]
+        times = []
+        for pr in procs:
+            o, _ = pr.communicate()
+            try:
+                times.append(float(o.strip().splitlines()[-1]))
+            except Exception:
+                pass
+        agg = sum(cn ** 3 / t for t in times) if times else cell_steps
+        cpu = {"value": round(agg / N, 6), "unit": "outer-iterations/s", "cores": max(len(times), 1), "kind": "port",
+               "sample": "oracle/plume.py (numpy assembly + C solvers): %d single-core replicas side by side, each %d^3 cells, 1 warm-up + 1 timed step, "
+                         "%.2f s/step on average = %.3g cell-steps/s in aggregate, scaled by cell count to %d cells" % (len(times), cn, sum(times) / max(len(times), 1), agg, N),
+               "one_core": {"value": round(cell_steps / N, 6), "s_per_step": round(cdt, 3), "cells": cn ** 3, "steps": nst}}
         # the linear-algebra kernels of the path on the host: Amul GB/s on one core, and the synthetic p_rgh PCG
         # solve on one core against P block subdomains on P threads (block-Jacobi DIC, oracle/ffo_multi.c)
         try:

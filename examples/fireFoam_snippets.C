@@ -48,6 +48,11 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     // steckler one: p_rgh, ph_rgh GAMG + GaussSeidel (fvSolution:36-60; gamg = the mesh's agglomeration, ffm_gamg_create), U / Yi / h
     // PBiCG + DILU (:67-75,115-152), div(phi,U) Gauss filteredLinear2V 0.2 0.05 (fvSchemes:41)
     int wallFireSelection; ffm_gamg* gamg;
+    // pyro != NULL: a reactingOneDim panel (ffm_pyro_*, cases/wallFireSpread2D's pyrolysis region) behind the boundary faces
+    // pyroMap[0..pyroCols): its columns are evolved by the reference's `pyrolysis.evolve()` call (solver/fireFoam.C:90-93, in
+    // firefoam_snippets_time_step) with the mapped patch conditions of lib/fvPatchFieldsPyrolysis between the two regions;
+    // pyroQin [B]: incident radiative flux on the wall faces
+    ffm_pyro* pyro; int pyroCols; const int* pyroMap; const double* pyroQin; double pyroEmissivity, pyroAbsorptivity, pyroHocSolid, pyroQFuel;
 };
 
 // ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
@@ -91,7 +96,7 @@ struct snippetSolver
     scalar cumulativeContErr = 0;
     Time runTime;
     struct { bool adjustTimeStep; scalar maxCo, maxDeltaT; } timeControls;
-    noPyrolysis pyrolysis;
+    pyrolysisModelCollection pyrolysis;
     const scalar maxDi;                                         // solver/readPyrolysisTimeControls.H:32
     const bool solvePyrolysisRegion = true, solvePrimaryRegion = true;      // solver/createFields.H:134-145
 
@@ -172,6 +177,14 @@ struct snippetSolver
         }
         else radiation = autoPtr<radiation::radiationModel>(new noRadiation());
         mesh.store("phi", phi); mesh.store("rho", rho); mesh.store("U", U);
+        if (cs->pyro) {
+            pyrolysis.attach(mesh, cs->pyro, cs->pyroCols, cs->pyroMap, cs->pyroQin, cs->pyroEmissivity, cs->pyroAbsorptivity, cs->pyroHocSolid, cs->pyroQFuel,
+                             U, thermo.he(), T, rho);
+            const scalar Cp = cs->Cp, Tref = cs->Tref;
+            // gas side of the wall: kappaEff = Cp*alphaEff (the stand-in thermo's constant Cp), he = Cp*(T - Tref)
+            pyrolysis.kappaDelta = [this, Cp]() { return binary(FFM_OP_MUL, scalarOp(FFM_OP_MUL, turbulence->alphaEff().b, Cp), mesh.boundaryGeometry(5)); };
+            pyrolysis.heOfT = [Cp, Tref](const dField& Tw) { return scalarOp(FFM_OP_MUL, scalarOp(FFM_OP_SUB, Tw, Tref), Cp); };
+        }
         thermo.correct();                                           // T, psi of the start state
         U.correctBoundaryConditions(); thermo.he().correctBoundaryConditions();
         forAll(Y, i) { Y[i].correctBoundaryConditions(); }

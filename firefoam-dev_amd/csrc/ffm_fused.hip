@@ -100,7 +100,10 @@ struct ScalarEqns {
 };
 
 template <int W, int NF>
-__global__ __launch_bounds__(256) void k_scalar_eqns(MeshView q, ScalarEqns a)
+// Occupancy: the fused four-field kernel is bound by the latency of its neighbour gathers; capped at 128 VGPRs (4 waves per SIMD,
+// 84 bytes of scratch per lane) it takes 17.5 ms at 400^3 instead of 21.9 ms with the 150 VGPRs the compiler picks by itself; 5 / 6
+// waves spill too much (25 / 27 ms), and the one-field kernel is better left alone (7.97 vs 8.35 ms).  Measured r02u.
+__global__ __launch_bounds__(256, (NF > 1 ? 4 : 1)) void k_scalar_eqns(MeshView q, ScalarEqns a)
 {
     CELL_SCHED(ci, q) {
         const int c = (int)ci;

@@ -211,6 +211,11 @@ class Plume:
     def zg(self, vf):            # zero-gradient boundary copy of a cell field
         return [vf[p.faceCells] for p in self.m.patches]
 
+    # the inlet patch as the gas side of a pyrolysing panel (lib/fvPatchFieldsPyrolysis: flowRateInletVelocityPyrolysisCoupled,
+    # turbulentTemperatureRadiationQinCoupledMixed fluid branch): per-face velocity [n][3] and enthalpy [n] handed over by
+    # oracle/pyrolysis.couple() before every step (tests/test_wallfire_pyrolysis_gpu.py); None = the plume's fixed inlet
+    inlet_U, inlet_h = None, None
+
     # ---- boundary conditions (mixed form) --------------------------------------------------
     def bc_U(self):
         m = self.m
@@ -218,7 +223,8 @@ class Plume:
         for q, p in enumerate(m.patches):
             for c in range(3):
                 if p.name == "inlet":
-                    bcs[c].f[q][:] = 1.0; bcs[c].ref[q][:] = U_IN if c == 1 else 0.0
+                    bcs[c].f[q][:] = 1.0
+                    bcs[c].ref[q][:] = (U_IN if c == 1 else 0.0) if self.inlet_U is None else self.inlet_U[:, c]
                 elif p.name == "floor":
                     bcs[c].f[q][:] = 1.0
                 else:   # pressureInletOutletVelocity: tangential components fixed 0 on inflow, normal zeroGradient
@@ -380,7 +386,7 @@ class Plume:
         self.Y[INERT] = np.maximum(1.0 - Yt, 0.0)
         if self.radFreq > 0 and self.stepNo % self.radFreq == 0:          # radiation->correct(), solver/YEEqn.H:80
             self.radiation_correct()
-        bch = self.bc_scalar(CP * (T_IN - TREF), 0.0, floor_fixed=0.0)
+        bch = self.bc_scalar(CP * (T_IN - TREF) if self.inlet_h is None else self.inlet_h, 0.0, floor_fixed=0.0)
         hb = bch.values(m, self.h)
         wh = fv.limited_weights(m, "limitedLinear", self.phi, self.h, fv.grad(m, self.h, hb), 1.0)
         Ub = [b.values(m, self.U[c]) for c, b in enumerate(bcU)]      # U.correctBoundaryConditions() after the solve

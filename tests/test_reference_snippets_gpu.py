@@ -31,7 +31,9 @@ class SnippetCase(C.Structure):
                 + [("radiationFreq", C.c_int), ("kAbs", C.c_double), ("sigmaSB", C.c_double), ("dAve", dp), ("omega", dp), ("GOut", dp)]
                 + [("psiB", dp), ("resOut", dp)]
                 + [("adjustTimeStep", C.c_int), ("maxCo", C.c_double), ("maxDeltaT", C.c_double), ("dtOut", dp), ("emptyDirections", C.c_int)]
-                + [("wallFireSelection", C.c_int), ("gamg", C.c_void_p)])
+                + [("wallFireSelection", C.c_int), ("gamg", C.c_void_p)]
+                + [("pyro", C.c_void_p), ("pyroCols", C.c_int), ("pyroMap", C.POINTER(C.c_int)), ("pyroQin", dp)]
+                + [(k, C.c_double) for k in ("pyroEmissivity", "pyroAbsorptivity", "pyroHocSolid", "pyroQFuel")])
 
 
 @pytest.mark.parametrize("shape,empty", [((10, 12, 9), ()), ((1, 24, 20), ("xmin", "xmax"))])

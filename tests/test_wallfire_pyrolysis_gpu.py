@@ -1,0 +1,142 @@
+"""BASELINE config 5 (cases/wallFireSpread2D: a 2-D gas region, one cell thick with `empty` patches, coupled to a reactingOneDim
+pyrolysis region) as ONE time loop on the device: the body of the reference's loop (solver/fireFoam.C:76-121 -- its unchanged
+solidRegionDiffusionNo.H / setMultiRegionDeltaT.H, `pyrolysis.evolve()`, rhoEqn.H, UEqn.H, YEEqn.H, pEqn.H) through
+examples/fireFoam_snippets.C with
+  * the case's solver / scheme selection (cases/wallFireSpread2D/system/fvSolution:36-60,67-152, fvSchemes:41): p_rgh by GAMG +
+    GaussSeidel, div(phi,U) Gauss filteredLinear2V 0.2 0.05, U / Yi / h by PBiCG + DILU;
+  * a pyrolysing panel behind one wall patch: pyrolysisModelCollection::evolve() (include/fireFoamHandles.H) = the mapped patch
+    conditions of lib/fvPatchFieldsPyrolysis the case selects (0/T:61-75 turbulentTemperatureRadiationQinCoupledMixed, 0/U:52-64
+    flowRateInletVelocityPyrolysisCoupled: ffm_pyro_couple_d) + reactingOneDim::evolveRegion for every column (ffm_pyro_step).
+The solid heats the gas (wall temperature -> the energy patch's fixed value), the gas and the incident radiation heat the solid,
+and the pyrolysate enters the gas region as the wall patch's inflow velocity.
+Oracle: oracle/plume.py (same selection: WallFireSolvers, filteredLinear2V) and oracle/pyrolysis.py (Panel.step, couple) composed
+in the same order.  Synthetic panel state (started hot so that the wood pyrolyses within the steps of the test); parity unpinned by
+reference data, as the two halves are."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from common import rel_l2
+from test_reference_snippets_gpu import SnippetCase
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gas_region_and_pyrolysis_panel_in_one_time_loop(O, ffm, ctx):
+    from oracle import plume, pyrolysis as PY
+    so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
+    if not os.path.exists(so):
+        pytest.skip("libffm_refsnippets.so not built (needs /root/reference at build time)")
+    lib = C.CDLL(so)
+    argt = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SnippetCase)]
+    lib.firefoam_snippets_create.restype = C.c_void_p; lib.firefoam_snippets_create.argtypes = argt
+    lib.firefoam_snippets_time_step.restype = C.c_int; lib.firefoam_snippets_time_step.argtypes = [C.c_void_p, C.POINTER(SnippetCase), C.c_int]
+    lib.firefoam_snippets_destroy.argtypes = [C.c_void_p]
+    shape, empty = (1, 24, 20), ("xmin", "xmax")
+    gasMesh = plume.make_mesh(shape, empty=empty)
+    m = gasMesh
+    N, F = m.nCells, m.nFaces
+    B = sum(p.size for p in m.patches)
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    mesh.set_face_centres(m.Cf[fOrd].T.copy())
+    G5 = ffm.GAMG(ctx, A, l2, u2, Sf=m.Sf[fOrd])
+    ref = plume.Plume(shape, mesh=gasMesh, solvers=plume.WallFireSolvers(cOrd, fOrd, l2, u2, m.Sf[fOrd]))
+    ref.stored_bc = True; ref.divU_scheme = ("filteredLinear2V", 0.2, 0.05)
+
+    # ---- the panel: one column behind every face of the wall patch (the plume's `inlet` patch plays the pyrolysing wall)
+    names = [p.name for p in m.patches]
+    qw = names.index("inlet"); pw = m.patches[qw]
+    start = int(np.concatenate([[0], np.cumsum([p.size for p in m.patches])])[qw])
+    nCol = pw.size
+    fmap = (start + np.arange(nCol)).astype(np.int32)
+    area = float(pw.magSf[0]); assert np.allclose(pw.magSf, area)
+    T0 = 600.0                                                    # above the reaction's critical temperature: pyrolysis from the first step
+    solid = PY.Panel(nCol, 8, thickness=0.0127, area=area, T0=T0)
+    dev = ffm.PyrolysisPanel(ctx, nCol, 8, thickness=0.0127, area=area, T0=T0)
+    qin = np.zeros(B); qin[fmap] = 3.0e4 * (1.0 + 0.3 * np.sin(0.7 * np.arange(nCol)))      # incident radiation on the wall faces [W/m2]
+    e, a, hocSolid, qFuel = 0.9, 0.85, 1.66e7, 4.6e7              # cases/wallFireSpread2D/0/U:62 hocSolid; propane qFuel
+    nfw = pw.Sf / pw.magSf[:, None]
+    kDw = (plume.MU / plume.PR * plume.CP) * pw.deltaCoeffs       # kappaEff*deltaCoeffs of the gas side (constant-property stand-in)
+
+    dp = C.POINTER(C.c_double)
+    keep = []
+
+    def P(x):
+        x = np.ascontiguousarray(x, np.float64); keep.append(x)
+        return x.ctypes.data_as(dp)
+
+    def PP(arrs):
+        arrs = [np.ascontiguousarray(x, np.float64) for x in arrs]; keep.append(arrs)
+        arr = (dp * len(arrs))(*[x.ctypes.data_as(dp) for x in arrs]); keep.append(arr)
+        return arr
+    cell = lambda x: np.asarray(x)[..., cOrd]
+    face = lambda x: np.asarray(x)[fOrd]
+    bnd = lambda lst: np.concatenate(lst)
+    per = lambda fn: bnd([fn(p) for p in m.patches])
+    is_open = lambda p: p.name not in ("inlet", "floor")
+    fU = np.concatenate([per(lambda p, d=d: np.where(np.abs(p.Sf[:, d]) > 0, 0.0, -1.0) if is_open(p) else np.ones(p.size)) for d in range(3)])
+    fixesU = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0))
+    fY = per(lambda p: np.full(p.size, 1.0 if p.name == "inlet" else (0.0 if p.name == "floor" else -1.0)))
+    refY = [per(lambda p, i=i: np.full(p.size, plume.Y_IN[i] if p.name == "inlet" else (plume.Y_AMB[i] if is_open(p) else 0.0))) for i in range(5)]
+    fH = per(lambda p: np.full(p.size, -1.0 if is_open(p) else 1.0))
+    fluxMask = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0)); totalMask = 1.0 - fluxMask
+    ghfb = bnd([p.Cf @ plume.G - ref.ghRef for p in m.patches])
+    out = dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), Y=[np.empty(N) for _ in range(5)],
+               T=np.empty(N), K=np.empty(N), dpdt=np.empty(N), phi=np.empty(F), phib=np.empty(B), p_rghB=np.empty(B))
+    nit, dtOut = (C.c_int * 32)(), np.zeros(1)
+    Z = np.zeros(B)
+    cs = SnippetCase(
+        deltaT=ref.dt, RR=plume.RR, Cp=plume.CP, Tref=plume.TREF, pRef=plume.PREF, mu=plume.MU, Pr=plume.PR, sO2=plume.S_O2, HC=plume.HC,
+        tau=plume.TAU, nSpecies=5, inertIndex=plume.INERT, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
+        rho=P(cell(ref.rho)), U=P(cell(ref.U)), p=P(cell(ref.p)), p_rgh=P(cell(ref.p_rgh)), h=P(cell(ref.h)), Y=PP([cell(ref.Y[i]) for i in range(5)]),
+        K=P(cell(ref.K)), dpdt=P(cell(ref.dpdt)), phiF=P(face(ref.phi)), phiB=P(bnd(ref.phib)),
+        gh=P(cell(ref.gh)), ghfF=P(face(ref.ghf)), ghfB=P(ghfb),
+        # the wall patch starts with U = 0 and the enthalpy of the gas at rest; evolve() overwrites both reference values on its faces
+        fU=P(fU), refU=P(np.zeros(3 * B)), fixesU=P(fixesU), fY=P(fY), refY=PP(refY), fH=P(fH), refH=P(Z),
+        fluxMaskP=P(fluxMask), totalMaskP=P(totalMask), ph_rgh_b=P(bnd(ref.ph_rgh_b)), p_rghB=P(bnd(ref.p_rgh_b)),
+        rhoOut=P(out["rho"]), UOut=P(out["U"]), pOut=P(out["p"]), p_rghOut=P(out["p_rgh"]), hOut=P(out["h"]), TOut=P(out["T"]), KOut=P(out["K"]),
+        dpdtOut=P(out["dpdt"]), phiOutF=P(out["phi"]), phiOutB=P(out["phib"]), p_rghBOut=P(out["p_rghB"]), nIterOut=nit, nIterCap=32)
+    cs.YOut = PP(out["Y"])
+    cs.emptyDirections = sum(1 << d for d in range(3) if m.solutionD[d] < 0)
+    cs.wallFireSelection = 1; cs.gamg = G5.h
+    cs.adjustTimeStep = 0; cs.maxCo = 0.3; cs.maxDeltaT = 0.05; cs.dtOut = dtOut.ctypes.data_as(dp)
+    cs.pyro = dev.h; cs.pyroCols = nCol; cs.pyroMap = fmap.ctypes.data_as(C.POINTER(C.c_int)); cs.pyroQin = P(qin)
+    cs.pyroEmissivity = e; cs.pyroAbsorptivity = a; cs.pyroHocSolid = hocSolid; cs.pyroQFuel = qFuel
+    os.environ["FFM_FOAM_QUIET"] = "1"
+    solver = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(cs))
+    inv0 = np.empty(N, np.int64); inv0[cOrd] = np.arange(N)
+    Tw = np.full(nCol, T0)                                        # the wall value starts at the solid's temperature (ffm_pyro_create)
+    nSteps = 6
+    for k in range(nSteps):
+        # oracle: the mapped conditions with the gas state at the start of the step, the columns, then the gas region
+        q, Tw, refT, Uw = PY.couple(solid, Tw, ref.T[pw.faceCells], kDw, qin[fmap], e, a, ref.rho[pw.faceCells], pw.magSf, nfw, hocSolid, qFuel)
+        solid.step(ref.dt, q)
+        ref.inlet_U = Uw; ref.inlet_h = plume.CP * (refT - plume.TREF)
+        ref.step()
+        n = lib.firefoam_snippets_time_step(solver, C.byref(cs), 1 if k == nSteps - 1 else 0)
+        assert abs(dtOut[0] - ref.dt) <= 1e-12 * ref.dt
+        assert list(nit[:n]) == [pf["nIterations"] for _, pf in ref.sol.log], (k, list(nit[:n]), [pf["nIterations"] for _, pf in ref.sol.log])
+        assert np.abs(dev.field("qSurf") - q).max() <= 1e-9 * np.abs(q).max(), k
+        assert np.abs(dev.field("T") - solid.T).max() <= 1e-9 * solid.T.max(), k
+        assert np.abs(dev.field("phiGas") - solid.massGas).max() <= 1e-9 * max(solid.massGas.max(), 1e-300), k
+    lib.firefoam_snippets_destroy(solver)
+    # the coupling acted in both directions
+    assert solid.massGas.min() > 0 and solid.Yw[:, 0].max() < 1.0                    # the wood pyrolyses ...
+    f = ref.fields()
+    Uin = (out["U"][:, inv0][:, pw.faceCells] * (-nfw.T)).sum(axis=0)                # ... its gas enters the gas region through the wall cells
+    assert f["T"][pw.faceCells].min() > plume.TREF + 1.0                             # and the hot wall heats the gas cell layer
+    assert Uin.max() > 0
+    # six steps of solves to 1e-7 / 1e-8 (p_rgh: GAMG to 1e-6 of the initial residual) with different summation orders: the velocity,
+    # which follows the pressure gradient, agrees to 1e-5, the transported scalars to 1e-6
+    errs = {name: rel_l2(got[inv0], f[name]) for name, got in (("rho", out["rho"]), ("T", out["T"]), ("h", out["h"]), ("Uy", out["U"][1]), ("Uz", out["U"][2]),
+                                                               ("O2", out["Y"][0]), ("C3H8", out["Y"][2]))}
+    bad = {k: v for k, v in errs.items() if not v < (1e-5 if k.startswith("U") else 1e-6)}
+    assert not bad, (bad, errs)
+    assert np.linalg.norm(out["p_rgh"][inv0] - f["p_rgh"]) / np.linalg.norm(f["p_rgh"] - f["p_rgh"].mean()) < 1e-4
+    G5.close(); dev.close(); mesh.close(); A.close()
