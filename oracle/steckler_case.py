@@ -8,9 +8,10 @@ through the FIRST TIME STEP of solver/fireFoam.C:76-121 with the real physics pl
 with OpenFOAM's stored-boundary-value semantics (a patch value changes only when something evaluates or assigns it).
 Golden data: cases/steckler/original/linux64/log.fireFoam:163-226 (the first time step): deltaT, the Ux/Uy/Uz, O2, C3H8, h, p_rgh
 and k solves, species min/ave/max, min/max(T).  What of it this restatement reproduces, and how closely, is asserted in
-tests/test_steckler_first_step_cpu.py; every deviation is documented there.  NOT modelled: the fvDOM radiation solve and its
-source radiation->Sh in the enthalpy equation, and the thermalBaffle1D temperature condition of the baffles (treated as
-fixedValue 300 K): both enter the first step through h only (and through thermo.correct() the pressure corrector after it).
+tests/test_steckler_first_step_cpu.py; every deviation is documented there.  The fvDOM ray solves of the step (the log's 32 GAMG
+lines, :183-214) are radiation_correct(), switched on by with_radiation.  NOT modelled: the source radiation->Sh in the enthalpy
+equation (-RadFraction*Qdot with a = 0: about 1e-8 W/m3 in this step).  compressible::thermalBaffle1D on the baffles is modelled
+(baffle_fixed = True keeps their file value 300 K instead).
 Only tests/ may import this module."""
 import os
 
@@ -169,6 +170,7 @@ class StecklerCase:
             self.psib.append(mb.psi(self.pb[q], self.Tb[q])); self.mub.append(mb.mu(self.pb[q], self.Tb[q]))
             self.alphab.append(mb.alphah(self.pb[q], self.Tb[q]))
 
+    with_radiation = False        # True: radiation->correct() (the 32 ray solves) between the species and the enthalpy equation
     baffle_fixed = False          # True: the baffle temperature kept at its file value (300 K) instead of thermalBaffle1D
 
     # ------------------------------------------------------------------ hydrostatic initialisation (solver/phrghEqn.H)
@@ -396,6 +398,8 @@ class StecklerCase:
         self.Y[self.iN2] = np.maximum(1.0 - Yt, 0.0)
         self.Yb[self.iN2] = [np.maximum(1.0 - b, 0.0) for b in Ytb]
         self.species_stats = {n: (self.Y[i].min(), self.Y[i].mean(), self.Y[i].max()) for i, n in enumerate(self.names)}
+        if self.with_radiation:
+            self.radiation_correct()
         if not with_h:
             return
         # ---- EEqn (radiation->Sh not modelled; baffle temperature fixed at its file value)
@@ -454,6 +458,48 @@ class StecklerCase:
         self.heb = bch.values(m, self.he)
         self.thermo_correct()
         self.minmaxT = (min(self.T.min(), min(b.min() for b in self.Tb)), max(self.T.max(), max(b.max() for b in self.Tb)))
+
+    # ------------------------------------------------------------------ radiation->correct(): fvDOM (solver/YEEqn.H:80)
+    def radiation_correct(self):
+        """fvDOM::calculate with the case's selections (cases/steckler/constant/radiationProperties): nPhi 2, nTheta 4 -> 32 rays,
+        maxIter 1; absorptionEmissionModel constRadFractionEmission (a = 0, E = RadFraction*Qdot with radScaling: RadFraction =
+        max(min(Ehrr1, Ehrr2), (mlr1 Ehrr1 + mlr2 Ehrr2)/max(SMALL, mlr1 + mlr2)), mlr = -gSum(phi) of the burner patch; reference
+        lib/.../constRadFractionEmission/constRadFractionEmission.C:ECont); scatterModel constantScatter with sigma 0.  Per ray
+        (reference packages/.../radiativeIntensityRay/radiativeIntensityRay.C:267-322):
+            fvm::div(Ji, Ii, "div(Ji,Ii_h)") + fvm::Sp(k*omega, Ii) == 1/pi*omega*(k*sigma*T^4 + E/4),   Ji = dAve & Sf, Gauss upwind
+        every patch greyDiffusiveRadiation with emissivity 1 (cases/steckler/0/IDefault): on faces the ray leaves into the domain
+        ((-n & dAve) > 0) the value sigma*T_w^4/pi with the stored wall temperatures, zeroGradient where it arrives; solved from
+        Ii = 0 by GAMG (smoother DILU, faceAreaPair, nCellsInCoarsestLevel 10, mergeLevels 1, tolerance 1e-4, relTol 0:
+        cases/steckler/system/fvSolution:63-73).  G = sum Ii*omega (fvDOM::updateG).  The golden log holds all 32 solves
+        (log.fireFoam:183-214): tests/test_steckler_first_step_cpu.py::test_the_32_ray_solves."""
+        from . import gamg
+        from .plume import ray_set, SIGMA_SB
+        m = self.m
+        if not hasattr(self, "agg"):
+            self.agg = gamg.Agglomeration(m.nCells, m.l, m.u, gamg.face_area_pair_weights(m.Sf), nCellsInCoarsestLevel=10, mergeLevels=1)
+        q = self.pidx["burner"]
+        mlr = -float(np.sum(self.phib[q]))
+        e1, e2 = 0.5, 0.22
+        self.radFraction = max(min(e1, e2), (mlr * e1 + mlr * e2) / max(SMALL, mlr + mlr))
+        E = self.radFraction * self.Qdot
+        a = 0.0
+        T4 = (self.T * self.T) * (self.T * self.T)
+        self.I, self.G = [], np.zeros(m.nCells)
+        for i, (d, omega) in enumerate(ray_set(2, 4)):
+            Ji = (d[0] * m.Sf[:, 0] + d[1] * m.Sf[:, 1]) + d[2] * m.Sf[:, 2]
+            Jib = [(d[0] * p.Sf[:, 0] + d[1] * p.Sf[:, 1]) + d[2] * p.Sf[:, 2] for p in m.patches]
+            bc = fv.MixedBC(m, f=[1.0 - fv.pos0(jb) for jb in Jib], ref=[SIGMA_SB * ((tb * tb) * (tb * tb)) / np.pi for tb in self.Tb])
+            M = fv.fvm_div(m, Ji, Jib, fv.pos0(Ji), [bc])
+            M.diag += m.V * (a * omega)
+            M.add_su(1.0 / np.pi * omega * (a * SIGMA_SB * T4 + E / 4.0))
+            dg, s = M.solve_system()
+            Ii, perf = gamg.GAMGSolver(self.agg, dg, M.upper, M.lower, smoother="DILU").solve(np.zeros(m.nCells), s, tolerance=1e-4, relTol=0.0)
+            self.log.append(("ILambda_%d_0" % i, perf))
+            if self.hook:
+                self.hook("ILambda_%d_0" % i, dict(kind="GAMG", Ji=Ji, Jib=Jib, bc=bc, d=dg, upper=M.upper, lower=M.lower, s=s, psi=Ii, perf=perf,
+                                                   source=M.source[0], tol=1e-4, relTol=0.0))
+            self.I.append(Ii)
+            self.G = self.G + Ii * omega
 
     # ------------------------------------------------------------------ solver/pEqn.H
     def p_corrector(self, final):
@@ -571,9 +617,10 @@ class StecklerCase:
         self.correct_nut()
 
 
-def first_step_records(with_h=True, hook=None):
+def first_step_records(with_h=True, hook=None, with_radiation=False):
     c = StecklerCase()
     c.hook = hook
+    c.with_radiation = with_radiation
     c.hydrostatic_init()
     c.correct_nut()                      # turbulence->validate()
     c.psi0, c.p0, c.p_rgh0, c.phi0 = c.psi.copy(), c.p.copy(), c.p_rgh.copy(), c.phi.copy()

@@ -128,3 +128,34 @@ def test_the_pins_are_sensitive_to_the_details_they_pin(O, monkeypatch):
     monkeypatch.setattr(fv, "limited_weights", three_valued)
     c = _run()
     assert dict(c.log)["k"]["nIterations"] == 2 and gold["k"]["nIterations"] == 3
+
+
+def test_the_32_ray_solves(O):
+    """radiation->correct() of the first time step (solver/YEEqn.H:80): the golden log holds one line per ray,
+    `GAMG:  Solving for ILambda_<i>_0, Initial residual = 1, Final residual = ..., No Iterations n` (log.fireFoam:183-214), and
+    `Radiant Fraction is 0.22`.  The oracle -- upwind ray equation with greyDiffusiveRadiation walls (oracle/steckler_case.py::
+    radiation_correct), GAMG with faceAreaPair agglomeration, DILU smoother, PBiCGStab on the coarsest level (oracle/gamg.py) --
+    reproduces every iteration count (1, 2 or 3 V-cycles) and every final residual: the 24 rays that need the multigrid cycle to
+    the log's 5 printed digits within 2e-4 (21 of the 24 in every printed digit), the 8 rays of the (+,+,+) / (-,-,-) octants, for which
+    DILU inverts the triangular upwind matrix exactly, at round-off level (log: 7.5e-16 ... 1.0e-15).
+    This pins through the reference's own output: GAMGSolver (V-cycle, nPreSweeps 0 / nPostSweeps 2 / nFinestSweeps 2, no scaling on
+    asymmetric matrices), pairGAMGAgglomeration with the faceAreaPair weights, the Galerkin coarse matrices, the DILU smoother and
+    preconditioner, PBiCGStab, fvm::div with Gauss upwind, the fvDOM ray set and solid angles."""
+    from oracle import steckler_case as SC
+    c = SC.first_step_records(with_h=False, with_radiation=True)
+    rays = [(n, p) for n, p in c.log if n.startswith("ILambda_")]
+    gold = GOLD["rays"]
+    assert len(rays) == len(gold) == 32
+    assert sig(c.radFraction, 5) == sig(GOLD["radiantFraction"], 5) == "0.22"
+    assert [n for n, _ in rays] == [g["name"] for g in gold]
+    assert [p["nIterations"] for _, p in rays] == [g["nIterations"] for g in gold]
+    exact = 0
+    for (name, p), g in zip(rays, gold):
+        assert sig(p["initialResidual"], 5) == sig(g["initialResidual"], 5) == "1", (name, p)
+        if g["finalResidual"] < 1e-14:
+            assert p["finalResidual"] < 2e-15, (name, p, g)                  # DILU is the exact inverse for these rays
+        else:
+            assert abs(p["finalResidual"] - g["finalResidual"]) <= 2e-4 * g["finalResidual"], (name, p, g)
+            exact += sig(p["finalResidual"], 5) == sig(g["finalResidual"], 5)
+    assert exact >= 20
+    assert sum(1 for g in gold if g["finalResidual"] < 1e-14) == 8
