@@ -6,7 +6,7 @@
       thermo        hePsiThermoJanaf      hePsiThermo<reactingMixture<sutherland<janaf<perfectGas>>>>   (constant/thermophysicalProperties:18-27)
       turbulence    kEqnLES               LES kEqn, delta cubeRootVol                                   (constant/turbulenceProperties:18-30)
       combustion    eddyDissipationEDC    the reference's eddyDissipationModel on the single-step mixture (constant/combustionProperties, reactions)
-      radiation     noRadiation           (the golden first step is reproduced without the fvDOM source: oracle/steckler_case.py)
+      radiation     fvDOM                 32 rays, constRadFractionEmission, greyDiffusiveRadiation walls, Ii by GAMG + DILU   (constant/radiationProperties)
       patch types   flowRateInletVelocity (0/U:40-54), totalFlowRateAdvectiveDiffusive (0/C3H8:44-50), inletOutlet, pressureInletOutletVelocity,
                     prghTotalHydrostaticPressure, fixedFluxPressure, mixedEnergy / fixedEnergy with compressible::thermalBaffle1D (0/T:51-82)
 
@@ -41,6 +41,9 @@ struct stecklerCaseData      // host arrays: cell fields [N] in the library's ce
     const double *fixesT, *inletOutletT; double Tinlet; long baffleMaster0, baffleSlave0, nBaffle; double baffleThickness, baffleQs, baffleKappa;
     const double *phTopMask, *phFluxMask, *fluxMaskP, *totalMaskP;      // ph_rgh: fixedValue 0 / fixedFluxPressure; p_rgh: fixedFluxPressure / prghTotalHydrostaticPressure
     const double *nutZeroGrad, *alphatZeroGrad;
+    // radiation: gamg != NULL selects the case's fvDOM (radiationProperties: nPhi 2, nTheta 4, solverFreq; constRadFractionEmission
+    // a = 0, Ehrr1 0.5, Ehrr2 0.22 over the burner faces = mlrMask; Ii by GAMG + DILU on the agglomeration gamg); NULL: noRadiation
+    ffm_gamg* gamg; int radiationFreq; const double* mlrMask; double sigmaSB;
     // results
     double *rhoOut, *UOut, *pOut, *p_rghOut, *hOut, *TOut, *kOut, *phiOutF; double* const* YOut;
     int* nIterOut; double* resOut; char* namesOut; int logCap;          // per solve: iterations, {initial, final} residual, field name [16]
@@ -162,7 +165,15 @@ struct stecklerSolver
         turbulence = autoPtr<compressible::turbulenceModel>(les);
         const singleStepMixture rx(cs->nSpecies, cs->W, cs->lowCpCoeffs, cs->RR, cs->stoich, cs->fuelIndex, cs->o2Index);
         combustion = autoPtr<combustionModels::psiCombustionModel>(new eddyDissipationEDC(thermo, rho, *les, cs->fuelIndex, cs->o2Index, rx.s, rx.qFuel, rx.massCoeffs));
-        radiation = autoPtr<radiation::radiationModel>(new noRadiation());
+        if (cs->gamg) {
+            mesh.gamg = cs->gamg;
+            solverControls ii; ii.solver = FFM_GAMG; ii.preconditioner = FFM_DILU; ii.tolerance = 1e-4; ii.relTol = 0;      // fvSolution:63-73
+            mesh.solvers["Ii"] = ii;
+            mesh.divSchemes["div(Ji,Ii_h)"] = {0, 1, 0, 1};                               // Gauss upwind (fvSchemes:60)
+            mesh.store("Qdot", Qdot);
+            radiation = autoPtr<radiation::radiationModel>(new fvDOM(mesh, T, 2, 4, cs->radiationFreq, 0.0, cs->sigmaSB, 0.5, 0.22, cs->mlrMask));
+        }
+        else radiation = autoPtr<radiation::radiationModel>(new noRadiation());
     }
     ~stecklerSolver() { if (th) ffm_thermo_destroy(th); }
 

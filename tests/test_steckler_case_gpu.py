@@ -3,8 +3,8 @@ createFields.H + time loop: the reference's own solver/phrghEqn.H, rhoEqn.H, UEq
 include/ffmFoam.H, with the case's real physics behind the handles of include/fireFoamHandles.H -- hePsiThermoJanaf (janaf /
 sutherland / perfectGas mixture, csrc/ffm_thermo.hip), kEqnLES (divDevRhoReff with the explicit stress term, the k equation:
 csrc/ffm_fused.hip), eddyDissipationEDC (the reference's eddyDissipationModel), flowRateInletVelocity,
-totalFlowRateAdvectiveDiffusive, mixedEnergy with thermalBaffle1D, prghTotalHydrostaticPressure, fixedFluxPressure, with OpenFOAM's
-stored-boundary-value semantics.  Nothing between the solves comes from the oracle: every field stays on the device from the 0/
+totalFlowRateAdvectiveDiffusive, mixedEnergy with thermalBaffle1D, prghTotalHydrostaticPressure, fixedFluxPressure, fvDOM (32 rays by
+GAMG + DILU, constRadFractionEmission, greyDiffusiveRadiation walls), with OpenFOAM's stored-boundary-value semantics.  Nothing between the solves comes from the oracle: every field stays on the device from the 0/
 files to the end of the step.
 
 Golden data: cases/steckler/original/linux64/log.fireFoam:92-101 (hydrostatic start-up) and :163-226 (first time step; fixture
@@ -39,6 +39,7 @@ class CaseData(C.Structure):
                 + [("fixesT", dp), ("inletOutletT", dp), ("Tinlet", C.c_double), ("baffleMaster0", C.c_long), ("baffleSlave0", C.c_long), ("nBaffle", C.c_long),
                    ("baffleThickness", C.c_double), ("baffleQs", C.c_double), ("baffleKappa", C.c_double)]
                 + [(n, dp) for n in ("phTopMask", "phFluxMask", "fluxMaskP", "totalMaskP", "nutZeroGrad", "alphatZeroGrad")]
+                + [("gamg", C.c_void_p), ("radiationFreq", C.c_int), ("mlrMask", dp), ("sigmaSB", C.c_double)]
                 + [(n, dp) for n in ("rhoOut", "UOut", "pOut", "p_rghOut", "hOut", "TOut", "kOut", "phiOutF")] + [("YOut", C.POINTER(dp))]
                 + [("nIterOut", C.POINTER(C.c_int)), ("resOut", dp), ("namesOut", C.c_char_p), ("logCap", C.c_int), ("contErrOut", dp)])
 
@@ -49,7 +50,7 @@ def sig(x, n):
 
 @pytest.mark.parametrize("tiled", [False, True])
 def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, capfd, tiled):
-    from oracle import steckler_case as SC, thermo as TH
+    from oracle import plume, steckler_case as SC, thermo as TH
     so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_steckler.so")
     if not os.path.exists(so):
         pytest.skip("libffm_steckler.so not built (needs /root/reference at build time)")
@@ -126,7 +127,9 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     fK = per(lambda p: -1.0 if p.name in io else (1.0 if p.name == "burner" else 0.0))
     out = dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), T=np.empty(N), k=np.empty(N), phi=np.empty(F),
                Y=[np.empty(N) for _ in sp])
-    cap = 32
+    cap = 64
+    # the mesh's cached GAMG agglomeration (faceAreaPair, nCellsInCoarsestLevel 10, mergeLevels 1: cases/steckler/system/fvSolution:63-73)
+    G = ffm.GAMG(ctx, A, l2, u2, Sf=m.Sf[fOrd])
     nit, res, nm, cerr = (C.c_int * cap)(), np.zeros(2 * cap), C.create_string_buffer(16 * cap), np.zeros(2)
     cnames = (C.c_char_p * len(sp))(*[s.encode() for s in sp]); keep.append(cnames)
     cs = CaseData(
@@ -142,6 +145,7 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
         nBaffle=m.patches[iM].size, baffleThickness=0.005, baffleQs=100.0, baffleKappa=1.0,
         phTopMask=P(on("top")), phFluxMask=P(1.0 - on("top")), fluxMaskP=P(1.0 - on(*io)), totalMaskP=P(on(*io)),
         nutZeroGrad=P(on("top", "sides", "burner")), alphatZeroGrad=P(1.0 - on(*wall)),
+        gamg=G.h, radiationFreq=100, mlrMask=P(on("burner")), sigmaSB=plume.SIGMA_SB,
         rhoOut=P(out["rho"]), UOut=P(out["U"]), pOut=P(out["p"]), p_rghOut=P(out["p_rgh"]), hOut=P(out["h"]), TOut=P(out["T"]), kOut=P(out["k"]),
         phiOutF=P(out["phi"]), YOut=PP(out["Y"]), nIterOut=nit, resOut=res.ctypes.data_as(dp), namesOut=C.cast(nm, C.c_char_p), logCap=cap,
         contErrOut=cerr.ctypes.data_as(dp))
@@ -167,10 +171,22 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     finally:
         os.environ["FFM_FOAM_QUIET"] = "1"
     got = [(nm.raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), nit[i], res[2 * i], res[2 * i + 1]) for i in range(n)]
-    gold = GOLD["solves"]
+    iCO2 = [g_["name"] for g_ in GOLD["solves"]].index("CO2")
+    gold = GOLD["solves"][:iCO2 + 1] + GOLD["rays"] + GOLD["solves"][iCO2 + 1:]          # radiation->correct() sits between Yi and h (solver/YEEqn.H:80)
     assert [g_[0] for g_ in got] == [g_["name"] for g_ in gold], got
     assert [g_[1] for g_ in got] == [g_["nIterations"] for g_ in gold], got
     for (name, _, r0, r1), g_ in zip(got, gold):
+        if name.startswith("ILambda_"):
+            # the 32 ray solves (log.fireFoam:183-214): V-cycle counts asserted above.  Final residuals: round-off level for the 8
+            # rays DILU inverts exactly; the others to 1 % -- the oracle, with OpenFOAM's serial sums, gets the log's five digits
+            # (tests/test_steckler_first_step_cpu.py::test_the_32_ray_solves), the device's tree-summed dot products inside the
+            # coarsest-level PBiCGStab and the residual norms move the 1e-5-level end value of a 1-3 cycle solve in its 3rd digit
+            assert sig(r0, 5) == "1", (name, r0)
+            if g_["finalResidual"] < 1e-14:
+                assert r1 < 2e-15, (name, r1, g_)
+            else:
+                assert abs(r1 - g_["finalResidual"]) <= 1e-2 * g_["finalResidual"], (name, r1, g_)
+            continue
         if name in ("O2", "C3H8"):
             assert abs(r0 - g_["initialResidual"]) < 1e-5, (name, r0, g_)
         else:
@@ -192,6 +208,8 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     assert "DICPCG:  Solving for p_rgh, Initial residual = 0.0052595, Final residual = 8.7647e-07, No Iterations 28" in text
     assert "smoothSolver:  Solving for h, Initial residual = 1, Final residual = 6.5274e-13, No Iterations 2" in text
     assert "min/max(T) = 298.15, 300.49" in text
+    assert "Radiation solver iter: 0" in text and "Radiant Fraction is 0.22" in text
+    assert "GAMG:  Solving for ILambda_17_0, Initial residual = 1, Final residual = " in text and text.count("GAMG:  Solving for ILambda_") == 32
     cont = re.findall(r"time step continuity errors : sum local = (\S+), global = (\S+), cumulative", text)
     assert len(cont) == 2
     for (a, b), g_ in zip(cont, GOLD["continuity_errors"]):
@@ -218,4 +236,4 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     for i, s in enumerate(sp):
         close(back(out["Y"][i]), c.Y[i], 1e-6, s)
     lib.firefoam_steckler_destroy(S)
-    mesh.close(); A.close()
+    G.close(); mesh.close(); A.close()
