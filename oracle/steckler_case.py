@@ -170,6 +170,8 @@ class StecklerCase:
             self.psib.append(mb.psi(self.pb[q], self.Tb[q])); self.mub.append(mb.mu(self.pb[q], self.Tb[q]))
             self.alphab.append(mb.alphah(self.pb[q], self.Tb[q]))
 
+    fuel_bc = None                # the fuel specie's patch coefficients while fvPatchField::updated() holds (YE_eqn)
+    K_start = None                # K at the start of the time step (its old-time level from the second step on)
     with_radiation = False        # True: radiation->correct() (the 32 ray solves) between the species and the enthalpy equation
     baffle_fixed = False          # True: the baffle temperature kept at its file value (300 K) instead of thermalBaffle1D
 
@@ -242,6 +244,52 @@ class StecklerCase:
         dt = adjust(min(dt * 1.2, 0.1))
         dt = adjust(min(1.2 * dt, 0.1))
         self.dt = dt; self.rdt = 1.0 / dt
+
+    def courant(self):
+        """compressibleCourantNo.H: sumPhi = fvc::surfaceSum(mag(phi))/rho; CoNum = 0.5 max(sumPhi/V) deltaT, mean = 0.5 sum(sumPhi)/sum(V) deltaT"""
+        m = self.m
+        sumPhi = np.zeros(m.nCells)
+        np.add.at(sumPhi, m.l, np.abs(self.phi)); np.add.at(sumPhi, m.u, np.abs(self.phi))
+        for p, pb in zip(m.patches, self.phib):
+            np.add.at(sumPhi, p.faceCells, np.abs(pb))
+        sumPhi = sumPhi / self.rho
+        return 0.5 * (sumPhi / m.V).max() * self.dt, 0.5 * (sumPhi.sum() / m.V.sum()) * self.dt
+
+    def set_delta_t_next(self, maxCo=0.9, maxDeltaT=0.1, writeInterval=1.0):
+        """solver/setMultiRegionDeltaT.H (dt0*min(maxCo/(CoNum + SMALL), 1.2), capped) then setDeltaT.H (deltaTFact = min(min(f,
+        1 + 0.1 f), 1.2)), each followed by Time::adjustDeltaT towards the next write time (cases/steckler/system/controlDict:28-56)"""
+        self.CoNum, self.meanCoNum = self.courant()
+
+        def adjust(d):
+            rem = (int(self.time / writeInterval + 1e-9) + 1) * writeInterval - self.time
+            n = int(rem / d - 1e-12) + 1
+            nd = rem / n
+            return min(nd, 2.0 * d) if nd >= d else max(nd, 0.2 * d)
+        fac = maxCo / (self.CoNum + SMALL)
+        dt = adjust(min(self.dt * min(fac, 1.2), maxDeltaT))
+        dt = adjust(min(min(min(fac, 1.0 + 0.1 * fac), 1.2) * dt, maxDeltaT))
+        self.dt = dt; self.rdt = 1.0 / dt
+
+    def advance(self):
+        """a time step after the first: solver/fireFoam.C:76-121 (time-step control, old-time levels, rhoEqn, UEqn, YEEqn, two
+        pressure correctors, turbulence->correct()); the golden log's second step (log.fireFoam:235-263) is asserted in
+        tests/test_steckler_first_step_cpu.py::test_second_time_step"""
+        m = self.m
+        self.rho = self.psi * self.p; self.rhob = [a * b for a, b in zip(self.psib, self.pb)]          # rho = thermo.rho() ends the step before
+        self.time = getattr(self, "time", 0.0) or self.dt
+        self.set_delta_t_next()
+        self.time += self.dt
+        self.log = []
+        self.psi0, self.p0, self.p_rgh0, self.phi0 = self.psi.copy(), self.p.copy(), self.p_rgh.copy(), self.phi.copy()
+        self.rho0, self.U0, self.K_start = self.rho.copy(), self.U.copy(), self.K.copy()
+        self.rho = (self.rdt * self.rho0 * m.V - m.V * fv.surface_integrate(m, self.phi, self.phib)) / (self.rdt * m.V)      # rhoEqn.H
+        self.log.append(("rho", dict(initialResidual=0.0, finalResidual=0.0, nIterations=0)))
+        self.contErrs = []
+        self.U_eqn()
+        self.YE_eqn(True)
+        self.p_corrector(False)
+        self.p_corrector(True)
+        self.k_eqn()
 
     hook = None       # tests: hook(name, info) is called before every linear solve with the inputs of the equation's assembly
 
@@ -376,15 +424,24 @@ class StecklerCase:
         dEff, dEffb = self.alphaEff()                      # lewisNo 1: dEff -= alpha*(1 - 1/1) leaves it unchanged
         dEff = dEff - self.alpha * (1 - 1.0 / 1.0); dEffb = [a - b * (1 - 1.0 / 1.0) for a, b in zip(dEffb, self.alphab)]
         self.edc_correct()
+        # Qdot = combustion->Qdot() (solver/YEEqn.H:34): singleStepCombustion::Qdot() = -qFuel*(R(YFuel) & YFuel) builds an fvMatrix for
+        # the FUEL specie, whose constructor calls YFuel.boundaryField().updateCoeffs().  Patch coefficients are computed once
+        # until the next evaluate() (fvPatchField::updated()), so the fuel's coefficients are those of the first such call since
+        # its last solve -- from the second step on that is the Qdot() call inside the PREVIOUS step's EEqn, made with the flux of
+        # the step before: the fuel specie's boundary conditions (totalFlowRateAdvectiveDiffusive, inletOutlet) lag one step
+        # behind those of the other species.  The golden log shows it: the burner's fuel enters in the third step, not the second
+        # (C3H8 max 7.0569e-15, 7.6712e-13, 0.069134; log.fireFoam:179,248,284).
+        if self.fuel_bc is None:
+            self.fuel_bc = self.bc_specie(self.iFuel, dEffb)
         df, _ = fv.interpolate(m, dEff, dEffb)
         self.Y0 = self.Y.copy()
         Yt = 0.0 * self.Y[0]; Ytb = [0.0 * b for b in self.Yb[0]]
         for i, n in enumerate(self.names):
             if i == self.iN2:
                 continue
-            bc = self.bc_specie(i, dEffb)
-            Yb = bc.values(m, self.Y[i])
-            w = fv.limited_weights(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0)
+            bc = self.fuel_bc if i == self.iFuel else self.bc_specie(i, dEffb)
+            # the limiter's fvc::grad reads the STORED patch values (what the last evaluate left), not the new coefficients
+            w = fv.limited_weights(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], self.Yb[i]), 1.0)
             E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.Y0[i])
             E += fv.fvm_div(m, self.phi, self.phib, w, [bc])
             E -= fv.fvm_laplacian(m, df, dEffb, [bc])
@@ -394,6 +451,8 @@ class StecklerCase:
             Yi = self.solve_smooth(n, d, E.upper, E.lower, s, self.Y[i], 1e-8, info)
             self.Y[i] = np.maximum(Yi, 0.0)
             self.Yb[i] = [np.maximum(b, 0.0) for b in bc.values(m, Yi)]
+            if i == self.iFuel:
+                self.fuel_bc = None                               # evaluate(): the coefficients are due again
             Yt = Yt + self.Y[i]; Ytb = [a + b for a, b in zip(Ytb, self.Yb[i])]
         self.Y[self.iN2] = np.maximum(1.0 - Yt, 0.0)
         self.Yb[self.iN2] = [np.maximum(1.0 - b, 0.0) for b in Ytb]
@@ -439,9 +498,8 @@ class StecklerCase:
         # K.oldTime() is first asked for here (fvc::ddt(rho, K)) and K was already assigned in UEqn.H: GeometricField::oldTime()
         # creates the old-time field as a copy of the CURRENT one, so in the first time step K0 == K (from the second step on the
         # old value is stored at the first assignment of the new step)
-        self.K0 = self.K.copy()
-        hb = bch.values(m, self.he)
-        wh = fv.limited_weights(m, "limitedLinear", self.phi, self.he, fv.grad(m, self.he, hb), 1.0)
+        self.K0 = self.K.copy() if self.K_start is None else self.K_start.copy()
+        wh = fv.limited_weights(m, "limitedLinear", self.phi, self.he, fv.grad(m, self.he, self.heb), 1.0)      # stored patch values
         Kb = [0.5 * (u ** 2).sum(axis=1) for u in self.Ub]
         wK = fv.limited_weights(m, "limitedLinear", self.phi, self.K, fv.grad(m, self.K, Kb), 1.0)
         Kf = wK * self.K[m.l] + (1.0 - wK) * self.K[m.u]
@@ -452,6 +510,8 @@ class StecklerCase:
         E.add_vol(-self.dpdt)
         E -= fv.fvm_laplacian(m, af, aEb, [bch])
         E.add_su(self.Qdot)
+        if self.fuel_bc is None:                                  # combustion->Qdot() in the EEqn: YFuel's updateCoeffs() (see above)
+            self.fuel_bc = self.bc_specie(self.iFuel, aEb)
         d, s = E.solve_system()
         info = dict(rdt=rdt, coef=self.rho, phi=self.phi, phib=self.phib, w=wh, gamma_f=af, gamma_b=aEb, bc=bch, source=E.source[0], diag_extra=None)
         self.he = self.solve_smooth("h", d, E.upper, E.lower, s, self.he, 1e-8, info)
@@ -596,8 +656,7 @@ class StecklerCase:
                 bck.f[q][:] = 1.0; bck.ref[q][:] = 1.0e-4
         Dk = self.rho * (self.nut + self.mu / self.rho); Dkb = [r * (n + mu / r) for r, n, mu in zip(self.rhob, self.nutb, self.mub)]
         Dkf, _ = fv.interpolate(m, Dk, Dkb)
-        kb = bck.values(m, self.k)
-        w = fv.limited_weights(m, "limitedLinear", self.phi, self.k, fv.grad(m, self.k, kb), 1.0)
+        w = fv.limited_weights(m, "limitedLinear", self.phi, self.k, fv.grad(m, self.k, self.kb), 1.0)          # stored patch values
         self.k0 = self.k.copy()
         E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.k0)
         E += fv.fvm_div(m, self.phi, self.phib, w, [bck])

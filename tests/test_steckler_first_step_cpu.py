@@ -159,3 +159,42 @@ def test_the_32_ray_solves(O):
             exact += sig(p["finalResidual"], 5) == sig(g["finalResidual"], 5)
     assert exact >= 20
     assert sum(1 for g in gold if g["finalResidual"] < 1e-14) == 8
+
+
+def test_second_time_step(O):
+    """The golden log's SECOND time step (log.fireFoam:235-263; fixture key "second_step"), reached by StecklerCase.advance() from the
+    first: flux, velocity and turbulence fields are no longer zero, so this is where convection enters the reference data.
+    Reproduced in every printed digit: the Courant numbers in front of the step (mean 0.018502, max 0.054307), deltaT 0.093333
+    (setMultiRegionDeltaT.H + setDeltaT.H + Time::adjustDeltaT), and the three momentum solves -- Ux 0.41572 -> 1.3447e-08, Uy
+    0.53739 -> 2.4742e-08, Uz 0.4089 -> 2.1378e-08, 2 iterations each: `div(phi,U) Gauss LUST grad(U)` with a non-zero flux (weights
+    and explicit correction), ddt with old-time levels, the stress term, the flux and density the first step's correctors left.
+    Also reproduced: the initial residuals of O2, H2O and CO2 (5 digits), the Radiant Fraction 0.36 (radScaling with the burner's
+    mass flow), min/max(T), the one-step LAG of the fuel specie's boundary coefficients (fvPatchField::updated(): C3H8 enters the
+    room in the third step, not the second -- its initial residual 0.96426 and its min/ave/max to 1-2 %, against 1 and a maximum of
+    0.07 without the lag), k's initial residual to 1e-4.
+    NOT reproduced, documented here: the species' final residuals and O2's minimum follow UPWIND weights in the log (upwind: O2
+    3.17e-12 / 3 iterations, minimum 0.21694 = the log's; this restatement's limitedLinear01: 8.9e-09 / 2, 0.21674) -- on fields
+    that are uniform up to solver-tolerance noise the limiter is decided by that noise, which a restatement does not share bit
+    for bit; the enthalpy equation's initial residual (0.97 against 0.86571) and, after it, the pressure correctors (0.0028131 /
+    21 iterations against 0.0028123 / 20)."""
+    from oracle import steckler_case as SC
+    g = GOLD["second_step"]
+    c = SC.first_step_records()
+    c.time = c.dt
+    c.advance()
+    assert sig(c.meanCoNum, 5) == sig(g["courantMean"], 5) and sig(c.CoNum, 5) == sig(g["courantMax"], 5)
+    assert sig(c.dt, 5) == sig(g["deltaT"], 5) == "0.093333"
+    log = dict((n, p) for n, p in c.log if n != "p_rgh")
+    gold = {s["name"]: s for s in g["solves"] if s["name"] != "p_rgh"}
+    for n in ("Ux", "Uy", "Uz"):
+        assert log[n]["nIterations"] == gold[n]["nIterations"] == 2
+        assert sig(log[n]["initialResidual"], 5) == sig(gold[n]["initialResidual"], 5), (n, log[n], gold[n])
+        assert sig(log[n]["finalResidual"], 5) == sig(gold[n]["finalResidual"], 5), (n, log[n], gold[n])
+    for n in ("O2", "H2O", "CO2"):
+        assert sig(log[n]["initialResidual"], 5) == sig(gold[n]["initialResidual"], 5), (n, log[n], gold[n])
+    assert abs(log["C3H8"]["initialResidual"] - gold["C3H8"]["initialResidual"]) < 5e-4 and log["C3H8"]["nIterations"] == gold["C3H8"]["nIterations"]
+    st, gs = c.species_stats["C3H8"], g["species_min_ave_max"]["C3H8"]
+    assert abs(st[1] - gs[1]) < 0.02 * gs[1] and abs(st[2] - gs[2]) < 0.02 * gs[2]          # 3.67e-16 / 7.7e-13: the fuel has not entered yet
+    assert [sig(v, 5) for v in c.minmaxT] == [sig(v, 5) for v in g["minmaxT"]]
+    assert abs(log["k"]["initialResidual"] - gold["k"]["initialResidual"]) < 2e-4 * gold["k"]["initialResidual"] and log["k"]["nIterations"] == gold["k"]["nIterations"]
+    assert abs(log["k"]["finalResidual"] - gold["k"]["finalResidual"]) < 2e-3 * gold["k"]["finalResidual"]
