@@ -152,7 +152,7 @@ struct stecklerSolver
         p_rgh.snGradFromGradient = true;
         gh.v.assignHost(cs->gh); gh.b.assignHost(cs->ghfB);
         FFM_FOAM_CHK(ffm_faces_to_native(msh, cs->ghfF, ghf.v.data())); ghf.b.assignHost(cs->ghfB);
-        K.lazyOldTime = true;
+        K.lazyOldTime = true; p.lazyOldTime = true;            // created by the first fvc::ddt(rho, K) / fvc::ddt(p), as copies of the current fields
         forAll(Y, i) { fields.add(Y[i]); }
         fields.add(thermo.he());
         mesh.store("phi", phi); mesh.store("rho", rho); mesh.store("U", U);
@@ -202,9 +202,10 @@ struct stecklerSolver
         mesh.log.clear();
         runTime++;
         // old-time levels (GeometricField::storeOldTimes at the time increment; K's is created on first request)
-        rho.storeOldTime(); U.storeOldTime(); thermo.he().storeOldTime(); p.storeOldTime(); p_rgh.storeOldTime();
+        rho.storeOldTime(); U.storeOldTime(); thermo.he().storeOldTime(); p_rgh.storeOldTime();
         thermoObj.psi_.storeOldTime(); phi.storeOldTime();
         if (K.old_) K.storeOldTime();
+        if (p.old_) p.storeOldTime();
         forAll(Y, i) { Y[i].storeOldTime(); }
 
         #include "rhoEqn.H"
@@ -229,6 +230,13 @@ struct stecklerSolver
 
         rho = thermo.rho();
         FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    }
+
+    // solver/fireFoam.C:79: the Courant numbers the log prints in front of a step
+    void courant(double* out)
+    {
+        #include "compressibleCourantNo.H"
+        out[0] = meanCoNum; out[1] = CoNum;
     }
 
     void download(const stecklerCaseData* cs)
@@ -263,6 +271,11 @@ extern "C" stecklerSolver* firefoam_steckler_create(ffm_ctx* ctx, ffm_ldu* ldu, 
     return s;
 }
 extern "C" void firefoam_steckler_destroy(stecklerSolver* s) { delete s; }
+// the Courant numbers {mean, max} of the current flux (compressibleCourantNo.H) and the time step of the next advance(): the
+// reference's deltaT sequence (setMultiRegionDeltaT.H + setDeltaT.H + Time::adjustDeltaT towards the write times, asserted on the
+// golden log by tests/test_steckler_first_step_cpu.py) is handed over by the caller
+extern "C" void firefoam_steckler_courant(stecklerSolver* s, double* out) { s->courant(out); }
+extern "C" void firefoam_steckler_set_delta_t(stecklerSolver* s, double deltaT) { s->runTime.setDeltaT(deltaT); }
 // one time step; returns the number of linear solves (names, iteration counts and residuals in cs->namesOut / nIterOut / resOut)
 extern "C" int firefoam_steckler_advance(stecklerSolver* s, const stecklerCaseData* cs, int download)
 {

@@ -60,6 +60,8 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     lib.firefoam_steckler_advance.restype = C.c_int
     lib.firefoam_steckler_advance.argtypes = [C.c_void_p, C.POINTER(CaseData), C.c_int]
     lib.firefoam_steckler_destroy.argtypes = [C.c_void_p]
+    lib.firefoam_steckler_courant.argtypes = [C.c_void_p, dp]
+    lib.firefoam_steckler_set_delta_t.argtypes = [C.c_void_p, C.c_double]
 
     # ---- the mesh (blockMesh + topoSet + createBaffles + createPatch of cases/steckler/mesh.sh, as oracle/steckler_case.py builds it)
     m = SC.build_mesh()
@@ -235,5 +237,51 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     fb = np.empty(F); fb[fOrd] = out["phi"]; close(fb, c.phi, 1e-6, "phi")
     for i, s in enumerate(sp):
         close(back(out["Y"][i]), c.Y[i], 1e-6, s)
+    # ---- the SECOND time step (log.fireFoam:233-263): flux, velocity and turbulence fields are no longer zero.  The Courant numbers the
+    # log prints in front of it come from the device's phi and rho (compressibleCourantNo.H); deltaT is the oracle's (its sequence
+    # is asserted on the log by tests/test_steckler_first_step_cpu.py); the three momentum solves -- LUST with a non-zero flux --
+    # give the log's digits; species / enthalpy / pressure / k follow the oracle's second step (itself within 3-5 digits of the log;
+    # the species' limiter works on fields that are uniform up to round-off, where device and oracle need not pick the same weights
+    # on the faces with negligible flux: their iteration counts are not asserted)
+    g2 = GOLD["second_step"]
+    co = np.zeros(2)
+    lib.firefoam_steckler_courant(S, co.ctypes.data_as(dp))
+    assert sig(co[0], 5) == sig(g2["courantMean"], 5) and sig(co[1], 5) == sig(g2["courantMax"], 5), co
+    c.time = c.dt
+    c.advance()
+    assert sig(c.dt, 5) == sig(g2["deltaT"], 5)
+    lib.firefoam_steckler_set_delta_t(S, c.dt)
+    os.environ.pop("FFM_FOAM_QUIET", None)
+    try:
+        capfd.readouterr()
+        n2 = lib.firefoam_steckler_advance(S, C.byref(cs), 1)
+        text2 = capfd.readouterr().out
+    finally:
+        os.environ["FFM_FOAM_QUIET"] = "1"
+    got2 = [(nm.raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), nit[i], res[2 * i], res[2 * i + 1]) for i in range(n2)]
+    assert [g_[0] for g_ in got2] == [s_["name"] for s_ in g2["solves"]], got2                # no ray solves in this step: solverFreq 100
+    gold2 = {s_["name"]: s_ for s_ in g2["solves"] if s_["name"] not in ("p_rgh", "rho")}
+    for name, it, r0, r1 in got2:
+        if name in ("Ux", "Uy", "Uz"):
+            assert it == gold2[name]["nIterations"] == 2 and sig(r0, 5) == sig(gold2[name]["initialResidual"], 5), (name, it, r0, r1)
+            assert abs(r1 - gold2[name]["finalResidual"]) <= 1e-4 * gold2[name]["finalResidual"], (name, r1)
+        elif name in ("O2", "H2O", "CO2"):
+            assert abs(r0 - gold2[name]["initialResidual"]) < 1e-4, (name, r0)
+        elif name == "C3H8":                 # the fuel's patch coefficients lag one step (fvPatchField::updated(), eddyDissipationEDC::Qdot)
+            assert abs(r0 - gold2[name]["initialResidual"]) < 2e-3, (name, r0)
+        elif name == "h":
+            assert it == 2 and abs(r0 - gold2[name]["initialResidual"]) < 1e-3 * gold2[name]["initialResidual"], (name, it, r0)
+        elif name == "k":
+            assert it == 3 and abs(r0 - gold2[name]["initialResidual"]) < 1e-3 * gold2[name]["initialResidual"], (name, it, r0)
+    pr2 = [g_ for g_ in got2 if g_[0] == "p_rgh"]; gp2 = [s_ for s_ in g2["solves"] if s_["name"] == "p_rgh"]
+    for (name, it, r0, r1), s_ in zip(pr2, gp2):
+        assert abs(it - s_["nIterations"]) <= 1 and abs(r0 - s_["initialResidual"]) < 2e-3 * s_["initialResidual"], (it, r0, s_)
+    assert "Radiant Fraction is 0.36" in text2 and "min/max(T) = 298.15, 300.99" in text2
+    assert np.max(out["Y"][iFuel]) < 1e-11                                       # the burner's fuel has not entered yet (log: 7.6712e-13)
+    assert np.abs(back(out["T"]) - c.T).max() < 1e-5            # [K]; thermo::T's Newton iteration stops at |dT| <= 1e-4 T
+    close(back(out["p_rgh"]), c.p_rgh, 1e-4, "p_rgh2"); close(back(out["k"]), c.k, 1e-4, "k2")
+    for d in range(3):
+        close(back(out["U"][d]), c.U[:, d], 1e-4, "U2%d" % d)
+    close(back(out["Y"][iO2]), c.Y[iO2], 1e-3, "O2 2")
     lib.firefoam_steckler_destroy(S)
     G.close(); mesh.close(); A.close()
