@@ -275,14 +275,9 @@ def reconstruct(mesh, ssf, bssf):
     return np.einsum("nab,nb->na", np.linalg.inv(T + E) - E, v)
 
 
-def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
-    """Face weights of upwind / linear / limitedLinear k / limitedLinear01 k
-    (limitedSurfaceInterpolationScheme::weights, NVDTVD::r, limitedLinearLimiter, LimitedLimiter)."""
-    w = mesh.weights
-    if scheme == "linear":
-        return w.copy()
-    if scheme == "upwind":
-        return pos0(phi)
+def limited_limiter(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
+    """The limiter field of limitedLinear k / limitedLinear01 k (limitedSurfaceInterpolationScheme::limiter: NVDTVD::r,
+    limitedLinearLimiter, LimitedLimiter): 1 = linear, 0 = upwind."""
     P, Nn = vf[mesh.l], vf[mesh.u]
     d = mesh.C[mesh.u] - mesh.C[mesh.l]
     gradf = Nn - P
@@ -301,6 +296,18 @@ def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
         lim = np.where(off, 0.0, lim)
     elif scheme != "limitedLinear":
         raise ValueError(scheme)
+    return lim
+
+
+def limited_weights(mesh, scheme, phi, vf, gradvf, k=1.0, bounds=(0.0, 1.0)):
+    """Face weights of upwind / linear / limitedLinear k / limitedLinear01 k
+    (limitedSurfaceInterpolationScheme::weights = limiter*linear + (1 - limiter)*upwind)."""
+    w = mesh.weights
+    if scheme == "linear":
+        return w.copy()
+    if scheme == "upwind":
+        return pos0(phi)
+    lim = limited_limiter(mesh, scheme, phi, vf, gradvf, k, bounds)
     return lim * w + (1.0 - lim) * pos0(phi)
 
 

@@ -9,8 +9,8 @@ with OpenFOAM's stored-boundary-value semantics (a patch value changes only when
 Golden data: cases/steckler/original/linux64/log.fireFoam:163-226 (the first time step): deltaT, the Ux/Uy/Uz, O2, C3H8, h, p_rgh
 and k solves, species min/ave/max, min/max(T).  What of it this restatement reproduces, and how closely, is asserted in
 tests/test_steckler_first_step_cpu.py; every deviation is documented there.  The fvDOM ray solves of the step (the log's 32 GAMG
-lines, :183-214) are radiation_correct(), switched on by with_radiation.  NOT modelled: the source radiation->Sh in the enthalpy
-equation (-RadFraction*Qdot with a = 0: about 1e-8 W/m3 in this step).  compressible::thermalBaffle1D on the baffles is modelled
+lines, :183-214) are radiation_correct(), switched on by with_radiation; the source radiation->Sh in the enthalpy equation is
+-RadFraction*Qdot (a = 0), always present.  compressible::thermalBaffle1D on the baffles is modelled
 (baffle_fixed = True keeps their file value 300 K instead).
 Only tests/ may import this module."""
 import os
@@ -172,7 +172,7 @@ class StecklerCase:
 
     # convection scheme of the species (cases/steckler/system/fvSchemes:36-47: limitedLinear01 1).  "upwind" is an experiment switch:
     # with it the golden log's second and third steps come out in (nearly) every digit, see tests/test_steckler_first_step_cpu.py
-    species_scheme = "limitedLinear01"
+    species_scheme = "multivariateSelection"
     p_old = None                  # p.oldTime() as fvc::ddt(p) sees it (p_corrector)
     fuel_bc = None                # the fuel specie's patch coefficients while fvPatchField::updated() holds (YE_eqn)
     K_start = None                # K at the start of the time step (its old-time level from the second step on)
@@ -438,6 +438,18 @@ class StecklerCase:
         if self.fuel_bc is None:
             self.fuel_bc = self.bc_specie(self.iFuel, dEffb)
         df, _ = fv.interpolate(m, dEff, dEffb)
+        # mvConvection (solver/YEEqn.H:1-10): `Gauss multivariateSelection { O2 limitedLinear01 1; ... h limitedLinear 1; }`.  The
+        # multivariateSelectionScheme computes ONE limiter when it is constructed -- the minimum, face by face, of the limiters its
+        # member schemes give for their own fields (all species, N2 included, and h: solver/createFields.H `fields`), from the values
+        # the fields have at that moment -- and every fvmDiv(phi, Yi) / fvmDiv(phi, he) of the step uses the weights made of it,
+        # so that the species are interpolated consistently.  Where one field is uniform up to solver noise its limiter is ~0
+        # (the face difference is noise, the cell gradient averages it away: r ~ -1), and all species fall back to upwind there:
+        # what the golden log's second and third steps show.  species_scheme = "independent" restores one limiter per field.
+        if self.species_scheme == "multivariateSelection":
+            lim = fv.limited_limiter(m, "limitedLinear", self.phi, self.he, fv.grad(m, self.he, self.heb), 1.0)
+            for i in range(len(self.names)):
+                lim = np.minimum(lim, fv.limited_limiter(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], self.Yb[i]), 1.0))
+            self.w_mv = lim * m.weights + (1.0 - lim) * fv.pos0(self.phi)
         self.Y0 = self.Y.copy()
         Yt = 0.0 * self.Y[0]; Ytb = [0.0 * b for b in self.Yb[0]]
         for i, n in enumerate(self.names):
@@ -445,7 +457,10 @@ class StecklerCase:
                 continue
             bc = self.fuel_bc if i == self.iFuel else self.bc_specie(i, dEffb)
             # the limiter's fvc::grad reads the STORED patch values (what the last evaluate left), not the new coefficients
-            w = fv.limited_weights(m, self.species_scheme, self.phi, self.Y[i], fv.grad(m, self.Y[i], self.Yb[i]), 1.0)
+            if self.species_scheme == "multivariateSelection":
+                w = self.w_mv
+            else:
+                w = fv.limited_weights(m, "upwind" if self.species_scheme == "upwind" else "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], self.Yb[i]), 1.0)
             E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.Y0[i])
             E += fv.fvm_div(m, self.phi, self.phib, w, [bc])
             E -= fv.fvm_laplacian(m, df, dEffb, [bc])
@@ -503,7 +518,8 @@ class StecklerCase:
         # creates the old-time field as a copy of the CURRENT one, so in the first time step K0 == K (from the second step on the
         # old value is stored at the first assignment of the new step)
         self.K0 = self.K.copy() if self.K_start is None else self.K_start.copy()
-        wh = fv.limited_weights(m, "limitedLinear", self.phi, self.he, fv.grad(m, self.he, self.heb), 1.0)      # stored patch values
+        wh = self.w_mv if self.species_scheme == "multivariateSelection" else \
+            fv.limited_weights(m, "limitedLinear", self.phi, self.he, fv.grad(m, self.he, self.heb), 1.0)      # stored patch values
         Kb = [0.5 * (u ** 2).sum(axis=1) for u in self.Ub]
         wK = fv.limited_weights(m, "limitedLinear", self.phi, self.K, fv.grad(m, self.K, Kb), 1.0)
         Kf = wK * self.K[m.l] + (1.0 - wK) * self.K[m.u]
@@ -514,6 +530,13 @@ class StecklerCase:
         E.add_vol(-self.dpdt)
         E -= fv.fvm_laplacian(m, af, aEb, [bch])
         E.add_su(self.Qdot)
+        # radiation->Sh(thermo, he) = Ru - fvm::Sp(4 Rp T^3/Cpv, he) - Rp T^3 (T - 4 he/Cpv) with a = 0 (constRadFractionEmission): Rp = 0,
+        # Ru = a G - E = -RadFraction*Qdot: the radiated fraction of the heat release leaves the enthalpy equation (from the fourth
+        # step on, when the mixture ignites, this is a third of the source: min/max(T) of the log, 329.05 there, needs it)
+        q = self.pidx["burner"]
+        mlr = -float(np.sum(self.phib[q]))
+        self.radFraction = max(min(0.5, 0.22), (mlr * 0.5 + mlr * 0.22) / max(SMALL, mlr + mlr))
+        E.add_su(-self.radFraction * self.Qdot)
         if self.fuel_bc is None:                                  # combustion->Qdot() in the EEqn: YFuel's updateCoeffs() (see above)
             self.fuel_bc = self.bc_specie(self.iFuel, aEb)
         d, s = E.solve_system()
