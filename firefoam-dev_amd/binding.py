@@ -206,6 +206,8 @@ def lib():
         "ffm_fvc_grad": ([vp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fvc_reconstruct": ([vp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fv_limited_weights": ([vp, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp], C.c_int),
+        "ffm_fv_limited_limiter": ([vp, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp, C.c_int], C.c_int),
+        "ffm_fv_weights_from_limiter": ([vp, dp, dp, dp], C.c_int),
         "ffm_fvm_transport": ([vp, C.c_double, dp, dp, dp, dp, C.c_int, dp, dp, dp], C.c_int),
         "ffm_fvm_boundary_coeffs": ([vp, dp, dp, C.c_int, dp, dp, dp, dp, dp], C.c_int),
         "ffm_bc_values": ([vp, dp, dp, dp, dp, dp], C.c_int),

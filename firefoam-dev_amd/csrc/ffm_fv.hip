@@ -224,6 +224,9 @@ __global__ void k_snGrad_b(int B, const int *__restrict__ fc, const double *__re
 
 // limited-scheme face weights (NVDTVD::r, limitedLinearLimiter, LimitedLimiter, weights())
 // scheme: 0 upwind, 1 linear, 2 limitedLinear, 3 limitedLinear01
+// MODE 0: the weights; MODE 1: the limiter itself (limitedSurfaceInterpolationScheme::limiter; schemes 2 and 3); MODE 2: out = min(out,
+// limiter) -- the running minimum over the fields of a multivariateSelection scheme (ffm_fv_limited_limiter)
+template <int MODE>
 __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double lo, double hi, const double *__restrict__ phi,
                                   const double *__restrict__ vf, const double *__restrict__ gx, const double *__restrict__ gy,
                                   const double *__restrict__ gz, const double *__restrict__ Cx, const double *__restrict__ Cy,
@@ -255,9 +258,9 @@ __global__ void k_limited_weights(MeshView q, int scheme, double twoByk, double 
                 if (scheme == 3) {
                     if ((flux > 0 && (P < lo || Nn > hi)) || (flux < 0 && (Nn < lo || P > hi))) lim = 0.0;
                 }
-                wgt = lim * q.w[e] + (1.0 - lim) * p0;
+                wgt = MODE == 0 ? lim * q.w[e] + (1.0 - lim) * p0 : lim;
             }
-            out[e] = wgt;
+            out[e] = MODE == 2 ? fmin(out[e], wgt) : wgt;
         }
     }
 }
@@ -614,7 +617,34 @@ extern "C" int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double 
 {
     CHECK_M(m);
     if (scheme < 0 || scheme > 5 || !phi_f || !out_w || ((scheme == 2 || scheme == 3) && (!vf || !gx || !gy || !gz))) return FFM_ERR_ARG;
-    LAUNCH_CELLS(k_limited_weights, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], out_w);
+    LAUNCH_CELLS(k_limited_weights<0>, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], out_w);
+    DONE();
+}
+// The limiter of limitedLinear k (scheme 2) / limitedLinear01 k (scheme 3) for one field; accumulateMin != 0: lim_f = min(lim_f, limiter).
+// With ffm_fv_weights_from_limiter this is multivariateSelectionScheme (solver/YEEqn.H:1-10, cases/steckler/system/fvSchemes:36-47):
+// one limiter for all fields of the table -- the face-wise minimum of the member schemes' limiters -- and the weights made of it.
+extern "C" int ffm_fv_limited_limiter(ffm_mesh *m, int scheme, double k, double lo, double hi, const double *phi_f, const double *vf,
+                                      const double *gx, const double *gy, const double *gz, double *lim_f, int accumulateMin)
+{
+    CHECK_M(m);
+    if ((scheme != 2 && scheme != 3) || !phi_f || !lim_f || !vf || !gx || !gy || !gz) return FFM_ERR_ARG;
+    if (accumulateMin) LAUNCH_CELLS(k_limited_weights<2>, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], lim_f);
+    else LAUNCH_CELLS(k_limited_weights<1>, mview(m), scheme, 2.0 / std::max(k, 1e-15), lo, hi, phi_f, vf, gx, gy, gz, m->C[0], m->C[1], m->C[2], lim_f);
+    DONE();
+}
+__global__ void k_weights_from_limiter(MeshView q, const double *__restrict__ phi, const double *__restrict__ lim, double *__restrict__ out)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        FOR_OWN_FACES(q, c, e, nb) { (void)nb; const double l = lim[e], p0 = phi[e] >= 0 ? 1.0 : 0.0; out[e] = l * q.w[e] + (1.0 - l) * p0; }
+    }
+}
+// limitedSurfaceInterpolationScheme::weights from a limiter field: limiter*linear + (1 - limiter)*upwind
+extern "C" int ffm_fv_weights_from_limiter(ffm_mesh *m, const double *phi_f, const double *lim_f, double *out_w)
+{
+    CHECK_M(m);
+    if (!phi_f || !lim_f || !out_w) return FFM_ERR_ARG;
+    LAUNCH_CELLS(k_weights_from_limiter, mview(m), phi_f, lim_f, out_w);
     DONE();
 }
 extern "C" int ffm_fv_filtered_linear2V_weights(ffm_mesh *m, double k, double l, const double *phi_f, const double *const *U,

@@ -273,6 +273,13 @@ int ffm_fvc_snGrad_correction(ffm_mesh *m, const double *gx, const double *gy, c
 int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double hi,
                            const double *phi_f, const double *vf, const double *gx,
                            const double *gy, const double *gz, double *out_w_f);
+/* multivariateSelectionScheme (solver/YEEqn.H:1-10 `fv::convectionScheme<scalar>::New(mesh, fields, phi, mesh.divScheme("div(phi,Yi_h)"))`,
+ * cases/steckler/system/fvSchemes:36-47): ONE limiter for all fields of the table, the face-wise minimum of the member schemes' limiters,
+ * and the weights made of it.  ffm_fv_limited_limiter: the limiter of limitedLinear k (scheme 2) / limitedLinear01 k (scheme 3) of one
+ * field into lim_f, or the running minimum when accumulateMin != 0; ffm_fv_weights_from_limiter: limiter*linear + (1 - limiter)*upwind. */
+int ffm_fv_limited_limiter(ffm_mesh *m, int scheme, double k, double lo, double hi, const double *phi_f, const double *vf,
+                           const double *gx, const double *gy, const double *gz, double *lim_f, int accumulateMin);
+int ffm_fv_weights_from_limiter(ffm_mesh *m, const double *phi_f, const double *lim_f, double *out_w);
 
 /* filteredLinear2V k l: the face weights of a VECTOR field, one limiter per face for its three components
  * (`div(phi,U) Gauss filteredLinear2V 0.2 0.05`, cases/wallFireSpread2D/system/fvSchemes:41, cases/pyrolysis1D/system/fvSchemes:39;

