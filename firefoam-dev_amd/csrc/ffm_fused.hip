@@ -97,28 +97,33 @@ struct ScalarEqns {
     const double *Cx, *Cy, *Cz, *bMagSf, *bDelta;
     double rdt, twoByk, lo, hi;
     int scheme;                                                          // 2 limitedLinear, 3 limitedLinear01
+    const double *wGiven;                                                // GIVENW: the face weights (a multivariate scheme's common ones)
 };
 
-template <int W, int NF>
 // Occupancy: the fused four-field kernel is bound by the latency of its neighbour gathers; capped at 128 VGPRs (4 waves per SIMD,
 // 84 bytes of scratch per lane) it takes 17.5 ms at 400^3 instead of 21.9 ms with the 150 VGPRs the compiler picks by itself; 5 / 6
 // waves spill too much (25 / 27 ms), and the one-field kernel is better left alone (7.97 vs 8.35 ms).  Measured r02u.
-__global__ __launch_bounds__(256, (NF > 1 ? 4 : 1)) void k_scalar_eqns(MeshView q, ScalarEqns a)
+// GIVENW: the face weights come from a.wGiven (a multivariateSelection scheme's common weights) instead of one limiter per field: no
+// gradient / neighbour-value gathers at all
+template <int W, int NF, bool GIVENW = false>
+__global__ __launch_bounds__(256, ((NF > 1 && !GIVENW) ? 4 : 1)) void k_scalar_eqns(MeshView q, ScalarEqns a)
 {
     CELL_SCHED(ci, q) {
         const int c = (int)ci;
         RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         // shared face data: flux, linear weight, laplacian coefficient gamma*magSf*delta, distance vector
         double fl[W], fu[W], wl[W], wu[W], gl[W], gu[W], dlx[W], dly[W], dlz[W], dux[W], duy[W], duz[W];
-        const double cx = a.Cx[c], cy = a.Cy[c], cz = a.Cz[c];
+        const double cx = GIVENW ? 0.0 : a.Cx[c], cy = GIVENW ? 0.0 : a.Cy[c], cz = GIVENW ? 0.0 : a.Cz[c];
 #pragma unroll
         for (int s = 0; s < W; s++) {
             const int el = L.f[s], eu = U.f[s];
-            fl[s] = a.phi[el]; fu[s] = a.phi[eu]; wl[s] = q.w[el]; wu[s] = q.w[eu];
+            fl[s] = a.phi[el]; fu[s] = a.phi[eu];
+            wl[s] = GIVENW ? a.wGiven[el] : q.w[el]; wu[s] = GIVENW ? a.wGiven[eu] : q.w[eu];
             gl[s] = a.gamma[el] * q.magSf[el] * q.delta[el]; gu[s] = a.gamma[eu] * q.magSf[eu] * q.delta[eu];
-            // d = C[neighbour] - C[owner]
-            dlx[s] = cx - a.Cx[L.nb[s]]; dly[s] = cy - a.Cy[L.nb[s]]; dlz[s] = cz - a.Cz[L.nb[s]];
-            dux[s] = a.Cx[U.nb[s]] - cx; duy[s] = a.Cy[U.nb[s]] - cy; duz[s] = a.Cz[U.nb[s]] - cz;
+            if (!GIVENW) {      // d = C[neighbour] - C[owner]
+                dlx[s] = cx - a.Cx[L.nb[s]]; dly[s] = cy - a.Cy[L.nb[s]]; dlz[s] = cz - a.Cz[L.nb[s]];
+                dux[s] = a.Cx[U.nb[s]] - cx; duy[s] = a.Cy[U.nb[s]] - cy; duz[s] = a.Cz[U.nb[s]] - cz;
+            } else { dlx[s] = dly[s] = dlz[s] = dux[s] = duy[s] = duz[s] = 0.0; }
         }
         const double V = q.V[c], rhoc = a.rho[c], rho0c = a.rho0[c];
         const int j = q.cellB[c];
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, (NF > 1 ? 4 : 1)) void k_scalar_eqns(MeshView 
 #pragma unroll FFM_SE2_UNROLL
         for (int i = 0; i < NF; i++) {
             const double *__restrict__ vf = a.vf[i], *__restrict__ gx = a.gx[i], *__restrict__ gy = a.gy[i], *__restrict__ gz = a.gz[i];
-            const double P = vf[c], gxc = gx[c], gyc = gy[c], gzc = gz[c];
+            const double P = GIVENW ? 0.0 : vf[c], gxc = GIVENW ? 0.0 : gx[c], gyc = GIVENW ? 0.0 : gy[c], gzc = GIVENW ? 0.0 : gz[c];
             double dDiv = 0.0, dLap = 0.0;
             // faces where c is the neighbour (owner = L.nb[s]): diag -= upper[f]
 #pragma unroll
@@ -136,8 +141,9 @@ __global__ __launch_bounds__(256, (NF > 1 ? 4 : 1)) void k_scalar_eqns(MeshView 
                 const int o = L.nb[s];
                 const double flux = fl[s];
                 const bool upO = flux > 0;                       // upwind cell: the owner when the flux is positive
-                const double w = limited_weight(a.scheme, a.twoByk, a.lo, a.hi, flux, wl[s], vf[o], P, dlx[s], dly[s], dlz[s],
-                                                upO ? gx[o] : gxc, upO ? gy[o] : gyc, upO ? gz[o] : gzc);
+                const double w = GIVENW ? wl[s] : limited_weight(a.scheme, a.twoByk, a.lo, a.hi, flux, wl[s], vf[o], P, dlx[s], dly[s], dlz[s],
+                                                                  upO ? gx[o] : gxc, upO ? gy[o] : gyc, upO ? gz[o] : gzc);
+                (void)o; (void)upO;
                 const double lo = -w * flux;
                 dDiv -= (lo + flux);
                 dLap -= gl[s];
@@ -148,8 +154,9 @@ __global__ __launch_bounds__(256, (NF > 1 ? 4 : 1)) void k_scalar_eqns(MeshView 
                 const int n = U.nb[s];
                 const double flux = fu[s];
                 const bool upO = flux > 0;
-                const double w = limited_weight(a.scheme, a.twoByk, a.lo, a.hi, flux, wu[s], P, vf[n], dux[s], duy[s], duz[s],
-                                                upO ? gxc : gx[n], upO ? gyc : gy[n], upO ? gzc : gz[n]);
+                const double w = GIVENW ? wu[s] : limited_weight(a.scheme, a.twoByk, a.lo, a.hi, flux, wu[s], P, vf[n], dux[s], duy[s], duz[s],
+                                                                  upO ? gxc : gx[n], upO ? gyc : gy[n], upO ? gzc : gz[n]);
+                (void)n; (void)upO;
                 double lo = -w * flux, up = lo + flux;
                 dDiv -= lo;
                 dLap -= gu[s];
@@ -176,6 +183,49 @@ __global__ __launch_bounds__(256, (NF > 1 ? 4 : 1)) void k_scalar_eqns(MeshView 
                 d += ic; sc += bc;
             }
             a.diag[i][c] = d; a.src[i][c] = sc;
+        }
+    }
+}
+
+// multivariateSelectionScheme (solver/YEEqn.H:1-10; cases/steckler/system/fvSchemes:36-47): the weights of ONE limiter for all fields
+// of the table -- the face-wise minimum of limitedLinear(01) limiters of NF fields (k_limited_weights<1/2> of ffm_fv.hip per field and
+// k_weights_from_limiter, in one pass over the owned faces)
+constexpr int MV_MAX = 8;
+struct MvWeights {
+    const double *vf[MV_MAX], *gx[MV_MAX], *gy[MV_MAX], *gz[MV_MAX];
+    int scheme[MV_MAX], nf;
+    const double *phi, *Cx, *Cy, *Cz;
+    double twoByk, lo, hi;
+    double *out;
+};
+__global__ __launch_bounds__(256) void k_mv_weights(MeshView q, MvWeights a)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci;
+        const double cx = a.Cx[c], cy = a.Cy[c], cz = a.Cz[c];
+        FOR_OWN_FACES(q, c, e, nb) {
+            const double flux = a.phi[e], wlin = q.w[e];
+            const double dx = a.Cx[nb] - cx, dy = a.Cy[nb] - cy, dz = a.Cz[nb] - cz;
+            const int up = flux > 0 ? c : nb;
+            const double p0 = flux >= 0 ? 1.0 : 0.0;
+            double lim = 1.0;
+            for (int i = 0; i < a.nf; i++) {
+                // limited_weight() with linear weight 1 and upwind weight 0 returns the limiter itself
+                const double P = a.vf[i][c], Nn = a.vf[i][nb];
+                const double gradf = Nn - P;
+                const double gradcf = dx * a.gx[i][up] + dy * a.gy[i][up] + dz * a.gz[i][up];
+                double r;
+                if (fabs(gradcf) >= 1000.0 * fabs(gradf)) {
+                    const double sa = gradcf >= 0 ? 1.0 : -1.0, sb = gradf >= 0 ? 1.0 : -1.0;
+                    r = 2.0 * 1000.0 * sa * sb - 1.0;
+                } else r = 2.0 * (gradcf / gradf) - 1.0;
+                double l = fmax(fmin(a.twoByk * r, 1.0), 0.0);
+                if (a.scheme[i] == 3) {
+                    if ((flux > 0 && (P < a.lo || Nn > a.hi)) || (flux < 0 && (Nn < a.lo || P > a.hi))) l = 0.0;
+                }
+                lim = i == 0 ? l : fmin(lim, l);
+            }
+            a.out[e] = lim * wlin + (1.0 - lim) * p0;
         }
     }
 }
@@ -276,10 +326,64 @@ extern "C" int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, d
     }
     a.rho = rho; a.rho0 = rho0; a.phi = phi_f; a.phib = phi_b; a.gamma = gamma_f; a.gammab = gamma_b;
     a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.bMagSf = m->bMagSf; a.bDelta = m->bDelta;
-    a.rdt = rDeltaT; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.scheme = scheme;
+    a.rdt = rDeltaT; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.scheme = scheme; a.wGiven = nullptr;
 #define SE(NF) FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_scalar_eqns<W, NF>), mview(m), a))
     switch (nf) { case 1: SE(1); break; case 2: SE(2); break; case 3: SE(3); break; default: SE(4); break; }
 #undef SE
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+// The common weights of a multivariateSelection scheme over nf fields (schemes[i]: 2 limitedLinear, 3 limitedLinear01; one k, one pair
+// of bounds): equal, bit for bit, to ffm_fv_limited_limiter over the fields (running minimum) followed by ffm_fv_weights_from_limiter
+extern "C" int ffm_fv_multivariate_weights(ffm_mesh *m, int nf, const int *schemes, double k, double lo, double hi, const double *phi_f,
+                                           const double *const *vf, const double *const *gx, const double *const *gy, const double *const *gz,
+                                           double *out_w)
+{
+    CHECK_M(m);
+    if (nf < 1 || nf > MV_MAX || !schemes || !phi_f || !vf || !gx || !gy || !gz || !out_w) return FFM_ERR_ARG;
+    MvWeights a;
+    for (int i = 0; i < MV_MAX; i++) {
+        const int q = i < nf ? i : 0;
+        if (i < nf && ((schemes[q] != 2 && schemes[q] != 3) || !vf[q] || !gx[q] || !gy[q] || !gz[q])) return FFM_ERR_ARG;
+        a.vf[i] = vf[q]; a.gx[i] = gx[q]; a.gy[i] = gy[q]; a.gz[i] = gz[q]; a.scheme[i] = schemes[q];
+    }
+    a.nf = nf; a.phi = phi_f; a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.out = out_w;
+    LAUNCH_CELLS(k_mv_weights, mview(m), a);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+// ffm_fvm_scalar_transport_multi with the face weights given (a multivariate scheme's common weights) instead of one limiter per field:
+// ddt(rho, vf_i) + div(phi, vf_i) [weights w_f] - laplacian(gamma, vf_i) == su_i ... for nf fields in one pass
+extern "C" int ffm_fvm_scalar_transport_multi_w(ffm_mesh *m, int nf, const double *w_f, double rDeltaT, const double *rho, const double *rho0,
+                                                const double *phi_f, const double *phi_b, const double *gamma_f, const double *gamma_b,
+                                                const double *const *vf0, const double *const *f, const double *const *ref,
+                                                const double *const *refGrad, const double *const *su, const double *const *su2,
+                                                const double *const *sp, const double *const *expl3, double *const *diag,
+                                                double *const *upper, double *const *lower, double *const *source)
+{
+    CHECK_M(m);
+    if (nf < 1 || nf > FUSE_MAX || !w_f || !rho || !rho0 || !phi_f || !gamma_f || (m->B && (!phi_b || !gamma_b))) return FFM_ERR_ARG;
+    if (!vf0 || !f || !ref || !refGrad || !diag || !upper || !lower || !source) return FFM_ERR_ARG;
+    ScalarEqns a;
+    for (int i = 0; i < FUSE_MAX; i++) {
+        const int q = i < nf ? i : 0;
+        if (i < nf && (!vf0[q] || !diag[q] || !upper[q] || !lower[q] || !source[q] || (m->B && (!f[q] || !ref[q] || !refGrad[q])))) return FFM_ERR_ARG;
+        a.vf[i] = a.gx[i] = a.gy[i] = a.gz[i] = nullptr; a.vf0[i] = vf0[q];
+        a.f[i] = f[q]; a.ref[i] = ref[q]; a.refGrad[i] = refGrad[q];
+        a.su[i] = su ? su[q] : nullptr;
+        a.su2[i] = su2 ? su2[q] : nullptr; a.sp[i] = sp ? sp[q] : nullptr;
+        for (int e = 0; e < 3; e++) a.expl[i][e] = expl3 ? expl3[3 * q + e] : nullptr;
+        if (a.expl[i][0] && (!a.expl[i][1] || !a.expl[i][2])) return FFM_ERR_ARG;
+        a.diag[i] = diag[q]; a.upper[i] = upper[q]; a.lower[i] = lower[q]; a.src[i] = source[q];
+    }
+    a.rho = rho; a.rho0 = rho0; a.phi = phi_f; a.phib = phi_b; a.gamma = gamma_f; a.gammab = gamma_b;
+    a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.bMagSf = m->bMagSf; a.bDelta = m->bDelta;
+    a.rdt = rDeltaT; a.twoByk = 2.0; a.lo = 0.0; a.hi = 1.0; a.scheme = 0; a.wGiven = w_f;
+#define SEW(NF) FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_scalar_eqns<W, NF, true>), mview(m), a))
+    switch (nf) { case 1: SEW(1); break; case 2: SEW(2); break; case 3: SEW(3); break; default: SEW(4); break; }
+#undef SEW
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }

@@ -47,6 +47,15 @@ int ffm_fvm_scalar_transport_multi(ffm_mesh *, int, int, double, double, double,
                                    const double *const *, const double *const *, const double *const *, const double *const *,
                                    const double *const *, const double *const *,
                                    double *const *, double *const *, double *const *, double *const *);
+int ffm_fv_limited_limiter(ffm_mesh *, int, double, double, double, const double *, const double *, const double *, const double *,
+                           const double *, double *, int);
+int ffm_fv_weights_from_limiter(ffm_mesh *, const double *, const double *, double *);
+int ffm_fv_multivariate_weights(ffm_mesh *, int, const int *, double, double, double, const double *, const double *const *,
+                                const double *const *, const double *const *, const double *const *, double *);
+int ffm_fvm_scalar_transport_multi_w(ffm_mesh *, int, const double *, double, const double *, const double *, const double *, const double *,
+                                     const double *, const double *, const double *const *, const double *const *, const double *const *,
+                                     const double *const *, const double *const *, const double *const *, const double *const *,
+                                     const double *const *, double *const *, double *const *, double *const *, double *const *);
 int ffm_fvm_lust_source3(ffm_mesh *, double, const double *, const double *, const double *const *, const double *const *,
                          const double *const *, const double *const *, double *const *);
 }
@@ -92,6 +101,11 @@ struct ffm_plume {
     double *ddtCorrF = nullptr; bool ddtCorrValid = false;      // coeff*rDeltaT*phiCorr of fvc::ddtCorr(rho, U, phi): old-time fields only, the same in both correctors of a step
     // fused assembly (ffm_fused.hip): gradients of up to 4 fields, the matrices of the 4 transported species, their patch values
     double *gM[4][3], *spD[4], *spU[4], *spL[4], *spS[4], *spB[4], *suM[4];
+    // mvConvection of solver/YEEqn.H:1-10 (`Gauss multivariateSelection`): the weights of the ONE limiter all species and h are
+    // convected with -- the minimum of the member schemes' limiters over the five species and h (FFM_PLUME_INDEPENDENT_LIMITERS=1:
+    // one limiter per field, as round 1 had it)
+    bool mvSelection = true;
+    double *wMv = nullptr, *mvG[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     bool fused = true;                     // FFM_PLUME_UNFUSED: one kernel per operator (tests compare the two paths)
     // UEqn kept for pEqn (A, H)
     double *Udiag, *Uupper, *Ulower, *Usrc[3], *Uic[3], *Ubc[3];
@@ -256,14 +270,18 @@ static int hydrostatic_init(ffm_plume *P)
 // transport equation of a scalar: ddt(rho,vf) + div(phi,vf) - laplacian(gamma,vf) == su (+ explicit LHS terms in `expl`)
 static int scalar_transport(ffm_plume *P, const char *name, int scheme, double *vf, const double *vf0, const double *fBC, const double *ref,
                             const double *gamma_f, const double *gamma_b, const double *su, const double *const *expl, double tol,
-                            const double *su2 = nullptr, const double *sp = nullptr)
+                            const double *su2 = nullptr, const double *sp = nullptr, const double *wGiven = nullptr)
 {
     ffm_mesh *m = P->mesh; const int N = P->N;
-    double *vb = P->wB[2], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *w = P->wF[3];
-    FFM_TRY(ffm_bc_values(m, fBC, ref, P->zeroB, vf, vb));
-    FFM_TRY(ffm_fvc_grad(m, vf, vb, gx, gy, gz));
-    FFM_TRY(HX(P, gx)); FFM_TRY(HX(P, gy)); FFM_TRY(HX(P, gz));
-    FFM_TRY(ffm_fv_limited_weights(m, scheme, 1.0, 0.0, 1.0, P->phi, vf, gx, gy, gz, w));
+    double *vb = P->wB[2], *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3];
+    const double *w = wGiven;
+    if (!wGiven) {
+        FFM_TRY(ffm_bc_values(m, fBC, ref, P->zeroB, vf, vb));
+        FFM_TRY(ffm_fvc_grad(m, vf, vb, gx, gy, gz));
+        FFM_TRY(HX(P, gx)); FFM_TRY(HX(P, gy)); FFM_TRY(HX(P, gz));
+        FFM_TRY(ffm_fv_limited_weights(m, scheme, 1.0, 0.0, 1.0, P->phi, vf, gx, gy, gz, P->wF[3]));
+        w = P->wF[3];
+    }
     FFM_TRY(ffm_fvm_transport(m, P->rdt, P->rho, P->phi, w, gamma_f, -1, P->diag, P->upper, P->lower));
     FFM_TRY(ffm_fvm_boundary_coeffs(m, P->phib, gamma_b, -1, fBC, ref, P->zeroB, P->ic[0], P->bc[0]));
     // source = rdt*rho0*vf0*V (- V*expl) ; then + boundaryCoeffs + V*su
@@ -585,6 +603,44 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         const double *rho = P->rho, *fuel = P->Y[2], *o2 = P->Y[0];
         forN(P, N, [=] __device__(long i) { const double w = rho[i] * fmin(fuel[i], o2[i] / S_O2) / TAU; wFuel[i] = w; Qdot[i] = w * HC; Yt[i] = 0.0; });
     }
+    if (P->mvSelection) {
+        // ---- mvConvection: the common limiter over the five species and h, from the fields as they are now
+        int sp4[NSP - 1], n4 = 0;
+        for (int i = 0; i < NSP; i++) if (i != INERT) sp4[n4++] = i;
+        double *Nb = P->wB[1], *hb = P->wB[3];
+        for (int j = 0; j < n4; j++) FFM_TRY(ffm_bc_values(m, P->fS, P->refY[sp4[j]], P->zeroB, P->Y[sp4[j]], P->spB[j]));
+        {   // the inert specie's patch values: Y[inertIndex] == 1 - Yt; .max(0) on the patch faces too
+            const double *b0 = P->spB[0], *b1 = P->spB[1], *b2 = P->spB[2], *b3 = P->spB[3];
+            forN(P, B, [=] __device__(long k) { const double t = ((fmax(b0[k], 0.0) + fmax(b1[k], 0.0)) + fmax(b2[k], 0.0)) + fmax(b3[k], 0.0); Nb[k] = fmax(1.0 - t, 0.0); });
+        }
+        FFM_TRY(ffm_bc_values(m, P->fH, P->refH, P->zeroB, P->hs, hb));
+        if (P->fused) {
+            const double *vf[6], *vb[4], *cgx[6], *cgy[6], *cgz[6]; double *ggx[4], *ggy[4], *ggz[4]; int sch[6];
+            // h first, then the transported species, then the inert one (the minimum does not depend on the order)
+            const double *vf2[2] = {P->hs, P->Y[INERT]}, *vb2[2] = {hb, Nb};
+            double *g2x[2] = {P->mvG[0][0], P->mvG[1][0]}, *g2y[2] = {P->mvG[0][1], P->mvG[1][1]}, *g2z[2] = {P->mvG[0][2], P->mvG[1][2]};
+            FFM_TRY(ffm_fvc_grad_multi(m, 2, vf2, vb2, g2x, g2y, g2z));
+            for (int j = 0; j < n4; j++) { vf[j] = P->Y[sp4[j]]; vb[j] = P->spB[j]; ggx[j] = P->gM[j][0]; ggy[j] = P->gM[j][1]; ggz[j] = P->gM[j][2]; }
+            FFM_TRY(ffm_fvc_grad_multi(m, n4, vf, vb, ggx, ggy, ggz));
+            for (int j = 0; j < 2; j++) { FFM_TRY(HX(P, g2x[j])); FFM_TRY(HX(P, g2y[j])); FFM_TRY(HX(P, g2z[j])); }
+            for (int j = 0; j < n4; j++) { FFM_TRY(HX(P, ggx[j])); FFM_TRY(HX(P, ggy[j])); FFM_TRY(HX(P, ggz[j])); }
+            const double *af6[6] = {P->hs, P->Y[sp4[0]], P->Y[sp4[1]], P->Y[sp4[2]], P->Y[sp4[3]], P->Y[INERT]};
+            for (int j = 0; j < 6; j++) { vf[j] = af6[j]; sch[j] = j == 0 ? 2 : 3; }
+            cgx[0] = g2x[0]; cgy[0] = g2y[0]; cgz[0] = g2z[0]; cgx[5] = g2x[1]; cgy[5] = g2y[1]; cgz[5] = g2z[1];
+            for (int j = 0; j < n4; j++) { cgx[1 + j] = ggx[j]; cgy[1 + j] = ggy[j]; cgz[1 + j] = ggz[j]; }
+            FFM_TRY(ffm_fv_multivariate_weights(m, 6, sch, 1.0, 0.0, 1.0, P->phi, vf, cgx, cgy, cgz, P->wMv));
+        } else {
+            double *gx = P->wN[1], *gy = P->wN[2], *gz = P->wN[3], *lim = P->wF[1];
+            const double *fld[6] = {P->hs, P->Y[sp4[0]], P->Y[sp4[1]], P->Y[sp4[2]], P->Y[sp4[3]], P->Y[INERT]};
+            const double *fb[6] = {hb, P->spB[0], P->spB[1], P->spB[2], P->spB[3], Nb};
+            for (int j = 0; j < 6; j++) {
+                FFM_TRY(ffm_fvc_grad(m, fld[j], fb[j], gx, gy, gz));
+                FFM_TRY(HX(P, gx)); FFM_TRY(HX(P, gy)); FFM_TRY(HX(P, gz));
+                FFM_TRY(ffm_fv_limited_limiter(m, j == 0 ? 2 : 3, 1.0, 0.0, 1.0, P->phi, fld[j], gx, gy, gz, lim, j == 0 ? 0 : 1));
+            }
+            FFM_TRY(ffm_fv_weights_from_limiter(m, P->phi, lim, P->wMv));
+        }
+    }
     if (P->fused) {
         // the four transported species share phi, rho and dEff: boundary values, gradients and matrices of all four in one
         // pass each, then the solves in the reference's order (nothing a later equation reads changes in an earlier solve)
@@ -595,14 +651,19 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         for (int j = 0; j < ns; j++) {
             const int i = sp[j]; const double nu = NU[i]; double *sj = P->suM[j];
             forN(P, N, [=] __device__(long c) { sj[c] = nu * wFuel[c]; });
-            FFM_TRY(ffm_bc_values(m, P->fS, P->refY[i], P->zeroB, P->Y[i], P->spB[j]));
+            if (!P->mvSelection) FFM_TRY(ffm_bc_values(m, P->fS, P->refY[i], P->zeroB, P->Y[i], P->spB[j]));
             vf[j] = P->Y[i]; vb[j] = P->spB[j]; vf0[j] = P->Y0[i]; fq[j] = P->fS; rq[j] = P->refY[i]; gq[j] = P->zeroB; suq[j] = sj;
             ggx[j] = P->gM[j][0]; ggy[j] = P->gM[j][1]; ggz[j] = P->gM[j][2]; cgx[j] = ggx[j]; cgy[j] = ggy[j]; cgz[j] = ggz[j];
         }
+        if (P->mvSelection)
+            FFM_TRY(ffm_fvm_scalar_transport_multi_w(m, ns, P->wMv, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf0, fq, rq, gq, suq, nullptr, nullptr,
+                                                     nullptr, P->spD, P->spU, P->spL, P->spS));
+        else {
         FFM_TRY(ffm_fvc_grad_multi(m, ns, vf, vb, ggx, ggy, ggz));
         for (int j = 0; j < ns; j++) { FFM_TRY(HX(P, ggx[j])); FFM_TRY(HX(P, ggy[j])); FFM_TRY(HX(P, ggz[j])); }
         FFM_TRY(ffm_fvm_scalar_transport_multi(m, ns, 3, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
                                                fq, rq, gq, suq, nullptr, nullptr, nullptr, P->spD, P->spU, P->spL, P->spS));
+        }
         for (int j = 0; j < ns; j++) {
             const int i = sp[j];
             FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[j], P->spL[j], P->Y[i], P->spS[j]));
@@ -615,7 +676,7 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         if (i == INERT) continue;
         const double nu = NU[i];
         forN(P, N, [=] __device__(long c) { su[c] = nu * wFuel[c]; });
-        FFM_TRY(scalar_transport(P, SPN[i], 3, P->Y[i], P->Y0[i], P->fS, P->refY[i], af, afb, su, nullptr, 1e-8));
+        FFM_TRY(scalar_transport(P, SPN[i], 3, P->Y[i], P->Y0[i], P->fS, P->refY[i], af, afb, su, nullptr, 1e-8, nullptr, nullptr, P->mvSelection ? P->wMv : nullptr));
         double *Yi = P->Y[i];
         forN(P, N, [=] __device__(long c) { const double v = fmax(Yi[c], 0.0); Yi[c] = v; Yt[c] += v; });
     }
@@ -663,15 +724,20 @@ extern "C" int ffm_plume_step(ffm_plume *P)
             double *ggx[1] = {P->gM[0][0]}, *ggy[1] = {P->gM[0][1]}, *ggz[1] = {P->gM[0][2]};
             const double *cgx[1] = {ggx[0]}, *cgy[1] = {ggy[0]}, *cgz[1] = {ggz[0]}, *su2q[1] = {shSu}, *spq[1] = {shSp};
             double *dd[1] = {P->dWork}, *uu[1] = {P->upper}, *ll[1] = {P->lower}, *ss[1] = {P->sWork};
+            if (P->mvSelection)
+                FFM_TRY(ffm_fvm_scalar_transport_multi_w(m, 1, P->wMv, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf0, fq, rq, gq, suq, su2q, spq, expl,
+                                                         dd, uu, ll, ss));
+            else {
             FFM_TRY(ffm_bc_values(m, P->fH, P->refH, P->zeroB, P->hs, P->spB[0]));
             FFM_TRY(ffm_fvc_grad_multi(m, 1, vf, vb, ggx, ggy, ggz));
             FFM_TRY(HX(P, ggx[0])); FFM_TRY(HX(P, ggy[0])); FFM_TRY(HX(P, ggz[0]));
             FFM_TRY(ffm_fvm_scalar_transport_multi(m, 1, 2, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
                                                    fq, rq, gq, suq, su2q, spq, expl, dd, uu, ll, ss));
+            }
             FFM_TRY(solve_named(P, "h", FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->dWork, P->upper, P->lower, P->hs, P->sWork));
             FFM_TRY(HX(P, P->hs));
         } else
-        FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8, shSu, shSp));
+        FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8, shSu, shSp, P->mvSelection ? P->wMv : nullptr));
     }
     standin_thermo(P);
     { const char *st = getenv("FFM_PLUME_STOP"); if (st && atoi(st) == 2) { PL_HIP(hipStreamSynchronize(P->ctx->stream)); return FFM_OK; } }
@@ -872,10 +938,12 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     P->ddtCorrF = dalloc(P, nNat);
     for (auto &w : P->wB) w = dalloc(P, B);
     P->fused = getenv("FFM_PLUME_UNFUSED") == nullptr;
+    P->mvSelection = getenv("FFM_PLUME_INDEPENDENT_LIMITERS") == nullptr;
+    if (P->mvSelection) { P->wMv = dalloc(P, nNat); if (P->fused) for (int j = 0; j < 2; j++) for (int d = 0; d < 3; d++) P->mvG[j][d] = NN(); }
     for (int j = 0; j < 4; j++) {
         for (int d = 0; d < 3; d++) P->gM[j][d] = P->fused ? NN() : nullptr;
         P->spD[j] = P->fused ? NN() : nullptr; P->spS[j] = P->fused ? NN() : nullptr; P->suM[j] = P->fused ? NN() : nullptr;
-        P->spU[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spL[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spB[j] = P->fused ? dalloc(P, B) : nullptr;
+        P->spU[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spL[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spB[j] = (P->fused || P->mvSelection) ? dalloc(P, B) : nullptr;
     }
     for (double *p : P->pool) if (!p) { ffm_set_error("plume: out of device memory"); return FFM_ERR_HIP; }
     PL_HIP(hipDeviceSynchronize());

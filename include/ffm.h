@@ -280,6 +280,11 @@ int ffm_fv_limited_weights(ffm_mesh *m, int scheme, double k, double lo, double 
 int ffm_fv_limited_limiter(ffm_mesh *m, int scheme, double k, double lo, double hi, const double *phi_f, const double *vf,
                            const double *gx, const double *gy, const double *gz, double *lim_f, int accumulateMin);
 int ffm_fv_weights_from_limiter(ffm_mesh *m, const double *phi_f, const double *lim_f, double *out_w);
+/* the same in one pass: the common weights over nf fields (schemes[i]: 2 limitedLinear, 3 limitedLinear01), bitwise equal to the
+ * running-minimum chain above */
+int ffm_fv_multivariate_weights(ffm_mesh *m, int nf, const int *schemes, double k, double lo, double hi, const double *phi_f,
+                                const double *const *vf, const double *const *gx, const double *const *gy, const double *const *gz,
+                                double *out_w);
 
 /* filteredLinear2V k l: the face weights of a VECTOR field, one limiter per face for its three components
  * (`div(phi,U) Gauss filteredLinear2V 0.2 0.05`, cases/wallFireSpread2D/system/fvSchemes:41, cases/pyrolysis1D/system/fvSchemes:39;
@@ -370,6 +375,14 @@ int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, double k, do
                                    const double *const *su2, const double *const *sp,
                                    const double *const *expl3, double *const *diag, double *const *upper,
                                    double *const *lower, double *const *source);
+/* the same pass with the face weights given (a multivariateSelection scheme's common weights: ffm_fv_multivariate_weights) instead of
+ * one limiter per field -- what mvConvection->fvmDiv(phi, Yi) of solver/YEEqn.H:44 assembles */
+int ffm_fvm_scalar_transport_multi_w(ffm_mesh *m, int nf, const double *w_f, double rDeltaT, const double *rho, const double *rho0,
+                                     const double *phi_f, const double *phi_b, const double *gamma_f, const double *gamma_b,
+                                     const double *const *vf0, const double *const *f, const double *const *ref,
+                                     const double *const *refGrad, const double *const *su, const double *const *su2,
+                                     const double *const *sp, const double *const *expl3, double *const *diag,
+                                     double *const *upper, double *const *lower, double *const *source);
 /* momentum source of solver/UEqn.H:5 with `div(phi,U) Gauss LUST grad(U)`: source_c = rDeltaT*rho0*U0_c*V
  * - V*fvc::surfaceIntegrate(phi*LUST::correction(U_c)) for the three components from their gradients                  */
 int ffm_fvm_lust_source3(ffm_mesh *m, double rDeltaT, const double *phi_f, const double *rho0, const double *const *U0,

@@ -104,6 +104,90 @@ def test_scalar_transport_multi_equals_the_operator_chain(setup, O, ctx, nf, sch
         assert np.array_equal(S[i].cpu().numpy(), sO.cpu().numpy()), i
 
 
+@pytest.mark.parametrize("nf", [2, 6])
+def test_multivariate_weights_equal_the_running_minimum_chain(setup, O, ctx, nf):
+    """multivariateSelectionScheme: the weights of ONE limiter, the minimum over the fields' own limitedLinear / limitedLinear01
+    limiters.  The one-pass kernel (ffm_fv_multivariate_weights, the compiled time step) = ffm_fv_limited_limiter over the fields
+    (running minimum) + ffm_fv_weights_from_limiter (what the Foam layer's convectionScheme calls), bit for bit; and the minimum of the
+    fields' own weights can be recovered from it where the limiter is 0 or 1."""
+    import ctypes as C
+    s, mesh = setup, setup["mesh"]
+    N = s["N"]
+    vf, vb, phi = _fields(s, O, ctx, nf)
+    vf = [v * 1.1 - 0.2 if i % 2 else v for i, v in enumerate(vf)]           # limitedLinear01 fields with values outside [0, 1]
+    sch = [2 if i == 0 else 3 for i in range(nf)]
+    g = [[ctx.zeros(N) for _ in range(3)] for _ in range(nf)]
+    for i in range(nf):
+        mesh.call("fvc_grad", vf[i], vb[i], *g[i])
+    w1 = ctx.zeros(mesh.nNative)
+    mesh.call("fv_multivariate_weights", nf, (C.c_int * nf)(*sch), 1.0, 0.0, 1.0, phi, vf, [x[0] for x in g], [x[1] for x in g], [x[2] for x in g], w1)
+    lim, w2 = ctx.zeros(mesh.nNative), ctx.zeros(mesh.nNative)
+    for i in range(nf):
+        mesh.call("fv_limited_limiter", sch[i], 1.0, 0.0, 1.0, phi, vf[i], *g[i], lim, 0 if i == 0 else 1)
+    mesh.call("fv_weights_from_limiter", phi, lim, w2)
+    assert np.array_equal(w1.cpu().numpy(), w2.cpu().numpy())
+    # against the per-field weights: limiter_i = (w_i - upwind)/(linear - upwind); the common limiter is their minimum (real faces only:
+    # the native layout has padding entries)
+    fn = mesh.from_native
+    up = (fn(phi) >= 0).astype(float)
+    wl = ctx.zeros(mesh.nNative); mesh.call("fv_limited_weights", 1, 1.0, 0.0, 1.0, phi, None, None, None, None, wl)
+    lims = []
+    for i in range(nf):
+        wi = ctx.zeros(mesh.nNative)
+        mesh.call("fv_limited_weights", sch[i], 1.0, 0.0, 1.0, phi, vf[i], *g[i], wi)
+        lims.append((fn(wi) - up) / (fn(wl) - up))
+    assert np.allclose(np.min(lims, axis=0), fn(lim), rtol=0, atol=1e-12)
+    assert float(np.mean(fn(lim) > 0)) < 0.999 and (nf > 2 or float(np.mean(fn(lim) > 0)) > 0.02)      # (six random fields: the minimum is 0 nearly everywhere)
+
+
+@pytest.mark.parametrize("nf,with_expl", [(4, False), (1, True)])
+def test_scalar_transport_multi_with_given_weights_equals_the_operator_chain(setup, O, ctx, nf, with_expl):
+    """ffm_fvm_scalar_transport_multi_w (mvConvection->fvmDiv with the common weights + ddt + laplacian + sources + boundary terms of nf
+    equations in one pass) against fvm_transport(w) / fvm_boundary_coeffs / fvm_add_boundary per field, bitwise."""
+    s, mesh = setup, setup["mesh"]
+    N, F, B = s["N"], s["F"], s["B"]
+    dev = ctx.to_device
+    _, _, phi = _fields(s, O, ctx, nf)
+    w = mesh.to_native(O.hash_u(41, np.arange(F)))                             # any weights in [0, 1]
+    rho, rho0 = dev(1.0 + O.hash_u(60, np.arange(N))), dev(1.0 + O.hash_u(61, np.arange(N)))
+    vf0 = [dev(O.hash_u(62 + i, np.arange(N))) for i in range(nf)]
+    gam = mesh.to_native(0.01 * (1 + O.hash_u(63, np.arange(F)))); gamb = dev(0.01 * (1 + O.hash_u(64, np.arange(B))))
+    phib = dev(0.2 * (O.hash_u(70, np.arange(B)) - 0.5))
+    f = [dev(np.round(O.hash_u(80 + i, np.arange(B)) * 2) / 2) for i in range(nf)]
+    ref = [dev(O.hash_u(84 + i, np.arange(B))) for i in range(nf)]
+    rg = [dev(O.hash_u(88 + i, np.arange(B)) - 0.5) for i in range(nf)]
+    su = [dev(O.hash_u(90 + i, np.arange(N)) - 0.3) if i % 2 == 0 else None for i in range(nf)]
+    expl = [dev(O.hash_u(95 + e, np.arange(N)) - 0.5) for e in range(3)] if with_expl else None
+    su2 = [dev(O.hash_u(98, np.arange(N)) - 0.2) if (with_expl and i == 0) else None for i in range(nf)]
+    sp = [dev(O.hash_u(99, np.arange(N))) if (with_expl and i == 0) else None for i in range(nf)]
+    rdt = 1000.0
+    D = [ctx.zeros(N) for _ in range(nf)]; S = [ctx.zeros(N) for _ in range(nf)]
+    Up = [ctx.zeros(mesh.nNative) for _ in range(nf)]; Lo = [ctx.zeros(mesh.nNative) for _ in range(nf)]
+    mesh.call("fvm_scalar_transport_multi_w", nf, w, rdt, rho, rho0, phi, phib, gam, gamb, vf0, f, ref, rg, su, su2, sp,
+              (expl + [None] * (3 * (nf - 1))) if with_expl else None, D, Up, Lo, S)
+    V = dev(s["m"].V[s["cOrd"]])
+    for i in range(nf):
+        d, up, lo = ctx.zeros(N), ctx.zeros(mesh.nNative), ctx.zeros(mesh.nNative)
+        mesh.call("fvm_transport", rdt, rho, phi, w, gam, -1, d, up, lo)
+        ic, bc = ctx.zeros(B), ctx.zeros(B)
+        mesh.call("fvm_boundary_coeffs", phib, gamb, -1, f[i], ref[i], rg[i], ic, bc)
+        src = rdt * rho0 * vf0[i] * V
+        if with_expl and i == 0:
+            src = ((src - V * expl[0]) - V * expl[1]) - V * expl[2]
+        if su[i] is not None:
+            src = src + V * su[i]
+        if sp[i] is not None:
+            d = d + V * sp[i]
+        if su2[i] is not None:
+            src = src + V * su2[i]
+        dO, sO = ctx.zeros(N), ctx.zeros(N)
+        mesh.call("fvm_add_boundary", ic, bc, d, src, None, dO, sO)
+        assert np.array_equal(Up[i].cpu().numpy(), up.cpu().numpy()), i
+        assert np.array_equal(Lo[i].cpu().numpy(), lo.cpu().numpy()), i
+        assert np.array_equal(D[i].cpu().numpy(), dO.cpu().numpy()), i
+        assert np.array_equal(S[i].cpu().numpy(), sO.cpu().numpy()), i
+
+
 def test_lust_source3_equals_the_operator_chain(setup, O, ctx):
     s, mesh = setup, setup["mesh"]
     N, B = s["N"], s["B"]
