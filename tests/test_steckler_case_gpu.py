@@ -7,10 +7,12 @@ totalFlowRateAdvectiveDiffusive, mixedEnergy with thermalBaffle1D, prghTotalHydr
 GAMG + DILU, constRadFractionEmission, greyDiffusiveRadiation walls), with OpenFOAM's stored-boundary-value semantics.  Nothing between the solves comes from the oracle: every field stays on the device from the 0/
 files to the end of the step.
 
-Golden data: cases/steckler/original/linux64/log.fireFoam:92-101 (hydrostatic start-up) and :163-226 (first time step; fixture
-tests/golden/steckler_first_step.json).  The device run must give the log's solver lines: names, iteration counts and printed
-residuals -- with the tolerances tests/test_steckler_first_step_cpu.py documents for the oracle, plus 1e-5 on the O2 / C3H8 initial
-residuals (the device's tree sums differ from OpenFOAM's serial gAverage in the 9th digit) -- and its fields must equal the oracle's."""
+Golden data: cases/steckler/original/linux64/log.fireFoam:92-101 (hydrostatic start-up), :163-226 (first time step; fixture
+tests/golden/steckler_first_step.json) and all the other 28 steps (tests/golden/steckler_log_steps.json).  The device run must give the
+log's solver lines: names, iteration counts and printed residuals -- in the first step with the tolerances
+tests/test_steckler_first_step_cpu.py documents for the oracle, plus 1e-5 on the O2 / C3H8 initial residuals (the device's tree sums
+differ from OpenFOAM's serial gAverage in the 9th digit); in the later steps as stated there -- and its fields must equal the oracle's.
+THE DEVICE FOLLOWS THE WHOLE LOG: 29 time steps, from the cold start through ignition to the 1027 K flame."""
 import ctypes as C
 import json
 import os
@@ -237,51 +239,53 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     fb = np.empty(F); fb[fOrd] = out["phi"]; close(fb, c.phi, 1e-6, "phi")
     for i, s in enumerate(sp):
         close(back(out["Y"][i]), c.Y[i], 1e-6, s)
-    # ---- the SECOND time step (log.fireFoam:233-263): flux, velocity and turbulence fields are no longer zero.  The Courant numbers the
-    # log prints in front of it come from the device's phi and rho (compressibleCourantNo.H); deltaT is the oracle's (its sequence
-    # is asserted on the log by tests/test_steckler_first_step_cpu.py); the three momentum solves -- LUST with a non-zero flux --
-    # give the log's digits; species / enthalpy / pressure / k follow the oracle's second step (itself within 3-5 digits of the log;
-    # the species' limiter works on fields that are uniform up to round-off, where device and oracle need not pick the same weights
-    # on the faces with negligible flux: their iteration counts are not asserted)
-    g2 = GOLD["second_step"]
-    co = np.zeros(2)
-    lib.firefoam_steckler_courant(S, co.ctypes.data_as(dp))
-    assert sig(co[0], 5) == sig(g2["courantMean"], 5) and sig(co[1], 5) == sig(g2["courantMax"], 5), co
+    # ---- ALL THE OTHER 28 TIME STEPS OF THE LOG (log.fireFoam:233-1243: t = 0.16 ... 2 s; the burner's fuel enters in the third step,
+    # ignites in the fourth, the flame reaches 1027 K): flux, velocity and turbulence fields are no longer zero.  The Courant numbers the log prints in front of every
+    # step come from the device's phi and rho (compressibleCourantNo.H); deltaT is the oracle's (its sequence is asserted on the log by
+    # tests/test_steckler_whole_log_cpu.py).  Against the LOG: the solver lines in order, the iteration counts (identical for U, h, k;
+    # p_rgh within one iteration; the species within one sweep: their limiter works on fields that are uniform up to round-off, where
+    # device and oracle need not pick the same weights on faces with negligible flux), every initial residual within 2e-3, min/max(T).
+    # Against the ORACLE (which follows the log to 3-5 digits): the fields at the end of every step.
+    LOGSTEPS = json.load(open(os.path.join(HERE, "golden", "steckler_log_steps.json")))["steps"]
     c.time = c.dt
-    c.advance()
-    assert sig(c.dt, 5) == sig(g2["deltaT"], 5)
-    lib.firefoam_steckler_set_delta_t(S, c.dt)
-    os.environ.pop("FFM_FOAM_QUIET", None)
-    try:
-        capfd.readouterr()
-        n2 = lib.firefoam_steckler_advance(S, C.byref(cs), 1)
-        text2 = capfd.readouterr().out
-    finally:
-        os.environ["FFM_FOAM_QUIET"] = "1"
-    got2 = [(nm.raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), nit[i], res[2 * i], res[2 * i + 1]) for i in range(n2)]
-    assert [g_[0] for g_ in got2] == [s_["name"] for s_ in g2["solves"]], got2                # no ray solves in this step: solverFreq 100
-    gold2 = {s_["name"]: s_ for s_ in g2["solves"] if s_["name"] not in ("p_rgh", "rho")}
-    for name, it, r0, r1 in got2:
-        if name in ("Ux", "Uy", "Uz"):
-            assert it == gold2[name]["nIterations"] == 2 and sig(r0, 5) == sig(gold2[name]["initialResidual"], 5), (name, it, r0, r1)
-            assert abs(r1 - gold2[name]["finalResidual"]) <= 1e-4 * gold2[name]["finalResidual"], (name, r1)
-        elif name in ("O2", "H2O", "CO2"):
-            assert abs(r0 - gold2[name]["initialResidual"]) < 1e-4, (name, r0)
-        elif name == "C3H8":                 # the fuel's patch coefficients lag one step (fvPatchField::updated(), eddyDissipationEDC::Qdot)
-            assert abs(r0 - gold2[name]["initialResidual"]) < 2e-3, (name, r0)
-        elif name == "h":
-            assert it == 2 and abs(r0 - gold2[name]["initialResidual"]) < 1e-3 * gold2[name]["initialResidual"], (name, it, r0)
-        elif name == "k":
-            assert it == 3 and abs(r0 - gold2[name]["initialResidual"]) < 1e-3 * gold2[name]["initialResidual"], (name, it, r0)
-    pr2 = [g_ for g_ in got2 if g_[0] == "p_rgh"]; gp2 = [s_ for s_ in g2["solves"] if s_["name"] == "p_rgh"]
-    for (name, it, r0, r1), s_ in zip(pr2, gp2):
-        assert abs(it - s_["nIterations"]) <= 1 and abs(r0 - s_["initialResidual"]) < 2e-3 * s_["initialResidual"], (it, r0, s_)
-    assert "Radiant Fraction is 0.36" in text2 and "min/max(T) = 298.15, 300.99" in text2
-    assert np.max(out["Y"][iFuel]) < 1e-11                                       # the burner's fuel has not entered yet (log: 7.6712e-13)
-    assert np.abs(back(out["T"]) - c.T).max() < 1e-5            # [K]; thermo::T's Newton iteration stops at |dT| <= 1e-4 T
-    close(back(out["p_rgh"]), c.p_rgh, 1e-4, "p_rgh2"); close(back(out["k"]), c.k, 1e-4, "k2")
-    for d in range(3):
-        close(back(out["U"][d]), c.U[:, d], 1e-4, "U2%d" % d)
-    close(back(out["Y"][iO2]), c.Y[iO2], 1e-3, "O2 2")
+    for k in range(1, int(os.environ.get("FFM_STECKLER_STEPS", "29"))):
+        g2 = LOGSTEPS[k]
+        co = np.zeros(2)
+        lib.firefoam_steckler_courant(S, co.ctypes.data_as(dp))
+        tolCo = 5e-5 if k < 12 else 6e-4                     # 5 digits for the first dozen steps, 4 later (as the oracle: tests/test_steckler_whole_log_cpu.py)
+        assert abs(co[0] - g2["courantMean"]) <= tolCo * g2["courantMean"] and abs(co[1] - g2["courantMax"]) <= tolCo * g2["courantMax"], (k + 1, co, g2["courantMean"], g2["courantMax"])
+        c.advance()
+        assert sig(c.dt, 5) == sig(g2["deltaT"], 5)
+        lib.firefoam_steckler_set_delta_t(S, c.dt)
+        os.environ.pop("FFM_FOAM_QUIET", None)
+        try:
+            capfd.readouterr()
+            n2 = lib.firefoam_steckler_advance(S, C.byref(cs), 1)
+            text2 = capfd.readouterr().out
+        finally:
+            os.environ["FFM_FOAM_QUIET"] = "1"
+        got2 = [(nm.raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), nit[i], res[2 * i], res[2 * i + 1]) for i in range(n2)]
+        assert [g_[0] for g_ in got2] == [s_["name"] for s_ in g2["solves"]], (k + 1, got2)          # no ray solves in these steps: solverFreq 100
+        for (name, it, r0, r1), s_ in zip(got2, g2["solves"]):
+            if name in ("Ux", "Uy", "Uz", "h", "k", "rho"):
+                assert it == s_["nIterations"], (k + 1, name, it, s_)
+            else:
+                assert abs(it - s_["nIterations"]) <= 1, (k + 1, name, it, s_)
+            if s_["initialResidual"] > 0:
+                assert abs(r0 - s_["initialResidual"]) <= 2e-3 * s_["initialResidual"], (k + 1, name, r0, s_)
+            if name in ("Ux", "Uy", "Uz") and k == 1:         # second step: the log's digits (LUST with a non-zero flux)
+                assert sig(r0, 5) == sig(s_["initialResidual"], 5) and abs(r1 - s_["finalResidual"]) <= 1e-4 * s_["finalResidual"], (name, r0, r1)
+        assert "Radiant Fraction is %s" % sig(g2["radiantFraction"], 5) in text2
+        assert "min/max(T) = %s, " % sig(g2["minmaxT"][0], 5) in text2
+        Tmax = float(re.search(r"min/max\(T\) = \S+, (\S+)", text2).group(1))
+        assert abs(Tmax - g2["minmaxT"][1]) <= 3e-4 * g2["minmaxT"][1], (k + 1, Tmax, g2["minmaxT"])
+        if k == 1:
+            assert np.max(out["Y"][iFuel]) < 1e-11                                   # the burner's fuel has not entered yet (log: 7.6712e-13)
+        assert np.abs(back(out["T"]) - c.T).max() < 1e-3 * max(c.T.max() - 298.15, 1.0)
+        close(back(out["p_rgh"]), c.p_rgh, 1e-3, "p_rgh %d" % (k + 1)); close(back(out["k"]), c.k, 1e-3, "k %d" % (k + 1))
+        for d in range(3):
+            close(back(out["U"][d]), c.U[:, d], 1e-3, "U%d %d" % (d, k + 1))
+        close(back(out["Y"][iO2]), c.Y[iO2], 1e-3, "O2 %d" % (k + 1))
+    assert np.max(out["Y"][iFuel]) > 0.1 and Tmax > 360.0                          # the fuel has entered and burns
     lib.firefoam_steckler_destroy(S)
     G.close(); mesh.close(); A.close()
