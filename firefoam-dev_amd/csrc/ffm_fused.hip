@@ -198,34 +198,69 @@ struct MvWeights {
     double twoByk, lo, hi;
     double *out;
 };
+// One limiter value of one field: limited_weight() with linear weight 1 and upwind weight 0
+__device__ __forceinline__ double mv_limiter(int scheme, double twoByk, double lo, double hi, double flux, double P, double Nn, double gradcf)
+{
+    const double gradf = Nn - P;
+    double r;
+    if (fabs(gradcf) >= 1000.0 * fabs(gradf)) {
+        const double sa = gradcf >= 0 ? 1.0 : -1.0, sb = gradf >= 0 ? 1.0 : -1.0;
+        r = 2.0 * 1000.0 * sa * sb - 1.0;
+    } else r = 2.0 * (gradcf / gradf) - 1.0;
+    double l = fmax(fmin(twoByk * r, 1.0), 0.0);
+    if (scheme == 3) {
+        if ((flux > 0 && (P < lo || Nn > hi)) || (flux < 0 && (Nn < lo || P > hi))) l = 0.0;
+    }
+    return l;
+}
+// Every face is written by its UPWIND cell (the owner when the flux is positive, else the neighbour): the limiter needs the upwind
+// cell's gradient of every field, which that cell holds itself -- only the other cell's value is gathered (8 B per field and face
+// instead of 32).  P / N keep their owner / neighbour meaning, so the arithmetic is that of the owner-face loop, bit for bit.
+template <int W>
 __global__ __launch_bounds__(256) void k_mv_weights(MeshView q, MvWeights a)
 {
     CELL_SCHED(ci, q) {
         const int c = (int)ci;
+        RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
         const double cx = a.Cx[c], cy = a.Cy[c], cz = a.Cz[c];
-        FOR_OWN_FACES(q, c, e, nb) {
-            const double flux = a.phi[e], wlin = q.w[e];
-            const double dx = a.Cx[nb] - cx, dy = a.Cy[nb] - cy, dz = a.Cz[nb] - cz;
-            const int up = flux > 0 ? c : nb;
-            const double p0 = flux >= 0 ? 1.0 : 0.0;
-            double lim = 1.0;
-            for (int i = 0; i < a.nf; i++) {
-                // limited_weight() with linear weight 1 and upwind weight 0 returns the limiter itself
-                const double P = a.vf[i][c], Nn = a.vf[i][nb];
-                const double gradf = Nn - P;
-                const double gradcf = dx * a.gx[i][up] + dy * a.gy[i][up] + dz * a.gz[i][up];
-                double r;
-                if (fabs(gradcf) >= 1000.0 * fabs(gradf)) {
-                    const double sa = gradcf >= 0 ? 1.0 : -1.0, sb = gradf >= 0 ? 1.0 : -1.0;
-                    r = 2.0 * 1000.0 * sa * sb - 1.0;
-                } else r = 2.0 * (gradcf / gradf) - 1.0;
-                double l = fmax(fmin(a.twoByk * r, 1.0), 0.0);
-                if (a.scheme[i] == 3) {
-                    if ((flux > 0 && (P < a.lo || Nn > a.hi)) || (flux < 0 && (Nn < a.lo || P > a.hi))) l = 0.0;
+        double fl[2 * W], lim[2 * W], dx[2 * W], dy[2 * W], dz[2 * W];
+        bool mine[2 * W], ghostUp[W];       // ghostUp: the upwind cell is a ghost cell (a cut face of a decomposed mesh, owned by c): c writes it too
+#pragma unroll
+        for (int s = 0; s < W; s++) {
+            // lower face: owner = L.nb[s], neighbour = c; upwind is c when the flux is not positive.  d = C[neighbour] - C[owner]
+            fl[s] = L.on[s] ? a.phi[L.f[s]] : 0.0; mine[s] = L.on[s] && !(fl[s] > 0);
+            dx[s] = cx - a.Cx[L.nb[s]]; dy[s] = cy - a.Cy[L.nb[s]]; dz[s] = cz - a.Cz[L.nb[s]];
+            // upper face: owner = c, neighbour = U.nb[s]; upwind is c when the flux is positive
+            fl[W + s] = U.on[s] ? a.phi[U.f[s]] : 0.0; mine[W + s] = U.on[s] && fl[W + s] > 0;
+            ghostUp[s] = U.on[s] && !(fl[W + s] > 0) && U.nb[s] >= q.v.N;
+            dx[W + s] = a.Cx[U.nb[s]] - cx; dy[W + s] = a.Cy[U.nb[s]] - cy; dz[W + s] = a.Cz[U.nb[s]] - cz;
+            lim[s] = lim[W + s] = 1.0;
+        }
+#pragma unroll 1
+        for (int i = 0; i < a.nf; i++) {
+            const double *__restrict__ vf = a.vf[i];
+            const double vc = vf[c], gxc = a.gx[i][c], gyc = a.gy[i][c], gzc = a.gz[i][c];
+            const int sch = a.scheme[i];
+#pragma unroll
+            for (int s = 0; s < W; s++) {
+                if (mine[s]) {          // P = owner's value (the other cell), N = c's
+                    const double l = mv_limiter(sch, a.twoByk, a.lo, a.hi, fl[s], vf[L.nb[s]], vc, dx[s] * gxc + dy[s] * gyc + dz[s] * gzc);
+                    lim[s] = i == 0 ? l : fmin(lim[s], l);
                 }
-                lim = i == 0 ? l : fmin(lim, l);
+                if (mine[W + s]) {      // P = c's value, N = the other cell's
+                    const double l = mv_limiter(sch, a.twoByk, a.lo, a.hi, fl[W + s], vc, vf[U.nb[s]], dx[W + s] * gxc + dy[W + s] * gyc + dz[W + s] * gzc);
+                    lim[W + s] = i == 0 ? l : fmin(lim[W + s], l);
+                } else if (ghostUp[s]) {
+                    const int n = U.nb[s];
+                    const double l = mv_limiter(sch, a.twoByk, a.lo, a.hi, fl[W + s], vc, vf[n], dx[W + s] * a.gx[i][n] + dy[W + s] * a.gy[i][n] + dz[W + s] * a.gz[i][n]);
+                    lim[W + s] = i == 0 ? l : fmin(lim[W + s], l);
+                }
             }
-            a.out[e] = lim * wlin + (1.0 - lim) * p0;
+        }
+#pragma unroll
+        for (int s = 0; s < W; s++) {
+            if (mine[s]) { const int e = L.f[s]; const double p0 = fl[s] >= 0 ? 1.0 : 0.0; a.out[e] = lim[s] * q.w[e] + (1.0 - lim[s]) * p0; }
+            if (mine[W + s] || ghostUp[s]) { const int e = U.f[s]; const double p0 = fl[W + s] >= 0 ? 1.0 : 0.0; a.out[e] = lim[W + s] * q.w[e] + (1.0 - lim[W + s]) * p0; }
         }
     }
 }
@@ -349,7 +384,7 @@ extern "C" int ffm_fv_multivariate_weights(ffm_mesh *m, int nf, const int *schem
         a.vf[i] = vf[q]; a.gx[i] = gx[q]; a.gy[i] = gy[q]; a.gz[i] = gz[q]; a.scheme[i] = schemes[q];
     }
     a.nf = nf; a.phi = phi_f; a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.out = out_w;
-    LAUNCH_CELLS(k_mv_weights, mview(m), a);
+    FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_mv_weights<W>, mview(m), a));
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
