@@ -26,12 +26,12 @@ HREF, PREF = 3.0, 101325.0
 SMALL = 1.0e-15
 
 
-def build_mesh():
+def build_mesh(refine=1):
     """steckler.build_mesh() with the floor of the block split as topoSet + createPatch do (cases/steckler/system/
     topoSetDictBurner, topoSetDictCompartment:405-455, createPatchDict): burner = base faces with centre in
     (-0.1524 .. 0.1524)^3, floor = base faces with centre in (-1.4 0 -1.4)-(1.4 2.18 1.4) minus burner; patch order
     top, sides, base, burner, floor, baffle1DWall_master, baffle1DWall_slave"""
-    m = steckler.build_mesh()
+    m = steckler.build_mesh(refine=refine)
     ymin = m._bdefs["ymin"]
     cx, cz = ymin.Cf[:, 0], ymin.Cf[:, 2]
     burner = (np.abs(cx) <= 0.1524) & (np.abs(cz) <= 0.1524)

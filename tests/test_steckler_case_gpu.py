@@ -50,8 +50,8 @@ def sig(x, n):
     return "%.*g" % (n, x)
 
 
-@pytest.mark.parametrize("tiled", [False, True])
-def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, capfd, tiled):
+def _case(ffm, ctx, tiled, refine=1, tileCells=8):
+    """the library, the device mesh and the case data (cases/steckler/0/*, constant/*) of the room refined `refine` times per direction"""
     from oracle import plume, steckler_case as SC, thermo as TH
     so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_steckler.so")
     if not os.path.exists(so):
@@ -66,10 +66,10 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     lib.firefoam_steckler_set_delta_t.argtypes = [C.c_void_p, C.c_double]
 
     # ---- the mesh (blockMesh + topoSet + createBaffles + createPatch of cases/steckler/mesh.sh, as oracle/steckler_case.py builds it)
-    m = SC.build_mesh()
+    m = SC.build_mesh(refine)
     N, F = m.nCells, m.nFaces
     B = sum(p.size for p in m.patches)
-    hint = ffm.tile_hint_from_centres(m.C.T.copy(), tileCells=8) if tiled else None
+    hint = ffm.tile_hint_from_centres(m.C.T.copy(), tileCells=tileCells) if tiled else None
     cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u, groupHint=hint)
     l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
     A = ffm.lduMatrix(ctx, N, l2, u2, groupHint=None if hint is None else hint[cOrd])
@@ -153,6 +153,17 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
         rhoOut=P(out["rho"]), UOut=P(out["U"]), pOut=P(out["p"]), p_rghOut=P(out["p_rgh"]), hOut=P(out["h"]), TOut=P(out["T"]), kOut=P(out["k"]),
         phiOutF=P(out["phi"]), YOut=PP(out["Y"]), nIterOut=nit, resOut=res.ctypes.data_as(dp), namesOut=C.cast(nm, C.c_char_p), logCap=cap,
         contErrOut=cerr.ctypes.data_as(dp))
+    return dict(lib=lib, m=m, N=N, F=F, B=B, cOrd=cOrd, fOrd=fOrd, A=A, mesh=mesh, G=G, cs=cs, out=out, nit=nit, res=res, nm=nm, keep=keep, sp=sp,
+                iO2=iO2, iFuel=iFuel, iN2=iN2, names=names, start=start)
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, capfd, tiled):
+    from oracle import plume, steckler_case as SC, thermo as TH
+    K_ = _case(ffm, ctx, tiled)
+    lib, m, N, F, B, cOrd, fOrd, A, mesh, G, cs, out, nit, res, nm, keep, sp = (K_[k] for k in ("lib", "m", "N", "F", "B", "cOrd", "fOrd", "A", "mesh", "G", "cs",
+                                                                                              "out", "nit", "res", "nm", "keep", "sp"))
+    iO2, iFuel, iN2 = K_["iO2"], K_["iFuel"], K_["iN2"]
     # P() copies non-contiguous / non-float arrays: the output arrays must be the ones the library writes to
     for k_ in ("rho", "U", "p", "p_rgh", "h", "T", "k", "phi"):
         assert any(a is out[k_] for a in keep if isinstance(a, np.ndarray)), k_
@@ -287,5 +298,53 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
             close(back(out["U"][d]), c.U[:, d], 1e-3, "U%d %d" % (d, k + 1))
         close(back(out["Y"][iO2]), c.Y[iO2], 1e-3, "O2 %d" % (k + 1))
     assert np.max(out["Y"][iFuel]) > 0.1 and Tmax > 360.0                          # the fuel has entered and burns
+    lib.firefoam_steckler_destroy(S)
+    G.close(); mesh.close(); A.close()
+
+
+def test_the_case_at_the_size_of_baseline_config_2(O, ffm, ctx, capfd):
+    """BASELINE configs[1]: the steckler room fire at ~0.5 M cells on one MI355X -- the 30 x 15 x 20 mesh refined 4 x 4 x 4 (576 000
+    cells, baffles and doorway in place), start-up and three time steps of the reference's unchanged equation files with the real
+    thermo / LES / EDC / fvDOM handles on the device, tiled sweeps.  No oracle run at this size (minutes of numpy): the checks are
+    what the case must satisfy -- the five hydrostatic solves converge like the coarse ones, the burner delivers 0.03 kg/s
+    (flowRateInletVelocity), the species sum to one, continuity errors stay small, the fields are finite and bounded -- and the
+    wall time per step is printed."""
+    import time
+    K_ = _case(ffm, ctx, True, refine=4, tileCells=16)
+    lib, m, N, cOrd, A, mesh, G, cs, out, nit, res, nm, sp = (K_[k] for k in ("lib", "m", "N", "cOrd", "A", "mesh", "G", "cs", "out", "nit", "res", "nm", "sp"))
+    assert N == 576000 and A.sweep_mode == 2
+    os.environ["FFM_FOAM_QUIET"] = "1"
+    nS = C.c_int()
+    t0 = time.perf_counter()
+    S = lib.firefoam_steckler_create(ctx.h, A.h, mesh.h, C.byref(cs), C.byref(nS))
+    tStart = time.perf_counter() - t0
+    assert nS.value == 5 and nit[0] > 50 and nit[3] <= 2 and nit[4] <= 2, list(nit[:5])      # the hydrostatic state is reached in three solves
+    co = np.zeros(2)
+    dts, times = [1.0 / 15.0], []
+    for k in range(3):
+        lib.firefoam_steckler_set_delta_t(S, dts[-1])
+        t0 = time.perf_counter()
+        n = lib.firefoam_steckler_advance(S, C.byref(cs), 1 if k == 2 else 0)
+        times.append(time.perf_counter() - t0)
+        names = [nm.raw[16 * i:16 * i + 16].split(b"\0")[0].decode() for i in range(n)]
+        assert names[:9] == ["rho", "Ux", "Uy", "Uz", "O2", "H2O", "C3H8", "CO2"] + (["ILambda_0_0"] if k == 0 else ["h"]), names[:10]
+        assert all(nit[i] <= 10 for i, nme in enumerate(names) if nme in ("Ux", "Uy", "Uz", "O2", "H2O", "C3H8", "CO2", "h", "k"))     # maxIter 10
+        assert all(np.isfinite(res[:2 * n]))
+        lib.firefoam_steckler_courant(S, co.ctypes.data_as(dp))
+        assert 0 < co[1] < 5.0
+        dts.append(min(dts[-1] * min(0.9 / (co[1] + 1e-15), 1.2), 0.1))          # solver/setMultiRegionDeltaT.H: maxCo 0.9, maxDeltaT 0.1
+    back = lambda a: (lambda r: (r.__setitem__(cOrd, a), r)[1])(np.empty(N))
+    Y = np.stack([back(y) for y in out["Y"]])
+    assert np.abs(Y.sum(axis=0) - 1.0).max() < 1e-12 and Y.min() >= 0.0
+    T = back(out["T"])
+    assert 298.0 < T.min() and T.max() < 320.0
+    rho = back(out["rho"]); assert 1.0 < rho.min() and rho.max() < 1.9          # the propane-rich cells above the burner are heavier than air
+    U = np.stack([back(u) for u in out["U"]], axis=1)
+    assert np.isfinite(U).all() and 0.0 < np.abs(U).max() < 5.0
+    # the burner's cells carry an upward flow that delivers the prescribed mass flow: 0.03 kg/s over 0.3048 m x 0.3048 m
+    q = K_["names"].index("burner"); pb = m.patches[q]
+    assert abs(pb.magSf.sum() - 0.3048 ** 2) < 0.05 * 0.3048 ** 2              # the faces whose centres lie inside the burner square
+    assert U[pb.faceCells, 1].mean() > 0.0
+    print("\nconfig 2 size (576 000 cells): start-up %.2f s, time steps %s ms" % (tStart, ["%.0f" % (1e3 * t) for t in times]))
     lib.firefoam_steckler_destroy(S)
     G.close(); mesh.close(); A.close()
