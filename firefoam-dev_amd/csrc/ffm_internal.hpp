@@ -132,6 +132,9 @@ struct ffm_ldu {
     int *upNbr = nullptr;                        // [upTotal]
     int *loEnt = nullptr;                        // [loTotal]
     int *bwdOrder = nullptr;                     // [N] (only when !bwdContig)
+    int *smallFwdStart = nullptr;                // [nLevels+1] device copy of h_fwdLevelStart (single-workgroup sweeps, ffm_solve.hip)
+    int *smallBwdRange = nullptr;                // [2*nBwdLevels] {p0, p1} of every backward level
+    int smallState = 0;                          // 0 not decided, 1 usable, -1 not (too large / switched off)
     int *cellPerm = nullptr;                     // [N] new->old (only when !identity)
     int *faceSrc = nullptr;                      // [upTotal] native face -> caller face id (-1 padding)
     std::vector<int> h_callerToNative;           // [F] caller face id -> native face index

@@ -349,6 +349,134 @@ __global__ void k_gs_bwd_level(int p0, int p1, const int *__restrict__ order, Ld
     psi[c] = val / diag[c];
 }
 
+// ------------------------------------------------- single-workgroup sweeps ---
+// Small matrices (the coarse levels of a GAMG hierarchy, small unstructured meshes): one launch per dependency level costs ~3.6 us
+// each and these have hundreds of levels with a handful of cells.  Here ONE workgroup of 1024 threads walks all levels of a sweep
+// (and of the sweep pair of a preconditioner application / symGaussSeidel), one workgroup barrier per level.  Values written in an
+// earlier level are read with agent-scope loads (they bypass the CU's L1, where a line fetched for a neighbouring cell may hold the
+// old value); the barrier's release waits for the stores.  Per-cell arithmetic is that of the level kernels above, bit for bit.
+constexpr int SMALL_T = 1024;
+__device__ __forceinline__ double s_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+enum { SM_RD = 0, SM_PRECOND = 1, SM_GS = 2, SM_SYMGS = 3 };
+struct SmallArgs {
+    LduView v;
+    int nLevels, nBwd, N;
+    const int *fwdStart, *bwdRange, *order;
+    const double *upper, *lower, *diag, *cf, *cb, *r, *bP;
+    double *rD, *w, *bSave, *psi;
+};
+template <int MODE, int W>
+__global__ __launch_bounds__(SMALL_T) void k_small_sweep(SmallArgs a)
+{
+    const int tid = threadIdx.x;
+    // ---- forward levels
+    for (int Lv = 0; Lv < a.nLevels; Lv++) {
+        const int c0 = a.fwdStart[Lv], c1 = a.fwdStart[Lv + 1];
+        for (int c = c0 + tid; c < c1; c += SMALL_T) {
+            if (MODE == SM_RD) {
+                RowEnt<W> L; load_lower<W>(a.v, c, L);
+                double au[W], al[W], rn[W];
+#pragma unroll
+                for (int s = 0; s < W; s++) { au[s] = a.upper[L.f[s]]; al[s] = a.lower[L.f[s]]; rn[s] = L.on[s] ? s_ld(&a.rD[L.nb[s]]) : 1.0; }
+                double d = a.diag[c];
+#pragma unroll
+                for (int s = 0; s < W; s++) if (L.on[s]) d -= au[s] * al[s] / rn[s];
+                a.rD[c] = d;
+            } else if (MODE == SM_PRECOND) {
+                RowEnt<W> L; load_lower<W>(a.v, c, L);
+                const double rd = a.rD[c], rc = a.r[c];
+                double q[W], wn[W];
+#pragma unroll
+                for (int s = 0; s < W; s++) { q[s] = a.cf[L.f[s]]; wn[s] = L.on[s] ? s_ld(&a.w[L.nb[s]]) : 0.0; }
+                double wc = rd * rc;
+#pragma unroll
+                for (int s = 0; s < W; s++) if (L.on[s]) wc -= rd * q[s] * wn[s];
+                a.w[c] = wc;
+            } else {
+                RowEnt<W> L, U; load_lower<W>(a.v, c, L); load_upper<W>(a.v, c, U);
+                double al[W], au[W], pl[W], pu[W];
+#pragma unroll
+                for (int s = 0; s < W; s++) {
+                    al[s] = a.lower[L.f[s]]; au[s] = a.upper[U.f[s]];
+                    pl[s] = L.on[s] ? s_ld(&a.psi[L.nb[s]]) : 0.0; pu[s] = U.on[s] ? s_ld(&a.psi[U.nb[s]]) : 0.0;
+                }
+                double val = a.bP[c];
+#pragma unroll
+                for (int s = 0; s < W; s++) if (L.on[s]) val -= al[s] * pl[s];
+                a.bSave[c] = val;
+#pragma unroll
+                for (int s = 0; s < W; s++) if (U.on[s]) val -= au[s] * pu[s];
+                a.psi[c] = val / a.diag[c];
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == SM_RD) {            // rD = 1/rD (k_recip)
+        for (int c = tid; c < a.N; c += SMALL_T) a.rD[c] = 1.0 / s_ld(&a.rD[c]);
+        return;
+    }
+    if (MODE == SM_GS) return;
+    // ---- backward levels (preconditioner: level 0 = cells without owned faces, nothing to do there)
+    for (int b = (MODE == SM_PRECOND ? 1 : 0); b < a.nBwd; b++) {
+        const int p0 = a.bwdRange[2 * b], p1 = a.bwdRange[2 * b + 1];
+        for (int p = p0 + tid; p < p1; p += SMALL_T) {
+            const int c = a.order ? a.order[p] : p;
+            if (MODE == SM_PRECOND) {
+                RowEnt<W> U; load_upper<W, true>(a.v, c, U);          // block-Jacobi: ghost neighbours are ignored
+                const double rd = a.rD[c];
+                double wc = s_ld(&a.w[c]);
+                double q[W], wn[W];
+#pragma unroll
+                for (int s = 0; s < W; s++) { q[s] = a.cb[U.f[s]]; wn[s] = U.on[s] ? s_ld(&a.w[U.nb[s]]) : 0.0; }
+#pragma unroll
+                for (int s = W - 1; s >= 0; s--) if (U.on[s]) wc -= rd * q[s] * wn[s];
+                a.w[c] = wc;
+            } else {
+                RowEnt<W> U; load_upper<W>(a.v, c, U);
+                double au[W], pu[W];
+#pragma unroll
+                for (int s = 0; s < W; s++) { au[s] = a.upper[U.f[s]]; pu[s] = U.on[s] ? s_ld(&a.psi[U.nb[s]]) : 0.0; }
+                double val = s_ld(&a.bSave[c]);
+#pragma unroll
+                for (int s = 0; s < W; s++) if (U.on[s]) val -= au[s] * pu[s];
+                a.psi[c] = val / a.diag[c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// usable for this matrix?  (level-scheduled mode, at most FFM_SMALL_SWEEP_CELLS owned cells -- default 131072, 0 switches it off)
+static bool small_usable(ffm_ldu *A)
+{
+    if (A->smallState) return A->smallState > 0;
+    const char *e = getenv("FFM_SMALL_SWEEP_CELLS");            // read per matrix: tests switch between the two paths
+    const long limit = e ? atol(e) : 131072L;
+    A->smallState = -1;
+    if (A->sweepMode == 2 || A->nOwned > limit || A->nLevels < 1) return false;
+    std::vector<int> br(2 * (size_t)std::max(A->nBwdLevels, 1), 0);
+    for (int b = 0; b < A->nBwdLevels; b++) {
+        const int s = A->h_bwdLevelStart[b], e = A->h_bwdLevelStart[b + 1];
+        if (A->bwdContig) { br[2 * b] = A->h_bwdFirstCell[b]; br[2 * b + 1] = A->h_bwdFirstCell[b] + (e - s); }
+        else { br[2 * b] = s; br[2 * b + 1] = e; }
+    }
+    if (hipMalloc((void **)&A->smallFwdStart, sizeof(int) * (A->nLevels + 1)) != hipSuccess) return false;
+    if (hipMalloc((void **)&A->smallBwdRange, sizeof(int) * br.size()) != hipSuccess) return false;
+    if (hipMemcpy(A->smallFwdStart, A->h_fwdLevelStart.data(), sizeof(int) * (A->nLevels + 1), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemcpy(A->smallBwdRange, br.data(), sizeof(int) * br.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+    A->smallState = 1;
+    return true;
+}
+static SmallArgs small_args(ffm_ldu *A)
+{
+    SmallArgs a{};
+    a.v = ffm_view(A); a.nLevels = A->nLevels; a.nBwd = A->nBwdLevels; a.N = A->nOwned;
+    a.fwdStart = A->smallFwdStart; a.bwdRange = A->smallBwdRange; a.order = A->bwdContig ? nullptr : A->bwdOrder;
+    a.upper = A->upper; a.lower = A->lower; a.diag = A->diag; a.rD = A->rD;
+    return a;
+}
+#define SMALL_LAUNCH(MODE, a) FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_small_sweep<MODE, W>), dim3(1), dim3(SMALL_T), 0, A->ctx->stream, a))
+
 // blocks needed to cover cells [c0,c1) when thread 0 of block 0 sits on the slice start of c0
 static inline int level_grid(int c0, int c1) { return ffm_grid(c1 - (c0 & ~63), 256); }
 
@@ -401,6 +529,12 @@ static int calc_rD(ffm_ldu *A)
         FFM_HIP(hipGetLastError());
         return FFM_OK;
     }
+    if (small_usable(A)) {
+        SmallArgs a = small_args(A);
+        SMALL_LAUNCH(SM_RD, a);
+        FFM_HIP(hipGetLastError());
+        return FFM_OK;
+    }
     SweepGraphKey key{SW_RD, {A->lower, A->upper, A->diag, A->rD, nullptr, nullptr}};
     FFM_TRY(run_graphed(A, key, [&]() -> int {
         for (int L = 0; L < A->nLevels; L++) {
@@ -446,6 +580,13 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
     const double *cf = (precond == FFM_DIC) ? A->upper : (transpose ? A->upper : A->lower);
     const double *cb = (precond == FFM_DIC) ? A->upper : (transpose ? A->lower : A->upper);
     if (A->sweepMode == 2) return ffm_tile_precond(A, precond, transpose, r, w);
+    if (small_usable(A)) {
+        SmallArgs a = small_args(A);
+        a.cf = cf; a.cb = cb; a.r = r; a.w = w;
+        SMALL_LAUNCH(SM_PRECOND, a);
+        FFM_HIP(hipGetLastError());
+        return FFM_OK;
+    }
     SweepGraphKey key{SW_PRECOND + 16 * (transpose ? 1 : 0) + 32 * precond, {r, w, cf, cb, A->rD, nullptr}};
     return run_graphed(A, key, [&]() -> int {
         for (int L = 0; L < A->nLevels; L++) {
@@ -487,6 +628,13 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             }
             if (!A->gsProd) FFM_HIP(hipMalloc((void **)&A->gsProd, sizeof(double) * 3 * (size_t)std::max(A->nCells, 1)));
             FFM_TRY(ffm_tile_gs(A, sym, psi, bUse, bSave, A->gsProd));
+            continue;
+        }
+        if (small_usable(A)) {
+            SmallArgs a = small_args(A);
+            a.bP = bUse; a.bSave = bSave; a.psi = psi;
+            if (sym) SMALL_LAUNCH(SM_SYMGS, a); else SMALL_LAUNCH(SM_GS, a);
+            FFM_HIP(hipGetLastError());
             continue;
         }
         SweepGraphKey key{sym ? SW_SYMGS : SW_GS, {psi, bUse, A->lower, A->upper, A->diag, bSave}};

@@ -222,3 +222,41 @@ def test_reductions(O, ctx):
     assert abs(ctx.gSumMag(xd) - np.abs(x).sum()) < 1e-9
     assert ctx.gMin(xd) == x.min() and ctx.gMax(xd) == x.max()
     assert ctx.gSum(xd) == ctx.gSum(xd)      # deterministic (no atomics)
+
+
+@pytest.mark.parametrize("smallLimit", ["0", "1000000"])
+def test_one_launch_per_level_and_single_workgroup_sweeps_agree(O, ffm, ctx, monkeypatch, smallLimit):
+    """Level-scheduled sweeps have two forms: one launch per dependency level (any size) and, for matrices of at most
+    FFM_SMALL_SWEEP_CELLS cells (default 131072: GAMG's coarse levels, small unstructured meshes), ONE workgroup that walks all
+    levels with a barrier per level (csrc/ffm_solve.hip: k_small_sweep).  Both must be the serial face loops bit for bit: DIC and DILU
+    (calcReciprocalD, precondition, transposed), GaussSeidel and symGaussSeidel, on a randomly relabelled DAG mesh (non-contiguous
+    backward levels) and a hex box."""
+    monkeypatch.setenv("FFM_SMALL_SWEEP_CELLS", smallLimit)
+    monkeypatch.setenv("FFM_SWEEP", "levels")
+    H = ffm.hexmesh
+    for name in ("dag", "hex"):
+        if name == "dag":
+            N, l, u = random_dag_mesh(O, 14, seed=5)
+        else:
+            blk = H.HexBlock((13, 11, 9)); N, l, u = blk.nCells, blk.l, blk.u
+        A = ffm.lduMatrix(ctx, N, l, u)
+        assert A.sweep_mode == 0
+        for asym in (0.0, 0.35):
+            diag, up, lo = laplacian_like(O, N, l, u, seed=3, asym=asym, shift=0.05)
+            A.set_coeffs(diag, up, lo)
+            Ao = O.Ldu(N, l, u).set_coeffs(diag, up, lo)
+            r = 2 * O.hash_u(12, np.arange(N)) - 1
+            rd = ctx.to_device(r)
+            if asym == 0.0:
+                rD = Ao.dic_rD()
+                assert np.array_equal(A.reciprocalD("DIC").cpu().numpy(), rD)
+                assert np.array_equal(A.precondition("DIC", rd).cpu().numpy(), Ao.dic_precondition(rD, r))
+            rD = Ao.dilu_rD()
+            assert np.array_equal(A.reciprocalD("DILU").cpu().numpy(), rD)
+            assert np.array_equal(A.precondition("DILU", rd).cpu().numpy(), Ao.dilu_precondition(rD, r))
+            assert np.array_equal(A.precondition("DILU", rd, transpose=True).cpu().numpy(), Ao.dilu_precondition(rD, r, transpose=True))
+            psi0 = O.hash_u(13, np.arange(N)); b = O.hash_u(14, np.arange(N))
+            for sym in (True, False):
+                got = A.smooth(ctx.to_device(psi0), ctx.to_device(b), nSweeps=2, smoother="symGaussSeidel" if sym else "GaussSeidel")
+                assert np.array_equal(got.cpu().numpy(), Ao.gs_smooth(psi0, b, nSweeps=2, sym=sym))
+        A.close()
