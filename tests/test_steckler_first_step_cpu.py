@@ -11,7 +11,8 @@ semantics: oracle/steckler_case.py), reproduces the FIRST TIME STEP of the refer
   smoothSolver h              Initial 1, Final 6.5274e-13, 2 iterations; min/max(T) = 298.15, 300.49              -- every printed digit
   DICPCG p_rgh                0.99822 -> 0.0080322 in 10; 0.0052595 -> 8.7647e-07 in 28                           -- every printed digit
   time step continuity errors 0.00047825 / -0.00013113 and 8.5653e-08 / -4.6658e-09                               -- every printed digit
-  smoothSolver k              Initial 1, 3 iterations; Final 1.8232e-12: the oracle gets 1.935e-12 (6 % off, cause not found) (**)
+  smoothSolver k              Initial 1, 3 iterations; Final 1.8232e-12: the oracle gets 1.935e-12 (6 % off: the residual sum is 9.3e-16 over
+                              9000 rows of 1.4e-05-sized terms, ~60 ulp per row -- the rounding floor of its own evaluation) (**)
 
 (*) the O2 field is 0.23301 almost everywhere and its final residual is 3e-9 of the initial one: it moves by 2e-4 when one
     operand changes in the last bit (pow(V,1/3) instead of cbrt(V) for the LES delta), so it is pinned to 1e-3 only.
