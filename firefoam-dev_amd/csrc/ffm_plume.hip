@@ -394,12 +394,17 @@ static int p_corrector(ffm_plume *P, bool final)
     const double *bSx = ffm_mesh_geom(m, 6), *bSy = ffm_mesh_geom(m, 7), *bSz = ffm_mesh_geom(m, 8);
     const double *Sx = ffm_mesh_geom(m, 9), *Sy = ffm_mesh_geom(m, 10), *Sz = ffm_mesh_geom(m, 11), *wlin = ffm_mesh_geom(m, 3);
     double *rho = P->rho; const double *psi = P->psi; double *p = P->p;
-    mul(P, rho, psi, p, N);                                                        // rho = thermo.rho()
     double *rAU = P->wN[0], *rhorAU = P->wN[1], *HbyA[3] = {P->wN[2], P->wN[3], P->wN[4]};
     FFM_TRY(ffm_fvm_A(m, 3, P->Udiag, P->Uic[0], P->Uic[1], P->Uic[2], rAU));
+    if (P->fused && P->N == P->nOwn) {
+        // rho = thermo.rho(); rAU = 1/A; rhorAU = rho*rAU in one pass (single block: no ghost refresh in between)
+        forN(P, N, [=] __device__(long i) { const double r = psi[i] * p[i], a = 1.0 / rAU[i]; rho[i] = r; rAU[i] = a; rhorAU[i] = r * a; });
+    } else {
+    mul(P, rho, psi, p, N);                                                        // rho = thermo.rho()
     forN(P, P->nOwn, [=] __device__(long i) { rAU[i] = 1.0 / rAU[i]; });
     FFM_TRY(HX(P, rAU));
     forN(P, N, [=] __device__(long i) { rhorAU[i] = rho[i] * rAU[i]; });
+    }
     double *rhorAUf = P->wF[0], *rhorAUfb = P->wB[0];
     FFM_TRY(ffm_fvc_interpolate(m, nullptr, rhorAU, rhorAUf));
     zg(P, rhorAUfb, rhorAU);
@@ -506,6 +511,18 @@ static int p_corrector(ffm_plume *P, bool final)
         FFM_TRY(ffm_fvc_reconstruct(m, t, tb, rx, ry, rz));
         double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2]; const double *h0 = HbyA[0], *h1 = HbyA[1], *h2 = HbyA[2];
         double *K = P->K, *dpdt = P->dpdt; const double *p_rgh = P->p_rgh, *gh = P->gh, *p0 = P->p0;
+        if (P->fused && P->N == P->nOwn) {
+            // U = HbyA + rAU*reconstruct(...), K = 0.5 magSqr(U), p = p_rgh + rho*gh + pRef, dpdt = fvc::ddt(p) in one pass over the cells
+            // (single block; rhoEqn.H, which follows p in solver/pEqn.H:46-48, reads neither)
+            forN(P, N, [=] __device__(long i) {
+                const double a = h0[i] + rAU[i] * rx[i], b = h1[i] + rAU[i] * ry[i], c = h2[i] + rAU[i] * rz[i];
+                U0[i] = a; U1[i] = b; U2[i] = c;
+                K[i] = 0.5 * ((a * a + b * b) + c * c);
+                const double pp = p_rgh[i] + rho[i] * gh[i] + PREF;
+                p[i] = pp; dpdt[i] = rdt * (pp - p0[i]);
+            });
+            FFM_TRY(rho_eqn(P));
+        } else {
         forN(P, P->nOwn, [=] __device__(long i) {
             const double a = h0[i] + rAU[i] * rx[i], b = h1[i] + rAU[i] * ry[i], c = h2[i] + rAU[i] * rz[i];
             U0[i] = a; U1[i] = b; U2[i] = c;
@@ -517,6 +534,7 @@ static int p_corrector(ffm_plume *P, bool final)
             K[i] = 0.5 * ((U0[i] * U0[i] + U1[i] * U1[i]) + U2[i] * U2[i]);
             dpdt[i] = rdt * (p[i] - p0[i]);
         });
+        }
     }
     return FFM_OK;
 }
