@@ -522,6 +522,83 @@ extern "C" int ffm_fvc_flux_rho(ffm_mesh *m, const double *rho, const double *vx
     return FFM_OK;
 }
 
+// ---- three face passes of the pressure corrector (solver/pEqn.H:9-19,43-44), each the fusion of two per-operator passes with their
+// arithmetic (fvc::snGrad's delta*(N - P); fvMatrix::flux's upper*psi_N - lower*psi_P), so that a face field is not written and read back:
+//   ffm_pc_phig      phig = -rhorAUf*ghf*fvc::snGrad(rho)*magSf
+//   ffm_pc_phiHbyA   phiHbyA = (fvc::flux(rho*HbyA) + rhorAUf*ddtCorr) + phig            (k_flux_rho + the two additions)
+//   ffm_pc_flux      fl = p_rghEqn.flux();  phi = phiHbyA + fl;  t = (fl + phig)/rhorAUf   (the argument of fvc::reconstruct)
+// every slot of the cell's slice row, padding included (nb < 0)
+#define PC_ALL_SLOTS(q, c, e, nb)                                                      \
+    const int sl_ = (c) >> 6, lane_ = (c)&63;                                          \
+    const int ub_ = up_base((q).v, sl_), uw_ = up_width((q).v, sl_);                   \
+    for (int s_ = 0, e = ub_ + lane_, nb = 0; s_ < uw_ && ((nb = (q).v.upNbr[e]), true); s_++, e += 64)
+__global__ __launch_bounds__(256) void k_pc_phig(MeshView q, const double *__restrict__ rhorAUf, const double *__restrict__ ghf,
+                                                 const double *__restrict__ rho, double *__restrict__ out)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci; const double P = rho[c];
+        PC_ALL_SLOTS(q, c, e, nb) {
+            if (nb < 0) { out[e] = 0.0; continue; }              // padding entries of the native face layout hold 0
+            const double sg = q.delta[e] * (rho[nb] - P); out[e] = -rhorAUf[e] * ghf[e] * sg * q.magSf[e];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_pc_phiHbyA(MeshView q, const double *__restrict__ rho, const double *__restrict__ vx,
+                                                    const double *__restrict__ vy, const double *__restrict__ vz, const double *__restrict__ rhorAUf,
+                                                    const double *__restrict__ dc, const double *__restrict__ phig, double *__restrict__ out)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci; const double rP = rho[c]; const double Px = rP * vx[c], Py = rP * vy[c], Pz = rP * vz[c];
+        PC_ALL_SLOTS(q, c, e, nb) {
+            if (nb < 0) { out[e] = 0.0; continue; }
+            const double w = q.w[e], rN = rho[nb];
+            const double fl = (w * Px + (1.0 - w) * (rN * vx[nb])) * q.Sfx[e] + (w * Py + (1.0 - w) * (rN * vy[nb])) * q.Sfy[e] + (w * Pz + (1.0 - w) * (rN * vz[nb])) * q.Sfz[e];
+            out[e] = (fl + rhorAUf[e] * dc[e]) + phig[e];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_pc_flux(MeshView q, const double *__restrict__ upper, const double *__restrict__ lower,
+                                                 const double *__restrict__ psi, const double *__restrict__ phiHbyA, const double *__restrict__ phig,
+                                                 const double *__restrict__ rhorAUf, double *__restrict__ fl, double *__restrict__ phi,
+                                                 double *__restrict__ t)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci; const double P = psi[c];
+        PC_ALL_SLOTS(q, c, e, nb) {
+            if (nb < 0) { fl[e] = 0.0; phi[e] = 0.0; t[e] = 0.0; continue; }
+            const double f = upper[e] * psi[nb] - lower[e] * P;
+            fl[e] = f; phi[e] = phiHbyA[e] + f;
+            t[e] = rhorAUf[e] != 0.0 ? (f + phig[e]) / rhorAUf[e] : 0.0;
+        }
+    }
+}
+extern "C" int ffm_pc_phig(ffm_mesh *m, const double *rhorAUf, const double *ghf, const double *rho, double *phig)
+{
+    CHECK_M(m);
+    if (!rhorAUf || !ghf || !rho || !phig) return FFM_ERR_ARG;
+    LAUNCH_CELLS(k_pc_phig, mview(m), rhorAUf, ghf, rho, phig);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+extern "C" int ffm_pc_phiHbyA(ffm_mesh *m, const double *rho, const double *vx, const double *vy, const double *vz, const double *rhorAUf,
+                              const double *ddtCorr, const double *phig, double *phiHbyA)
+{
+    CHECK_M(m);
+    if (!rho || !vx || !vy || !vz || !rhorAUf || !ddtCorr || !phig || !phiHbyA) return FFM_ERR_ARG;
+    LAUNCH_CELLS(k_pc_phiHbyA, mview(m), rho, vx, vy, vz, rhorAUf, ddtCorr, phig, phiHbyA);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+extern "C" int ffm_pc_flux(ffm_mesh *m, const double *upper, const double *lower, const double *psi, const double *phiHbyA, const double *phig,
+                           const double *rhorAUf, double *flux_f, double *phi_f, double *t_f)
+{
+    CHECK_M(m);
+    if (!upper || !lower || !psi || !phiHbyA || !phig || !rhorAUf || !flux_f || !phi_f || !t_f) return FFM_ERR_ARG;
+    LAUNCH_CELLS(k_pc_flux, mview(m), upper, lower, psi, phiHbyA, phig, rhorAUf, flux_f, phi_f, t_f);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
 // p_rghEqn of solver/pEqn.H:28-36 in one pass over the rows:
 //     fvm::ddt(psi, p_rgh) + fvc::ddt(psi, rho)*gh + fvc::ddt(psi)*pRef + fvc::div(phiHbyA) - fvm::laplacian(rhorAUf, p_rgh)
 // i.e. the laplacian coefficients (k_fvm_transport), fvc::div(phiHbyA) (k_face_sum), the three explicit terms (one source

@@ -754,7 +754,7 @@ extern "C" int ffm_fvm_flux(ffm_mesh *m, const double *upper, const double *lowe
                             const double *psi, double *out_f, double *out_b)
 {
     CHECK_M(m);
-    LAUNCH_CELLS(k_matrix_flux, mview(m), upper, lower, psi, out_f);
+    if (out_f) LAUNCH_CELLS(k_matrix_flux, mview(m), upper, lower, psi, out_f);      // (out_f null: the boundary part only)
     if (m->B && out_b) LAUNCH(k_matrix_flux_b, m->B, m->B, m->bCells, ic, bc, psi, out_b);
     DONE();
 }

@@ -47,6 +47,9 @@ int ffm_fvm_scalar_transport_multi(ffm_mesh *, int, int, double, double, double,
                                    const double *const *, const double *const *, const double *const *, const double *const *,
                                    const double *const *, const double *const *,
                                    double *const *, double *const *, double *const *, double *const *);
+int ffm_pc_phig(ffm_mesh *, const double *, const double *, const double *, double *);
+int ffm_pc_phiHbyA(ffm_mesh *, const double *, const double *, const double *, const double *, const double *, const double *, const double *, double *);
+int ffm_pc_flux(ffm_mesh *, const double *, const double *, const double *, const double *, const double *, const double *, double *, double *, double *);
 int ffm_fv_limited_limiter(ffm_mesh *, int, double, double, double, const double *, const double *, const double *, const double *,
                            const double *, double *, int);
 int ffm_fv_weights_from_limiter(ffm_mesh *, const double *, const double *, double *);
@@ -427,12 +430,15 @@ static int p_corrector(ffm_plume *P, bool final)
     zg(P, rhob, rho);
     // phig = -rhorAUf*ghf*snGrad(rho)*magSf
     double *sg = P->wF[1], *phig = P->wF[2];
-    FFM_TRY(ffm_fvc_snGrad(m, rho, sg));
     const double *ghf = P->ghf;
+    if (P->fused) FFM_TRY(ffm_pc_phig(m, rhorAUf, ghf, rho, phig));
+    else {
+    FFM_TRY(ffm_fvc_snGrad(m, rho, sg));
     forN(P, nNat, [=] __device__(long e) { phig[e] = -rhorAUf[e] * ghf[e] * sg[e] * magSf[e]; });
+    }
     // fvc::flux(rho*HbyA): interior by linear interpolation; boundary rho_b*HbyA_b.Sf with constrainHbyA
     double *phiHbyA = P->wF[3], *phiHbyAb = P->wB[5];
-    if (P->fused) FFM_TRY(ffm_fvc_flux_rho(m, rho, HbyA[0], HbyA[1], HbyA[2], phiHbyA));
+    if (P->fused) { /* formed below, together with the ddtCorr and phig terms (ffm_pc_phiHbyA) */ }
     else {
         double *rH[3] = {P->wN[5], P->wN[6], P->wN[7]};
         for (int c = 0; c < 3; c++) mul(P, rH[c], rho, HbyA[c], N);
@@ -466,7 +472,8 @@ static int p_corrector(ffm_plume *P, bool final)
             });
             P->ddtCorrValid = true;
         }
-        forN(P, nNat, [=] __device__(long e) { phiHbyA[e] = (phiHbyA[e] + rhorAUf[e] * dc[e]) + phig[e]; });
+        if (P->fused) FFM_TRY(ffm_pc_phiHbyA(m, rho, HbyA[0], HbyA[1], HbyA[2], rhorAUf, dc, phig, phiHbyA));
+        else forN(P, nNat, [=] __device__(long e) { phiHbyA[e] = (phiHbyA[e] + rhorAUf[e] * dc[e]) + phig[e]; });
         (void)Sx; (void)Sy; (void)Sz; (void)wlin;
     }
     // constrainPressure: gradient on fixedFluxPressure patches
@@ -502,10 +509,14 @@ static int p_corrector(ffm_plume *P, bool final)
     FFM_TRY(HX(P, P->p_rgh));
     // phi = phiHbyA + p_rghEqn.flux(); U = HbyA + rAU*reconstruct((flux + phig)/rhorAUf)
     double *fl = P->wF[4], *flb = P->wB[7];
+    if (P->fused) {
+        FFM_TRY(ffm_fvm_flux(m, P->upper, P->lower, P->ic[0], P->bc[0], P->p_rgh, nullptr, flb));
+        FFM_TRY(ffm_pc_flux(m, P->upper, P->lower, P->p_rgh, phiHbyA, phig, rhorAUf, fl, P->phi, P->wF[5]));
+    } else
     FFM_TRY(ffm_fvm_flux(m, P->upper, P->lower, P->ic[0], P->bc[0], P->p_rgh, fl, flb));
     {
         double *phi = P->phi, *phib = P->phib, *t = P->wF[5], *tb = P->wB[6];
-        forN(P, nNat, [=] __device__(long e) { phi[e] = phiHbyA[e] + fl[e]; t[e] = rhorAUf[e] != 0.0 ? (fl[e] + phig[e]) / rhorAUf[e] : 0.0; });
+        if (!P->fused) forN(P, nNat, [=] __device__(long e) { phi[e] = phiHbyA[e] + fl[e]; t[e] = rhorAUf[e] != 0.0 ? (fl[e] + phig[e]) / rhorAUf[e] : 0.0; });
         forN(P, B, [=] __device__(long k) { phib[k] = phiHbyAb[k] + flb[k]; tb[k] = flb[k] / rhorAUfb[k]; });
         double *rx = P->wN[5], *ry = P->wN[6], *rz = P->wN[7];
         FFM_TRY(ffm_fvc_reconstruct(m, t, tb, rx, ry, rz));

@@ -347,6 +347,14 @@ int ffm_fvm_pressure_eqn(ffm_mesh *m, double rDeltaT, const double *psi, const d
                          const double *rho, const double *rho0, const double *gh, double pRef, const double *gamma_f,
                          const double *phiHbyA_f, const double *phiHbyA_b, const double *internalCoeffs,
                          const double *boundaryCoeffs, double *upper, double *lower, double *diagOut, double *sourceOut);
+/* three face passes of the pressure corrector (solver/pEqn.H:9-19,43-44), each two per-operator passes in one with their arithmetic:
+ * phig = -rhorAUf*ghf*fvc::snGrad(rho)*magSf;  phiHbyA = (fvc::flux(rho*HbyA) + rhorAUf*ddtCorr) + phig;
+ * fl = p_rghEqn.flux(), phi = phiHbyA + fl, t = (fl + phig)/rhorAUf (internal faces, native layout; symmetric matrix: lower = upper) */
+int ffm_pc_phig(ffm_mesh *m, const double *rhorAUf, const double *ghf, const double *rho, double *phig);
+int ffm_pc_phiHbyA(ffm_mesh *m, const double *rho, const double *vx, const double *vy, const double *vz, const double *rhorAUf,
+                   const double *ddtCorr, const double *phig, double *phiHbyA);
+int ffm_pc_flux(ffm_mesh *m, const double *upper, const double *lower, const double *psi, const double *phiHbyA, const double *phig,
+                const double *rhorAUf, double *flux_f, double *phi_f, double *t_f);
 /* fvc::flux(rho*v) on the internal faces (solver/pEqn.H:15 fvc::flux(rho*HbyA); the old-time flux of fvc::ddtCorr) without
  * storing the product fields; bitwise equal to ffm_fvc_flux of the products */
 int ffm_fvc_flux_rho(ffm_mesh *m, const double *rho, const double *vx, const double *vy, const double *vz, double *out_f);
