@@ -191,6 +191,7 @@ def lib():
         "ffm_fv_multivariate_weights": ([vp, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_double, C.c_double, dp] + [C.POINTER(C.c_void_p)] * 4 + [dp], C.c_int),
         "ffm_fvm_lust_source3": ([vp, C.c_double, dp, dp] + [C.POINTER(C.c_void_p)] * 5, C.c_int),
         "ffm_pc_phig": ([vp, dp, dp, dp, dp], C.c_int),
+        "ffm_ue_buoyancy_flux": ([vp, dp, dp, dp, dp], C.c_int),
         "ffm_pc_phiHbyA": ([vp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_pc_flux": ([vp, dp, dp, dp, dp, dp, dp, dp, dp, dp], C.c_int),
         "ffm_fvc_div_dev2T_gradU": ([vp, C.POINTER(vp), dp, dp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)], C.c_int),

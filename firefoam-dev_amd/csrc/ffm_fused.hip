@@ -572,6 +572,28 @@ __global__ __launch_bounds__(256) void k_pc_flux(MeshView q, const double *__res
         }
     }
 }
+// the face flux fvc::reconstruct takes in solver/UEqn.H:23-29: t = (-ghf*fvc::snGrad(rho) - fvc::snGrad(p_rgh))*magSf (two snGrad passes and
+// their combination in one)
+__global__ __launch_bounds__(256) void k_ue_buoyancy_flux(MeshView q, const double *__restrict__ ghf, const double *__restrict__ rho,
+                                                         const double *__restrict__ prgh, double *__restrict__ out)
+{
+    CELL_SCHED(ci, q) {
+        const int c = (int)ci; const double rP = rho[c], pP = prgh[c];
+        PC_ALL_SLOTS(q, c, e, nb) {
+            if (nb < 0) { out[e] = 0.0; continue; }
+            const double sgr = q.delta[e] * (rho[nb] - rP), sgp = q.delta[e] * (prgh[nb] - pP);
+            out[e] = (-ghf[e] * sgr - sgp) * q.magSf[e];
+        }
+    }
+}
+extern "C" int ffm_ue_buoyancy_flux(ffm_mesh *m, const double *ghf, const double *rho, const double *p_rgh, double *t_f)
+{
+    CHECK_M(m);
+    if (!ghf || !rho || !p_rgh || !t_f) return FFM_ERR_ARG;
+    LAUNCH_CELLS(k_ue_buoyancy_flux, mview(m), ghf, rho, p_rgh, t_f);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
 extern "C" int ffm_pc_phig(ffm_mesh *m, const double *rhorAUf, const double *ghf, const double *rho, double *phig)
 {
     CHECK_M(m);

@@ -48,6 +48,7 @@ int ffm_fvm_scalar_transport_multi(ffm_mesh *, int, int, double, double, double,
                                    const double *const *, const double *const *,
                                    double *const *, double *const *, double *const *, double *const *);
 int ffm_pc_phig(ffm_mesh *, const double *, const double *, const double *, double *);
+int ffm_ue_buoyancy_flux(ffm_mesh *, const double *, const double *, const double *, double *);
 int ffm_pc_phiHbyA(ffm_mesh *, const double *, const double *, const double *, const double *, const double *, const double *, const double *, double *);
 int ffm_pc_flux(ffm_mesh *, const double *, const double *, const double *, const double *, const double *, const double *, double *, double *, double *);
 int ffm_fv_limited_limiter(ffm_mesh *, int, double, double, double, const double *, const double *, const double *, const double *,
@@ -577,15 +578,16 @@ extern "C" int ffm_plume_step(ffm_plume *P)
     FFM_TRY(ffm_fvm_transport(m, rdt, P->rho, P->phi, wU, muf, -1, P->Udiag, P->Uupper, P->Ulower));
     // reconstruct((-ghf*snGrad(rho) - snGrad(p_rgh))*magSf)
     double *sgr = P->wF[1], *sgp = P->wF[2], *t = P->wF[4], *tb = P->wB[5], *rhob = P->wB[6], *pb = P->wB[7];
-    FFM_TRY(ffm_fvc_snGrad(m, P->rho, sgr));
+    if (!P->fused) FFM_TRY(ffm_fvc_snGrad(m, P->rho, sgr));
     zg(P, rhob, P->rho);
     FFM_TRY(bc_p_rgh(P, nullptr, Ub, rhob));
     FFM_TRY(ffm_bc_values(m, P->fP, P->refP, P->gradP, P->p_rgh, pb));
-    FFM_TRY(ffm_fvc_snGrad(m, P->p_rgh, sgp));
+    if (!P->fused) FFM_TRY(ffm_fvc_snGrad(m, P->p_rgh, sgp));
     FFM_TRY(ffm_fvc_snGrad_b(m, P->p_rgh, pb, tb));
     {
         const double *ghf = P->ghf, *bMag = ffm_mesh_geom(m, 4);
-        forN(P, nNat, [=] __device__(long e) { t[e] = (-ghf[e] * sgr[e] - sgp[e]) * magSf[e]; });
+        if (P->fused) FFM_TRY(ffm_ue_buoyancy_flux(m, ghf, P->rho, P->p_rgh, t));
+        else forN(P, nNat, [=] __device__(long e) { t[e] = (-ghf[e] * sgr[e] - sgp[e]) * magSf[e]; });
         forN(P, B, [=] __device__(long k) { tb[k] = -tb[k] * bMag[k]; });
     }
     double *rx = P->wN[5], *ry = P->wN[6], *rz = P->wN[7];

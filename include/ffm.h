@@ -355,6 +355,8 @@ int ffm_pc_phiHbyA(ffm_mesh *m, const double *rho, const double *vx, const doubl
                    const double *ddtCorr, const double *phig, double *phiHbyA);
 int ffm_pc_flux(ffm_mesh *m, const double *upper, const double *lower, const double *psi, const double *phiHbyA, const double *phig,
                 const double *rhorAUf, double *flux_f, double *phi_f, double *t_f);
+/* solver/UEqn.H:23-29: the face flux of fvc::reconstruct, t = (-ghf*fvc::snGrad(rho) - fvc::snGrad(p_rgh))*magSf, in one pass */
+int ffm_ue_buoyancy_flux(ffm_mesh *m, const double *ghf, const double *rho, const double *p_rgh, double *t_f);
 /* fvc::flux(rho*v) on the internal faces (solver/pEqn.H:15 fvc::flux(rho*HbyA); the old-time flux of fvc::ddtCorr) without
  * storing the product fields; bitwise equal to ffm_fvc_flux of the products */
 int ffm_fvc_flux_rho(ffm_mesh *m, const double *rho, const double *vx, const double *vy, const double *vz, double *out_f);
