@@ -258,6 +258,7 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
     # device and oracle need not pick the same weights on faces with negligible flux), every initial residual within 2e-3, min/max(T).
     # Against the ORACLE (which follows the log to 3-5 digits): the fields at the end of every step.
     LOGSTEPS = json.load(open(os.path.join(HERE, "golden", "steckler_log_steps.json")))["steps"]
+    mism = []                                  # solver lines whose iteration count differs from the log's (by one)
     c.time = c.dt
     for k in range(1, int(os.environ.get("FFM_STECKLER_STEPS", "29"))):
         g2 = LOGSTEPS[k]
@@ -282,6 +283,8 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
                 assert it == s_["nIterations"], (k + 1, name, it, s_)
             else:
                 assert abs(it - s_["nIterations"]) <= 1, (k + 1, name, it, s_)
+                if it != s_["nIterations"]:
+                    mism.append((k + 1, name, it, s_["nIterations"]))
             if s_["initialResidual"] > 0:
                 assert abs(r0 - s_["initialResidual"]) <= 2e-3 * s_["initialResidual"], (k + 1, name, r0, s_)
             if name in ("Ux", "Uy", "Uz") and k == 1:         # second step: the log's digits (LUST with a non-zero flux)
@@ -298,6 +301,8 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
             close(back(out["U"][d]), c.U[:, d], 1e-3, "U%d %d" % (d, k + 1))
         close(back(out["Y"][iO2]), c.Y[iO2], 1e-3, "O2 %d" % (k + 1))
     assert np.max(out["Y"][iFuel]) > 0.1 and Tmax > 360.0                          # the fuel has entered and burns
+    print("\nsolver lines whose iteration count differs from the log's by one (of %d): %s" % (sum(len(g_["solves"]) for g_ in LOGSTEPS), mism))
+    assert len(mism) <= 4              # measured: 2 of 406 -- H2O and CO2 of the third step, 2 sweeps instead of 3, as the oracle (9.4e-09 against 1e-08)
     lib.firefoam_steckler_destroy(S)
     G.close(); mesh.close(); A.close()
 
