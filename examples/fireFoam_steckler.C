@@ -86,6 +86,10 @@ struct stecklerSolver
     const bool constD = false;
     scalar cumulativeContErr = 0;
     Time runTime;
+    struct { bool adjustTimeStep; scalar maxCo, maxDeltaT; } timeControls{true, 0.9, 0.1};      // cases/steckler/system/controlDict:50-56
+    pyrolysisModelCollection pyrolysis;                         // selection `none` (log.fireFoam:119)
+    const scalar maxDi = 0.25;                                  // controlDict:54
+    const bool solvePyrolysisRegion = true, solvePrimaryRegion = true;
     kEqnLES* les = nullptr;
 
     static pimpleDict pimpleOf()
@@ -196,11 +200,40 @@ struct stecklerSolver
         FFM_FOAM_CHK(ffm_ctx_sync(ctx));
     }
 
+    // the body of the reference's time loop, solver/fireFoam.C:76-121: time-step control -- the reference's solidRegionDiffusionNo.H and
+    // setMultiRegionDeltaT.H between this layer's restatements of the OpenFOAM headers, Time::setDeltaT adjusting towards the write
+    // times -- then the step.  The golden log's deltaT sequence comes out of it (tests/test_steckler_case_gpu.py)
+    void timeStep()
+    {
+        #include "readTimeControls.H"
+        #include "compressibleCourantNo.H"
+        #include "solidRegionDiffusionNo.H"
+        #include "setMultiRegionDeltaT.H"
+        #include "setDeltaT.H"
+
+        runTime++;
+
+        parcels.evolve();
+
+        surfaceFilm.evolve();
+
+        if(solvePyrolysisRegion)
+        {
+            pyrolysis.evolve();
+        }
+
+        if (solvePrimaryRegion)
+        {
+            step(false);
+        }
+        (void)meanCoNum;
+    }
+
     // one time step: solver/fireFoam.C:84,97-119 with the reference's equation files
-    void step()
+    void step(bool increment = true)
     {
         mesh.log.clear();
-        runTime++;
+        if (increment) runTime++;
         // old-time levels (GeometricField::storeOldTimes at the time increment; K's is created on first request)
         rho.storeOldTime(); U.storeOldTime(); thermo.he().storeOldTime(); p_rgh.storeOldTime();
         thermoObj.psi_.storeOldTime(); phi.storeOldTime();
@@ -276,6 +309,17 @@ extern "C" void firefoam_steckler_destroy(stecklerSolver* s) { delete s; }
 // golden log by tests/test_steckler_first_step_cpu.py) is handed over by the caller
 extern "C" void firefoam_steckler_courant(stecklerSolver* s, double* out) { s->courant(out); }
 extern "C" void firefoam_steckler_set_delta_t(stecklerSolver* s, double deltaT) { s->runTime.setDeltaT(deltaT); }
+// the whole loop body with the reference's time-step control: writeControl adjustableRunTime, writeInterval (controlDict:30-32) switch
+// Time::adjustDeltaT on; returns like firefoam_steckler_advance, the deltaT used in *deltaTOut
+extern "C" int firefoam_steckler_time_step(stecklerSolver* s, const stecklerCaseData* cs, int download, double writeInterval, double* deltaTOut)
+{
+    s->runTime.setWriteInterval(writeInterval);
+    s->timeStep();
+    if (deltaTOut) *deltaTOut = s->runTime.deltaTValue();
+    if (download) s->download(cs);
+    if (cs->contErrOut) cs->contErrOut[0] = s->cumulativeContErr;
+    return s->logOut(cs);
+}
 // one time step; returns the number of linear solves (names, iteration counts and residuals in cs->namesOut / nIterOut / resOut)
 extern "C" int firefoam_steckler_advance(stecklerSolver* s, const stecklerCaseData* cs, int download)
 {

@@ -64,6 +64,8 @@ def _case(ffm, ctx, tiled, refine=1, tileCells=8):
     lib.firefoam_steckler_destroy.argtypes = [C.c_void_p]
     lib.firefoam_steckler_courant.argtypes = [C.c_void_p, dp]
     lib.firefoam_steckler_set_delta_t.argtypes = [C.c_void_p, C.c_double]
+    lib.firefoam_steckler_time_step.restype = C.c_int
+    lib.firefoam_steckler_time_step.argtypes = [C.c_void_p, C.POINTER(CaseData), C.c_int, C.c_double, dp]
 
     # ---- the mesh (blockMesh + topoSet + createBaffles + createPatch of cases/steckler/mesh.sh, as oracle/steckler_case.py builds it)
     m = SC.build_mesh(refine)
@@ -180,9 +182,14 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
         assert nS.value == 5 and list(nit[:5]) == [g_["nIterations"] for g_ in GOLD0] == [29, 32, 7, 0, 0], list(nit[:nS.value])
         for k_, g_ in enumerate(GOLD0):
             assert abs(res[2 * k_] - g_["initialResidual"]) <= 1e-6 * g_["initialResidual"] and abs(res[2 * k_ + 1] - g_["finalResidual"]) <= 1e-6 * g_["finalResidual"]
+        # the whole body of the reference's time loop (solver/fireFoam.C:76-121) from the case's deltaT 0.05 (controlDict:26): the time-step
+        # control runs on the device's fields too -- 0.05 -> 0.06 -> 1/17 -> 1.2/17 -> 1/15, the log's `deltaT = 0.066666667`
+        lib.firefoam_steckler_set_delta_t(S, 0.05)
+        dtDev = np.zeros(1)
         with nocapture():
-            n = lib.firefoam_steckler_advance(S, C.byref(cs), 1)
+            n = lib.firefoam_steckler_time_step(S, C.byref(cs), 1, 1.0, dtDev.ctypes.data_as(dp))
         text = capfd.readouterr().out
+        assert abs(dtDev[0] - 1.0 / 15.0) < 1e-15 and "Courant Number mean: 0 max: 0" in text and sig(float(re.search(r"^deltaT = (\S+)", text, re.M).group(1)), 5) == "0.066667", dtDev
     finally:
         os.environ["FFM_FOAM_QUIET"] = "1"
     got = [(nm.raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), nit[i], res[2 * i], res[2 * i + 1]) for i in range(n)]
@@ -252,8 +259,8 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
         close(back(out["Y"][i]), c.Y[i], 1e-6, s)
     # ---- ALL THE OTHER 28 TIME STEPS OF THE LOG (log.fireFoam:233-1243: t = 0.16 ... 2 s; the burner's fuel enters in the third step,
     # ignites in the fourth, the flame reaches 1027 K): flux, velocity and turbulence fields are no longer zero.  The Courant numbers the log prints in front of every
-    # step come from the device's phi and rho (compressibleCourantNo.H); deltaT is the oracle's (its sequence is asserted on the log by
-    # tests/test_steckler_whole_log_cpu.py).  Against the LOG: the solver lines in order, the iteration counts (identical for U, h, k;
+    # step come from the device's phi and rho (compressibleCourantNo.H) and so does deltaT: firefoam_steckler_time_step runs the reference's
+    # time-step control on them (the oracle's sequence is asserted on the log by tests/test_steckler_whole_log_cpu.py).  Against the LOG: the solver lines in order, the iteration counts (identical for U, h, k;
     # p_rgh within one iteration; the species within one sweep: their limiter works on fields that are uniform up to round-off, where
     # device and oracle need not pick the same weights on faces with negligible flux), every initial residual within 2e-3, min/max(T).
     # Against the ORACLE (which follows the log to 3-5 digits): the fields at the end of every step.
@@ -268,14 +275,18 @@ def test_the_steckler_case_runs_its_first_time_step_on_the_device(O, ffm, ctx, c
         assert abs(co[0] - g2["courantMean"]) <= tolCo * g2["courantMean"] and abs(co[1] - g2["courantMax"]) <= tolCo * g2["courantMax"], (k + 1, co, g2["courantMean"], g2["courantMax"])
         c.advance()
         assert sig(c.dt, 5) == sig(g2["deltaT"], 5)
-        lib.firefoam_steckler_set_delta_t(S, c.dt)
         os.environ.pop("FFM_FOAM_QUIET", None)
         try:
             capfd.readouterr()
-            n2 = lib.firefoam_steckler_advance(S, C.byref(cs), 1)
+            n2 = lib.firefoam_steckler_time_step(S, C.byref(cs), 1, 1.0, dtDev.ctypes.data_as(dp))
             text2 = capfd.readouterr().out
         finally:
             os.environ["FFM_FOAM_QUIET"] = "1"
+        # the device's own time-step control (setMultiRegionDeltaT.H, setDeltaT.H, Time::adjustDeltaT on its Courant number): the log's
+        # five printed digits, and the oracle's value to the accuracy of the Courant number
+        assert sig(dtDev[0], 5) == sig(g2["deltaT"], 5) or abs(dtDev[0] - g2["deltaT"]) <= 2e-5 * g2["deltaT"], (k + 1, dtDev[0], g2["deltaT"])
+        assert abs(dtDev[0] - c.dt) <= tolCo * c.dt, (k + 1, dtDev[0], c.dt)
+        assert sig(float(re.search(r"^deltaT = (\S+)", text2, re.M).group(1)), 5) == sig(g2["deltaT"], 5) or k >= 12
         got2 = [(nm.raw[16 * i:16 * i + 16].split(b"\0")[0].decode(), nit[i], res[2 * i], res[2 * i + 1]) for i in range(n2)]
         assert [g_[0] for g_ in got2] == [s_["name"] for s_ in g2["solves"]], (k + 1, got2)          # no ray solves in these steps: solverFreq 100
         for (name, it, r0, r1), s_ in zip(got2, g2["solves"]):
