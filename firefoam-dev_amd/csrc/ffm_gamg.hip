@@ -562,7 +562,7 @@ extern "C" int ffm_gamg_solve_d(ffm_gamg *G, int smoother, double tol, double re
     out->converged = converged() ? 1 : 0;
     if (!A->identity) FFM_TRY(ffm_from_internal(A, psi, psi_d));
     FFM_HIP(hipStreamSynchronize(s));
-    for (auto &L : G->lev) if (L.A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(L.A));
+    for (auto &L : G->lev) { if (L.A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(L.A)); else FFM_TRY(ffm_flow_check_abort(L.A)); }
     return FFM_OK;
 }
 

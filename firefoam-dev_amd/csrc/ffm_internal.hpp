@@ -135,6 +135,8 @@ struct ffm_ldu {
     int *smallFwdStart = nullptr;                // [nLevels+1] device copy of h_fwdLevelStart (single-workgroup sweeps, ffm_solve.hip)
     int *smallBwdRange = nullptr;                // [2*nBwdLevels] {p0, p1} of every backward level
     int smallState = 0;                          // 0 not decided, 1 usable, -1 not (too large / switched off)
+    int *flowOrder = nullptr;                    // [nOwned] cells by backward level (dataflow sweeps, ffm_solve.hip)
+    int flowState = 0;                           // 0 not decided, 1 usable, -1 not
     int *cellPerm = nullptr;                     // [N] new->old (only when !identity)
     int *faceSrc = nullptr;                      // [upTotal] native face -> caller face id (-1 padding)
     std::vector<int> h_callerToNative;           // [F] caller face id -> native face index
@@ -237,6 +239,7 @@ int ffm_tile_build(ffm_ldu *A, const std::vector<int> &lev, const std::vector<in
                    const std::vector<int> *bwdCells /* null: the backward order mirrors the forward order */);
 bool ffm_tile_feasible(int nOwn, int F, const int *l, const int *u);
 int ffm_tile_calc_rD(ffm_ldu *A);
+int ffm_flow_check_abort(ffm_ldu *A);                    // dataflow sweeps of level-scheduled matrices (ffm_solve.hip)
 bool ffm_tile_gs_usable(const ffm_ldu *A);
 int ffm_tile_gs_ghost_terms(ffm_ldu *A, const double *psi, double *bP);
 int ffm_ghost_exchange(ffm_ldu *A, double *x);

@@ -586,7 +586,7 @@ extern "C" int ffm_ldu_destroy(ffm_ldu *A)
     hipFree(A->gsProd);
     for (int i = 0; i < 3; i++) hipFree(A->permIn[i]);
     hipFree(A->upOff); hipFree(A->loOff); hipFree(A->upNbr); hipFree(A->loEnt); hipFree(A->faceSrc);
-    hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative); hipFree(A->smallFwdStart); hipFree(A->smallBwdRange);
+    hipFree(A->bwdOrder); hipFree(A->cellPerm); hipFree(A->callerToNative); hipFree(A->smallFwdStart); hipFree(A->smallBwdRange); hipFree(A->flowOrder);
     hipFree(A->grpCell); hipFree(A->bwdCells); hipFree(A->sweepTicket); hipFree(A->rowSched);
     ffm_tile_free(A);
     hipFree(A->ghSendCells); hipFree(A->ghSendBuf); if (A->ghSendBuf_h) hipHostFree(A->ghSendBuf_h); if (A->ghRecvBuf_h) hipHostFree(A->ghRecvBuf_h);

@@ -24,6 +24,7 @@
 #include "ffm_device.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 static inline int sgrid(long n) { long g = (n + 255) / 256; return (int)std::max(1L, std::min(g, (long)RED_BLOCKS)); }
 
@@ -356,6 +357,7 @@ __global__ void k_gs_bwd_level(int p0, int p1, const int *__restrict__ order, Ld
 // earlier level are read with agent-scope loads (they bypass the CU's L1, where a line fetched for a neighbouring cell may hold the
 // old value); the barrier's release waits for the stores.  Per-cell arithmetic is that of the level kernels above, bit for bit.
 constexpr int SMALL_T = 1024;
+constexpr long FFM_SMALL_SWEEP_DEFAULT = 131072L;
 __device__ __forceinline__ double s_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 enum { SM_RD = 0, SM_PRECOND = 1, SM_GS = 2, SM_SYMGS = 3 };
 struct SmallArgs {
@@ -446,12 +448,16 @@ __global__ __launch_bounds__(SMALL_T) void k_small_sweep(SmallArgs a)
     }
 }
 
-// usable for this matrix?  (level-scheduled mode, at most FFM_SMALL_SWEEP_CELLS owned cells -- default 131072, 0 switches it off)
+// usable for this matrix?  (level-scheduled mode, at most FFM_SMALL_SWEEP_CELLS owned cells -- 0 switches it off; default 0, or
+// 131072 when the dataflow sweeps are switched off)
 static bool small_usable(ffm_ldu *A)
 {
     if (A->smallState) return A->smallState > 0;
-    const char *e = getenv("FFM_SMALL_SWEEP_CELLS");            // read per matrix: tests switch between the two paths
-    const long limit = e ? atol(e) : 131072L;
+    const char *e = getenv("FFM_SMALL_SWEEP_CELLS");            // read per matrix: tests switch between the paths
+    const char *f = getenv("FFM_FLOW_SWEEP");
+    // measured (GAMG V-cycle at 96^3 and 200^3): the dataflow sweeps below beat this form at every size, so it is only the default
+    // where they are switched off
+    const long limit = e ? atol(e) : ((f && !strcmp(f, "0")) ? FFM_SMALL_SWEEP_DEFAULT : 0L);
     A->smallState = -1;
     if (A->sweepMode == 2 || A->nOwned > limit || A->nLevels < 1) return false;
     std::vector<int> br(2 * (size_t)std::max(A->nBwdLevels, 1), 0);
@@ -476,6 +482,244 @@ static SmallArgs small_args(ffm_ldu *A)
     return a;
 }
 #define SMALL_LAUNCH(MODE, a) FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_small_sweep<MODE, W>), dim3(1), dim3(SMALL_T), 0, A->ctx->stream, a))
+
+// --------------------------------------------------------- dataflow sweeps ---
+// Level-scheduled matrices too large for one workgroup (unstructured meshes, the upper coarse levels of a GAMG hierarchy): instead of
+// one launch -- or one device-wide barrier -- per dependency level, ONE launch in which every cell waits for the values it needs.
+// Workgroups take chunks of 256 cells by an atomic ticket, forward chunks in the level-major cell order, then backward chunks in
+// backward-level order: every value a cell waits for belongs to a chunk with a lower ticket, i.e. to a workgroup that is running or
+// has finished, so the grid drains whatever the dispatch order or the residency (the scheme of the tiled sweeps, ffm_tile.hip).
+// Values are published in sentinel-filled arrays with agent-scope stores and polled with agent-scope loads: the value is its own
+// flag.  A lane never blocks in front of its store: the wait is a retry loop with the store inside and a wave-uniform exit (a ballot
+// over the lanes not yet done -- with a per-lane exit the compiler may sink the store behind the loop, where a finished lane would
+// wait for the lanes that wait for it), so a chain of dependent cells in one wavefront advances one link per trip.  Every wait is bounded and raises the abort word (reported when the solve ends).
+// Per-cell arithmetic is that of the level kernels above, term for term in the same order: results are bitwise equal.
+constexpr int FLOW_T = 256;
+constexpr unsigned FLOW_SPIN_LIMIT = 1u << 21;
+constexpr unsigned long long FLOW_SENT = 0xFFF8C0DEFEEDF10Full;       // a NaN no computation produces
+__device__ __forceinline__ bool f_pending(double v) { return (unsigned long long)__double_as_longlong(v) == FLOW_SENT; }
+__device__ __forceinline__ void f_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct FlowArgs {
+    LduView v;
+    int N, nChunkF, nChunkB, nap;
+    const int *order;                       // [N] cells by backward level
+    const double *upper, *lower, *diag, *cf, *cb, *r, *bP;
+    double *rD, *w, *psi;
+    double *mf, *mb, *sv;                   // published values: forward, backward, bSave (sentinel-filled before the launch)
+    unsigned int *ticket;                   // [0] ticket counter, [1] abort word
+};
+__global__ void k_flow_fill(long n, double *a, double *b, double *c, unsigned int *ticket)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticket[0] = 0u;
+    const double sent = __longlong_as_double((long long)FLOW_SENT);
+    GRID_STRIDE(i, n) { if (a) a[i] = sent; if (b) b[i] = sent; if (c) c[i] = sent; }
+}
+// one trip of a wait: false = keep waiting; raises / follows the abort word
+__device__ __forceinline__ bool f_give_up(unsigned &spins, unsigned int *ticket, int nap)
+{
+    if (nap) __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 1023u) == 0u) {
+        if (__hip_atomic_load(&ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+        if (spins > FLOW_SPIN_LIMIT) { __hip_atomic_store(&ticket[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+    }
+    return false;
+}
+template <int MODE, int W>
+__global__ __launch_bounds__(FLOW_T) void k_flow_sweep(FlowArgs a)
+{
+    __shared__ unsigned shTicket;
+    if (threadIdx.x == 0) shTicket = atomicAdd(&a.ticket[0], 1u);
+    __syncthreads();
+    const unsigned tk = shTicket;
+    unsigned spins = 0;
+    if (tk < (unsigned)a.nChunkF) {
+        // ---- forward
+        const int c = (int)tk * FLOW_T + threadIdx.x;
+        if (c >= a.N) return;
+        if (MODE == SM_RD) {
+            RowEnt<W> L; load_lower<W>(a.v, c, L);
+            double au[W], al[W], rn[W];
+#pragma unroll
+            for (int s = 0; s < W; s++) { au[s] = a.upper[L.f[s]]; al[s] = a.lower[L.f[s]]; rn[s] = 1.0; }
+            const double dg = a.diag[c];
+            bool done = false; do { if (!done) {
+                bool ready = true;
+#pragma unroll
+                for (int s = 0; s < W; s++) if (L.on[s]) { rn[s] = s_ld(&a.mf[L.nb[s]]); ready = ready && !f_pending(rn[s]); }
+                if (ready) {
+                    double d = dg;
+#pragma unroll
+                    for (int s = 0; s < W; s++) if (L.on[s]) d -= au[s] * al[s] / rn[s];
+                    f_st(&a.mf[c], d);
+                    a.rD[c] = 1.0 / d;              // k_recip
+                    done = true;
+                } else done = f_give_up(spins, a.ticket, a.nap);
+            } } while (__ballot(!done) != 0ull);
+        } else if (MODE == SM_PRECOND) {
+            RowEnt<W> L; load_lower<W>(a.v, c, L);
+            const double rd = a.rD[c], rc = a.r[c];
+            double q[W], wn[W];
+#pragma unroll
+            for (int s = 0; s < W; s++) { q[s] = a.cf[L.f[s]]; wn[s] = 0.0; }
+            bool done = false; do { if (!done) {
+                bool ready = true;
+#pragma unroll
+                for (int s = 0; s < W; s++) if (L.on[s]) { wn[s] = s_ld(&a.mf[L.nb[s]]); ready = ready && !f_pending(wn[s]); }
+                if (ready) {
+                    double wc = rd * rc;
+#pragma unroll
+                    for (int s = 0; s < W; s++) if (L.on[s]) wc -= rd * q[s] * wn[s];
+                    f_st(&a.mf[c], wc);
+                    done = true;
+                } else done = f_give_up(spins, a.ticket, a.nap);
+            } } while (__ballot(!done) != 0ull);
+        } else {
+            RowEnt<W> L, U; load_lower<W>(a.v, c, L); load_upper<W>(a.v, c, U);
+            double al[W], au[W], pl[W], pu[W];
+#pragma unroll
+            for (int s = 0; s < W; s++) {
+                al[s] = a.lower[L.f[s]]; au[s] = a.upper[U.f[s]];
+                pl[s] = 0.0; pu[s] = U.on[s] ? a.psi[U.nb[s]] : 0.0;          // upper neighbours: the values before this sweep
+            }
+            const double bc = a.bP[c], dg = a.diag[c];
+            bool done = false; do { if (!done) {
+                bool ready = true;
+#pragma unroll
+                for (int s = 0; s < W; s++) if (L.on[s]) { pl[s] = s_ld(&a.mf[L.nb[s]]); ready = ready && !f_pending(pl[s]); }
+                if (ready) {
+                    double val = bc;
+#pragma unroll
+                    for (int s = 0; s < W; s++) if (L.on[s]) val -= al[s] * pl[s];
+                    const double save = val;
+#pragma unroll
+                    for (int s = 0; s < W; s++) if (U.on[s]) val -= au[s] * pu[s];
+                    val /= dg;
+                    if (MODE == SM_SYMGS) f_st(&a.sv[c], save); else a.psi[c] = val;
+                    f_st(&a.mf[c], val);
+                    done = true;
+                } else done = f_give_up(spins, a.ticket, a.nap);
+            } } while (__ballot(!done) != 0ull);
+        }
+        return;
+    }
+    // ---- backward (preconditioner application, symGaussSeidel)
+    if (MODE == SM_RD || MODE == SM_GS) return;
+    const int p = (int)(tk - (unsigned)a.nChunkF) * FLOW_T + threadIdx.x;
+    if (p >= a.N) return;
+    const int c = a.order[p];
+    if (MODE == SM_PRECOND) {
+        RowEnt<W> U; load_upper<W, true>(a.v, c, U);          // block-Jacobi: ghost neighbours are ignored
+        const double rd = a.rD[c];
+        double q[W], wn[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) { q[s] = a.cb[U.f[s]]; wn[s] = 0.0; }
+        bool done = false; do { if (!done) {
+            double wc = s_ld(&a.mf[c]);
+            bool ready = !f_pending(wc);
+#pragma unroll
+            for (int s = 0; s < W; s++) if (U.on[s]) { wn[s] = s_ld(&a.mb[U.nb[s]]); ready = ready && !f_pending(wn[s]); }
+            if (ready) {
+#pragma unroll
+                for (int s = W - 1; s >= 0; s--) if (U.on[s]) wc -= rd * q[s] * wn[s];
+                f_st(&a.mb[c], wc);
+                a.w[c] = wc;
+                done = true;
+            } else done = f_give_up(spins, a.ticket, a.nap);
+        } } while (__ballot(!done) != 0ull);
+    } else {
+        RowEnt<W> U; load_upper<W>(a.v, c, U);
+        double au[W], pu[W];
+        bool own[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) {
+            au[s] = a.upper[U.f[s]]; own[s] = U.on[s] && U.nb[s] < a.N;
+            pu[s] = (U.on[s] && !own[s]) ? a.psi[U.nb[s]] : 0.0;              // ghost neighbours: unchanged by the sweep
+        }
+        const double dg = a.diag[c];
+        bool done = false; do { if (!done) {
+            double val = s_ld(&a.sv[c]);
+            bool ready = !f_pending(val);
+#pragma unroll
+            for (int s = 0; s < W; s++) if (own[s]) { pu[s] = s_ld(&a.mb[U.nb[s]]); ready = ready && !f_pending(pu[s]); }
+            if (ready) {
+#pragma unroll
+                for (int s = 0; s < W; s++) if (U.on[s]) val -= au[s] * pu[s];
+                val /= dg;
+                f_st(&a.mb[c], val);
+                a.psi[c] = val;
+                done = true;
+            } else done = f_give_up(spins, a.ticket, a.nap);
+        } } while (__ballot(!done) != 0ull);
+    }
+}
+
+// usable for this matrix?  level-scheduled mode, not taken by the single-workgroup sweeps; FFM_FLOW_SWEEP=0 switches it off (one
+// launch per level, the round-1 path), FFM_FLOW_SWEEP=all takes every matrix whatever FFM_SMALL_SWEEP_CELLS says.
+// Measured on one MI355X: a DIC application (two sweeps) in level-major numbering 4.30 -> 2.36 ms at 200^3 (598 levels: 2.0 us per
+// level and sweep, the store -> poll round trip between workgroups on different XCDs; the poll's s_sleep makes no difference),
+// 1.66 -> 1.05 ms at 100^3; a GAMG V-cycle 29.0 -> 15.5 ms at 200^3 and 8.6 -> 5.8 ms at 96^3 (profiles/README.md)
+static bool flow_usable(ffm_ldu *A)
+{
+    if (A->flowState) return A->flowState > 0;
+    const char *e = getenv("FFM_FLOW_SWEEP");                   // read per matrix: tests switch between the paths
+    A->flowState = -1;
+    if (A->sweepMode == 2 || A->nLevels < 1 || A->nOwned < 1 || (e && !strcmp(e, "0"))) return false;
+    std::vector<int> ord((size_t)A->nOwned);
+    if (A->bwdContig) {
+        size_t k = 0;
+        for (int b = 0; b < A->nBwdLevels; b++)
+            for (int i = 0, n = A->h_bwdLevelStart[b + 1] - A->h_bwdLevelStart[b]; i < n; i++) ord[k++] = A->h_bwdFirstCell[b] + i;
+        if (k != ord.size()) return false;
+    } else {
+        if (hipMemcpy(ord.data(), A->bwdOrder, sizeof(int) * ord.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    }
+    if (hipMalloc((void **)&A->flowOrder, sizeof(int) * ord.size()) != hipSuccess) return false;
+    if (hipMemcpy(A->flowOrder, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (!A->sweepTicket) {
+        if (hipMalloc((void **)&A->sweepTicket, 2 * sizeof(unsigned int)) != hipSuccess) return false;
+        // on the context's stream: a null-stream hipMemset returns before it has run and is not ordered against that (non-blocking)
+        // stream -- it could zero the ticket counter in the middle of the first sweep
+        if (hipMemsetAsync(A->sweepTicket, 0, 2 * sizeof(unsigned int), A->ctx->stream) != hipSuccess) return false;
+    }
+    A->flowState = 1;
+    return true;
+}
+static bool flow_preferred(ffm_ldu *A)
+{
+    const char *e = getenv("FFM_FLOW_SWEEP");
+    return e && !strcmp(e, "all") && flow_usable(A);
+}
+static int flow_args(ffm_ldu *A, int mode, FlowArgs &a)
+{
+    a = FlowArgs{};
+    a.v = ffm_view(A); a.N = A->nOwned; a.nChunkF = (A->nOwned + FLOW_T - 1) / FLOW_T;
+    a.nChunkB = (mode == SM_PRECOND || mode == SM_SYMGS) ? a.nChunkF : 0;
+    a.nap = 1;
+    a.order = A->flowOrder; a.upper = A->upper; a.lower = A->lower; a.diag = A->diag; a.rD = A->rD; a.ticket = A->sweepTicket;
+    FFM_TRY(ffm_ldu_work(A, 20, &a.mf));
+    if (a.nChunkB) FFM_TRY(ffm_ldu_work(A, 21, &a.mb));
+    if (mode == SM_SYMGS) FFM_TRY(ffm_ldu_work(A, 22, &a.sv));
+    hipLaunchKernelGGL(k_flow_fill, dim3(sgrid(A->nOwned)), dim3(256), 0, A->ctx->stream, (long)A->nOwned, a.mf, a.mb, a.sv, a.ticket);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+#define FLOW_LAUNCH(MODE, a) FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_flow_sweep<MODE, W>), dim3((a).nChunkF + (a).nChunkB), dim3(FLOW_T), 0, A->ctx->stream, a))
+
+// the abort word of the dataflow sweeps (a bounded wait ran out): reported when a solve ends
+int ffm_flow_check_abort(ffm_ldu *A)
+{
+    if (A->flowState <= 0 || !A->sweepTicket) return FFM_OK;
+    unsigned int h[2] = {0, 0};
+    FFM_HIP(hipMemcpyAsync(h, A->sweepTicket, sizeof(h), hipMemcpyDeviceToHost, A->ctx->stream));
+    FFM_HIP(hipStreamSynchronize(A->ctx->stream));
+    if (h[1]) {
+        ffm_set_error("dataflow sweep timed out waiting for the value of a predecessor cell (abort word set)");
+        unsigned int z = 0;
+        hipMemcpy(A->sweepTicket + 1, &z, sizeof(z), hipMemcpyHostToDevice);
+        return FFM_ERR_HIP;
+    }
+    return FFM_OK;
+}
 
 // blocks needed to cover cells [c0,c1) when thread 0 of block 0 sits on the slice start of c0
 static inline int level_grid(int c0, int c1) { return ffm_grid(c1 - (c0 & ~63), 256); }
@@ -529,9 +773,15 @@ static int calc_rD(ffm_ldu *A)
         FFM_HIP(hipGetLastError());
         return FFM_OK;
     }
-    if (small_usable(A)) {
+    if (!flow_preferred(A) && small_usable(A)) {
         SmallArgs a = small_args(A);
         SMALL_LAUNCH(SM_RD, a);
+        FFM_HIP(hipGetLastError());
+        return FFM_OK;
+    }
+    if (flow_usable(A)) {
+        FlowArgs a; FFM_TRY(flow_args(A, SM_RD, a));
+        FLOW_LAUNCH(SM_RD, a);
         FFM_HIP(hipGetLastError());
         return FFM_OK;
     }
@@ -580,10 +830,17 @@ int ffm_precond_apply_i(ffm_ldu *A, int precond, bool transpose, const double *r
     const double *cf = (precond == FFM_DIC) ? A->upper : (transpose ? A->upper : A->lower);
     const double *cb = (precond == FFM_DIC) ? A->upper : (transpose ? A->lower : A->upper);
     if (A->sweepMode == 2) return ffm_tile_precond(A, precond, transpose, r, w);
-    if (small_usable(A)) {
+    if (!flow_preferred(A) && small_usable(A)) {
         SmallArgs a = small_args(A);
         a.cf = cf; a.cb = cb; a.r = r; a.w = w;
         SMALL_LAUNCH(SM_PRECOND, a);
+        FFM_HIP(hipGetLastError());
+        return FFM_OK;
+    }
+    if (flow_usable(A)) {
+        FlowArgs a; FFM_TRY(flow_args(A, SM_PRECOND, a));
+        a.cf = cf; a.cb = cb; a.r = r; a.w = w;
+        FLOW_LAUNCH(SM_PRECOND, a);
         FFM_HIP(hipGetLastError());
         return FFM_OK;
     }
@@ -630,10 +887,17 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             FFM_TRY(ffm_tile_gs(A, sym, psi, bUse, bSave, A->gsProd));
             continue;
         }
-        if (small_usable(A)) {
+        if (!flow_preferred(A) && small_usable(A)) {
             SmallArgs a = small_args(A);
             a.bP = bUse; a.bSave = bSave; a.psi = psi;
             if (sym) SMALL_LAUNCH(SM_SYMGS, a); else SMALL_LAUNCH(SM_GS, a);
+            FFM_HIP(hipGetLastError());
+            continue;
+        }
+        if (flow_usable(A)) {
+            FlowArgs a; FFM_TRY(flow_args(A, sym ? SM_SYMGS : SM_GS, a));
+            a.bP = bUse; a.psi = psi;
+            if (sym) FLOW_LAUNCH(SM_SYMGS, a); else FLOW_LAUNCH(SM_GS, a);
             FFM_HIP(hipGetLastError());
             continue;
         }
@@ -922,7 +1186,7 @@ extern "C" int ffm_solve_d(ffm_ldu *A, int solver, int precond, double tol, doub
         FFM_TRY(ffm_from_internal(A, pi, psi_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A)); else FFM_TRY(ffm_flow_check_abort(A));
     return FFM_OK;
 }
 
@@ -949,7 +1213,7 @@ extern "C" int ffm_precond_setup(ffm_ldu *A, int precond, double *rD_out_d)
     FFM_TRY(ffm_precond_setup_i(A, precond));
     if (rD_out_d) FFM_TRY(ffm_from_internal(A, A->rD, rD_out_d));
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A)); else FFM_TRY(ffm_flow_check_abort(A));
     return FFM_OK;
 }
 
@@ -986,7 +1250,7 @@ extern "C" int ffm_precond_apply(ffm_ldu *A, int precond, int transpose, const d
         FFM_TRY(ffm_from_internal(A, wi, w_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A)); else FFM_TRY(ffm_flow_check_abort(A));
     return FFM_OK;
 }
 
@@ -1001,6 +1265,6 @@ extern "C" int ffm_gs_smooth(ffm_ldu *A, int symmetric_sweep, int nSweeps, doubl
         FFM_TRY(ffm_from_internal(A, A->permIn[2], psi_d));
     }
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A));
+    if (A->sweepMode == 2) FFM_TRY(ffm_tile_check_abort(A)); else FFM_TRY(ffm_flow_check_abort(A));
     return FFM_OK;
 }

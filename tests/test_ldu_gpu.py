@@ -224,19 +224,32 @@ def test_reductions(O, ctx):
     assert ctx.gSum(xd) == ctx.gSum(xd)      # deterministic (no atomics)
 
 
-@pytest.mark.parametrize("smallLimit", ["0", "1000000"])
-def test_one_launch_per_level_and_single_workgroup_sweeps_agree(O, ffm, ctx, monkeypatch, smallLimit):
-    """Level-scheduled sweeps have two forms: one launch per dependency level (any size) and, for matrices of at most
-    FFM_SMALL_SWEEP_CELLS cells (default 131072: GAMG's coarse levels, small unstructured meshes), ONE workgroup that walks all
-    levels with a barrier per level (csrc/ffm_solve.hip: k_small_sweep).  Both must be the serial face loops bit for bit: DIC and DILU
-    (calcReciprocalD, precondition, transposed), GaussSeidel and symGaussSeidel, on a randomly relabelled DAG mesh (non-contiguous
-    backward levels) and a hex box."""
-    monkeypatch.setenv("FFM_SMALL_SWEEP_CELLS", smallLimit)
+@pytest.mark.parametrize("smallLimit,flow", [("0", "0"), ("1000000", None), ("0", None), ("1000000", "all"), (None, None), (None, "0")])
+def test_one_launch_per_level_and_single_workgroup_sweeps_agree(O, ffm, ctx, monkeypatch, smallLimit, flow):
+    """Level-scheduled sweeps have three forms: one launch per dependency level (FFM_FLOW_SWEEP=0; the round-1 path); for matrices of
+    at most FFM_SMALL_SWEEP_CELLS cells ONE workgroup that walks all levels with a barrier per level (csrc/ffm_solve.hip:
+    k_small_sweep); and -- the default for every level-scheduled matrix: unstructured meshes, GAMG's coarse levels -- ONE launch in
+    which every cell waits for the values it needs (k_flow_sweep: chunks of 256 cells by ticket, values published in sentinel-filled
+    arrays).  All must be the
+    serial face loops bit for bit: DIC and DILU (calcReciprocalD, precondition, transposed), GaussSeidel and symGaussSeidel, on a
+    randomly relabelled DAG mesh (non-contiguous backward levels), a hex box, and larger ones of both (hundreds of chunks)."""
+    if smallLimit is None:                      # the defaults: dataflow sweeps for every size; with them off, single-workgroup sweeps up to 131072 cells
+        monkeypatch.delenv("FFM_SMALL_SWEEP_CELLS", raising=False)
+    else:
+        monkeypatch.setenv("FFM_SMALL_SWEEP_CELLS", smallLimit)
+    if flow is None:
+        monkeypatch.delenv("FFM_FLOW_SWEEP", raising=False)
+    else:
+        monkeypatch.setenv("FFM_FLOW_SWEEP", flow)
     monkeypatch.setenv("FFM_SWEEP", "levels")
     H = ffm.hexmesh
-    for name in ("dag", "hex"):
+    for name in ("dag", "hex", "dag-large", "hex-large"):
         if name == "dag":
             N, l, u = random_dag_mesh(O, 14, seed=5)
+        elif name == "dag-large":
+            N, l, u = random_dag_mesh(O, 36, seed=9)
+        elif name == "hex-large":
+            blk = H.HexBlock((47, 41, 33)); N, l, u = blk.nCells, blk.l, blk.u
         else:
             blk = H.HexBlock((13, 11, 9)); N, l, u = blk.nCells, blk.l, blk.u
         A = ffm.lduMatrix(ctx, N, l, u)
