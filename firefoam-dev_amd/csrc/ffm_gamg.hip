@@ -279,6 +279,24 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
     G->lev.emplace_back();
     { Level &L0 = G->lev[0]; L0.A = finest; L0.nCells = nCells; L0.nFaces = nFaces; L0.l.assign(lowerAddr, lowerAddr + nFaces); L0.u.assign(upperAddr, upperAddr + nFaces); }
     std::vector<double> w(faceWeights, faceWeights + nFaces);
+    // Tile plans for the coarse levels: when the finest matrix runs the tiled wavefront kernels, a coarse cell inherits the tile
+    // (group) of its first fine cell.  On a hex box the pairs of the first few agglomerations lie inside the tiles, the coarse
+    // levels keep <= 3 lower / upper neighbours per cell and an acyclic tile graph, and their smoother sweeps run as tiled
+    // wavefronts instead of the dataflow sweeps (2 us per dependency level); wherever the planner cannot use the inherited groups
+    // ffm_ldu_create_hint falls back to the level-scheduled form by itself.  FFM_GAMG_TILES=0 switches the inheritance off.
+    std::vector<int> hint;                  // group label per cell of the current level (caller order); empty: no inheritance
+    {
+        const char *e = getenv("FFM_GAMG_TILES");
+        if (finest->sweepMode == 2 && finest->grpCell && finest->nGroups > 0 && !(e && atoi(e) == 0)) {
+            std::vector<int> gc((size_t)finest->nGroups + 1);
+            FFM_HIP(hipMemcpy(gc.data(), finest->grpCell, sizeof(int) * gc.size(), hipMemcpyDeviceToHost));
+            hint.assign(nCells, 0);
+            for (int g = 0; g < finest->nGroups; g++)
+                for (int n = gc[g]; n < gc[g + 1] && n < nCells; n++) hint[finest->identity ? n : finest->h_newToOldCell[n]] = g;
+        }
+    }
+    long tileMinCells = 2048;               // below this a level is a handful of tiles (measured: 2048 ... 8192 equal, 32768 slower)
+    if (const char *e = getenv("FFM_GAMG_TILE_MIN_CELLS")) tileMinCells = atol(e);
     bool forward = true;                    // pairGAMGAgglomeration::forward_ (static, true at the first agglomeration of a run)
     const int maxLevels = 50;
     while ((int)G->lev.size() - 1 < maxLevels - 1) {
@@ -298,8 +316,18 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
         w.swap(cw);
         // the coarse matrix
         ffm_ldu *Ac = nullptr;
-        int rc = ffm_ldu_create(ctx, nCoarse, nCF, cl.data(), cu.data(), &Ac);
+        int rc;
+        if (!hint.empty()) {
+            std::vector<int> ch(nCoarse, -1);
+            for (int c = 0; c < nFine; c++) if (ch[cmap[c]] < 0) ch[cmap[c]] = hint[c];          // the first fine cell's tile
+            hint.swap(ch);
+            if (nCoarse < tileMinCells) hint.clear();
+        }
+        if (!hint.empty()) rc = ffm_ldu_create_hint(ctx, nCoarse, 0, nCF, cl.data(), cu.data(), hint.data(), &Ac);
+        else rc = ffm_ldu_create(ctx, nCoarse, nCF, cl.data(), cu.data(), &Ac);
         if (rc) return fail(rc);
+        if (Ac->sweepMode != 2) hint.clear();           // the planner gave up here: no tiles further down either
+        if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm gamg: coarse level %d: %d cells, %s sweeps\n", k + 1, nCoarse, Ac->sweepMode == 2 ? "tiled" : "level-scheduled");
         G->lev.emplace_back();
         Level &Lf = G->lev[k], &Lc = G->lev[k + 1];
         Lc.A = Ac; Lc.owned = true; Lc.nCells = nCoarse; Lc.nFaces = nCF; Lc.l = cl; Lc.u = cu;
