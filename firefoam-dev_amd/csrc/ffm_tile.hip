@@ -336,6 +336,7 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
     T->nTail = (int)tailCell.size();
     FFM_TRY(upv(&T->tailCell, tailCell)); FFM_TRY(upv(&T->tailStart, tailStart)); FFM_TRY(upv(&T->tailFace, tailFace)); FFM_TRY(upv(&T->tailNbr, tailNbr));
     T->gsTables = true;
+#define AMUL_GIVE_UP(why) do { if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm: no ring plan for the tiled Amul (%s, entry %d of %d): row kernel\n", why, e, nEnt); return FFM_OK; } while (0)
     // ---- ring plan of the tiled Amul: may give up (too many out-of-window neighbours in one entry), Amul then runs on the row kernel
     std::vector<int> entOf(nOwn, -1);
     for (int e = 0; e < nEnt; e++) for (int c = recF[e].x; c < recF[e].x + (recF[e].y & 0xFFFF); c++) entOf[c] = e;
@@ -356,10 +357,10 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
                 const int q = A->h_loEnt[A->h_loOff[sl] + s * 64 + lane];
                 if (q < 0) continue;
                 const int o = q >> 4, os = q & 15;
-                if (k >= 3) return FFM_OK;                                   // not usable
+                if (k >= 3) { AMUL_GIVE_UP("more than 3 lower neighbours"); }
                 if (inRing(c, o) && os < 3 && c - o < 2048) code[(size_t)8 * c + k] = (unsigned short)((c - o) | (os << 12));
                 else {
-                    if (t >= A_XMAX) return FFM_OK;
+                    if (t >= A_XMAX) { AMUL_GIVE_UP("more than A_XMAX externals in one entry"); }
                     code[(size_t)8 * c + k] = (unsigned short)(A_EXT | t);
                     aext.push_back(make_int2(o, A->h_upOff[o >> 6] + os * 64 + (o & 63))); t++;
                 }
@@ -371,7 +372,7 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
                 if (nb < 0) break;
                 if (inRing(c, nb) && nb - c < 2048) code[(size_t)8 * c + 3 + k] = (unsigned short)(nb - c);
                 else {
-                    if (t >= A_XMAX) return FFM_OK;
+                    if (t >= A_XMAX) { AMUL_GIVE_UP("more than A_XMAX externals in one entry"); }
                     code[(size_t)8 * c + 3 + k] = (unsigned short)(A_EXT | t);
                     aext.push_back(make_int2(nb, -1)); t++;
                 }
