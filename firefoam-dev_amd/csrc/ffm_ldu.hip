@@ -382,7 +382,21 @@ extern "C" int ffm_tile_hint_from_centres(int nCells, const double *C /* [3][nCe
     for (int d = 0; d < 3; d++) L[d] = std::max(hi[d] - lo[d], 1e-300);
     // cells per axis from N and the aspect ratios (cell centres span L = (n-1) h): n_d ~ (N L_d^2/(L_e L_f))^(1/3)
     auto cellsAlong = [&](int d) { const int e = (d + 1) % 3, f = (d + 2) % 3; return std::max(1.0, std::cbrt((double)nCells * L[d] * L[d] / (L[e] * L[f]))); };
-    const double ha = L[a] / std::max(cellsAlong(a) - 1.0, 1.0), hb = L[b] / std::max(cellsAlong(b) - 1.0, 1.0);
+    double ha = L[a] / std::max(cellsAlong(a) - 1.0, 1.0), hb = L[b] / std::max(cellsAlong(b) - 1.0, 1.0);
+    // better where the numbering allows it: the smallest step of the coordinate between consecutive cells (a structured block wraps
+    // its rows by exactly one spacing).  The estimate above is off by a fraction of a percent (centres span (n-1) h, not n h), enough
+    // to put a 17th cell row into a tile: levels of more than 256 cells, split entries, no ring plan for the tiled Amul
+    {
+        double sa = 1e300, sb = 1e300;
+        for (int c = 0; c + 1 < nCells; c++) {
+            const double da = std::fabs(C[(size_t)a * nCells + c + 1] - C[(size_t)a * nCells + c]);
+            const double db = std::fabs(C[(size_t)b * nCells + c + 1] - C[(size_t)b * nCells + c]);
+            if (da > 1e-9 * L[a] && da < sa) sa = da;
+            if (db > 1e-9 * L[b] && db < sb) sb = db;
+        }
+        if (sa < 1e300 && sa >= 0.5 * ha) ha = sa;          // (a step far below the estimate: graded or unstructured, keep the estimate)
+        if (sb < 1e300 && sb >= 0.5 * hb) hb = sb;
+    }
     for (int c = 0; c < nCells; c++) {
         const int ta = (int)std::floor((C[(size_t)a * nCells + c] - lo[a]) / (tileCells * ha) + 1e-9);
         const int tb = (int)std::floor((C[(size_t)b * nCells + c] - lo[b]) / (tileCells * hb) + 1e-9);
