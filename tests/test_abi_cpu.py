@@ -161,3 +161,23 @@ def test_renumbering_is_a_topological_order_of_the_same_dag(mode):
         starts = np.concatenate(([0], change + 1, [N]))
         for a, b in zip(starts[:-1], starts[1:]):
             assert (np.diff(lev[a:b]) >= 0).all()                     # level-major inside a tile
+
+
+def test_tile_hint_from_centres_makes_tiles_of_exactly_the_requested_width(ffm):
+    """ffm_tile_hint_from_centres (host code): 2-D tiles of cell columns from the cell centres alone.  The cell spacing must be the
+    mesh's own (taken from consecutive centres), not an estimate from the bounding box: that one is a fraction of a percent off, which
+    put a 17th row of cells into every tile of the 120 x 60 x 80 steckler room, dependency levels of more than 256 cells and split
+    entries into the tile plan."""
+    H = ffm.hexmesh
+    for (nx, ny, nz), T in (((120, 60, 80), 16), ((30, 15, 20), 8), ((40, 40, 40), 16)):
+        h = 0.05
+        i, j, k = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+        order = np.lexsort((i.ravel(), j.ravel(), k.ravel()))                 # x fastest, as blockMesh numbers its cells
+        C = np.stack([(-1.975 + h * i.ravel()[order]), (0.025 + h * j.ravel()[order]), (-1.975 + h * k.ravel()[order])])
+        hint = ffm.tile_hint_from_centres(C.copy(), tileCells=T)
+        jj, kk = j.ravel()[order], k.ravel()[order]
+        want = (jj // T) + 100000 * (kk // T)
+        # same partition (the labels themselves are the library's business)
+        pairs = np.unique(np.stack([hint, want]), axis=1)
+        assert pairs.shape[1] == len(np.unique(hint)) == len(np.unique(want)) == -(-ny // T) * -(-nz // T)
+        assert np.bincount(np.unique(hint, return_inverse=True)[1]).max() == nx * T * T
