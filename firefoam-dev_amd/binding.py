@@ -325,7 +325,9 @@ class Context:
         return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
 
     def zeros(self, n):
-        return self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+        z = self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)
+        self._ready()               # the fill runs on torch's stream: complete before libffm's stream writes into the tensor
+        return z
 
     def _ready(self):
         # tensors produced on torch's stream must be complete before libffm's stream reads them
@@ -529,6 +531,7 @@ class lduMatrix:
     def reciprocalD(self, preconditioner):
         rD = self.ctx.empty(self.nCells)
         _check(lib().ffm_precond_setup(self.h, PRECONDS[preconditioner], C.c_void_p(rD.data_ptr())), "ffm_precond_setup")
+        self.ctx.sync()
         return rD
 
     def precondition(self, preconditioner, rA, transpose=False):
@@ -536,6 +539,7 @@ class lduMatrix:
         w = self.ctx.empty(self.nCells)
         _check(lib().ffm_precond_apply(self.h, PRECONDS[preconditioner], 1 if transpose else 0,
                                        C.c_void_p(rA.data_ptr()), C.c_void_p(w.data_ptr())), "ffm_precond_apply")
+        self.ctx.sync()
         return w
 
     def smooth(self, psi, source, nSweeps=1, smoother="symGaussSeidel"):
@@ -544,6 +548,7 @@ class lduMatrix:
         self.ctx._ready()
         _check(lib().ffm_gs_smooth(self.h, 1 if smoother == "symGaussSeidel" else 0, nSweeps,
                                    C.c_void_p(psi.data_ptr()), C.c_void_p(source.data_ptr())), "ffm_gs_smooth")
+        self.ctx.sync()
         return psi
 
     def solve(self, psi, source, solver="PCG", preconditioner="DIC", smoother=None, tolerance=1e-6,
@@ -666,14 +671,17 @@ class Thermo:
         self.ctx._ready()
         P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         _check(lib().ffm_thermo_correct_d(self.h, he.numel(), self._Y(Y), P(he), P(p), P(T), P(psi), P(mu), P(alpha)), "ffm_thermo_correct_d")
+        self.ctx.sync()             # the outputs are the caller's tensors: complete before torch's stream reads them
 
     def he(self, Y, T, out):
         self.ctx._ready()
         _check(lib().ffm_thermo_he_d(self.h, T.numel(), self._Y(Y), C.c_void_p(T.data_ptr()), C.c_void_p(out.data_ptr())), "ffm_thermo_he_d")
+        self.ctx.sync()
 
     def Cp(self, Y, T, out):
         self.ctx._ready()
         _check(lib().ffm_thermo_Cp_d(self.h, T.numel(), self._Y(Y), C.c_void_p(T.data_ptr()), C.c_void_p(out.data_ptr())), "ffm_thermo_Cp_d")
+        self.ctx.sync()
 
     def close(self):
         if getattr(self, "h", None):
@@ -776,6 +784,7 @@ class PyrolysisPanel:
         P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         _check(lib().ffm_pyro_couple_d(self.h, P(map), P(Tgas_cell), P(kappaDelta), P(qin), float(emissivity), float(absorptivity), P(rho_b), P(magSf),
                                        P(nf[0]), P(nf[1]), P(nf[2]), float(hocSolid), float(qFuel), P(refT), P(U[0]), P(U[1]), P(U[2])), "ffm_pyro_couple_d")
+        self.ctx.sync()             # refT and U are the caller's tensors: complete before torch's stream reads them
 
     def step_coupled(self, dt, Tback=None):
         """one step with the heat flux of the last couple()"""
@@ -831,6 +840,7 @@ class fvMesh:
         out = self.ctx.zeros(max(self.nNative, 1))
         a = np.ascontiguousarray(faceField, np.float64)
         _check(lib().ffm_faces_to_native(self.h, _hp(a), C.c_void_p(out.data_ptr())), "ffm_faces_to_native")
+        self.ctx.sync()
         return out
 
     def from_native(self, t):

@@ -79,14 +79,14 @@ static int pool_zero(ffm_ctx *c, void *p, size_t bytes)
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
-extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p)
+static int pool_alloc(ffm_ctx *c, size_t bytes, void **p, bool zero)
 {
     if (!c || !p) return FFM_ERR_ARG;
     const size_t cls = pool_class(bytes);
     auto it = c->poolFree.find(cls);
     if (it != c->poolFree.end() && !it->second.empty()) {
         *p = it->second.back(); it->second.pop_back(); c->poolCachedBytes -= cls;
-        FFM_TRY(pool_zero(c, *p, cls));          // as fresh memory: the padding slots of face arrays must read 0
+        if (zero) FFM_TRY(pool_zero(c, *p, cls));          // as fresh memory: the padding slots of face arrays must read 0
         return FFM_OK;
     }
     FFM_HIP(hipSetDevice(c->device));
@@ -96,9 +96,11 @@ extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p)
         FFM_HIP(hipMalloc(p, cls));
     }
     c->poolSize[*p] = cls;
-    FFM_TRY(pool_zero(c, *p, cls));
+    if (zero) FFM_TRY(pool_zero(c, *p, cls));
     return FFM_OK;
 }
+extern "C" int ffm_malloc(ffm_ctx *c, size_t bytes, void **p) { return pool_alloc(c, bytes, p, true); }
+extern "C" int ffm_malloc_uninit(ffm_ctx *c, size_t bytes, void **p) { return pool_alloc(c, bytes, p, false); }
 extern "C" int ffm_free(ffm_ctx *c, void *p)
 {
     if (!c) return FFM_ERR_ARG;

@@ -74,6 +74,9 @@ const char *ffm_version(void);
  * OpenFOAM shim) can hold fields on the GPU                                  */
 int ffm_malloc(ffm_ctx *ctx, size_t bytes, void **ptr_d);
 int ffm_free(ffm_ctx *ctx, void *ptr_d);
+/* the same allocator without the zero-fill: for a block whose every byte the caller overwrites next (the result of a field
+ * operation, a copy) -- on small meshes the fill kernel costs as much as the operation */
+int ffm_malloc_uninit(ffm_ctx *ctx, size_t bytes, void **ptr_d);
 /* ffm_malloc / ffm_free go through a stream-ordered caching allocator (freed blocks are reused by later allocations of the same
  * size class on the context stream, without synchronising; every block is handed out zero-filled); ffm_ctx_trim returns the cached
  * blocks to the runtime */
