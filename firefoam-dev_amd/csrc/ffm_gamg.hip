@@ -289,6 +289,7 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
         const char *e = getenv("FFM_GAMG_TILES");
         if (finest->sweepMode == 2 && finest->grpCell && finest->nGroups > 0 && !(e && atoi(e) == 0)) {
             std::vector<int> gc((size_t)finest->nGroups + 1);
+            FFM_HIP(hipStreamSynchronize(ctx->stream));              // the table was uploaded on the context's (non-blocking) stream
             FFM_HIP(hipMemcpy(gc.data(), finest->grpCell, sizeof(int) * gc.size(), hipMemcpyDeviceToHost));
             hint.assign(nCells, 0);
             for (int g = 0; g < finest->nGroups; g++)

@@ -671,6 +671,7 @@ static bool flow_usable(ffm_ldu *A)
             for (int i = 0, n = A->h_bwdLevelStart[b + 1] - A->h_bwdLevelStart[b]; i < n; i++) ord[k++] = A->h_bwdFirstCell[b] + i;
         if (k != ord.size()) return false;
     } else {
+        if (hipStreamSynchronize(A->ctx->stream) != hipSuccess) return false;        // (uploaded on the context's non-blocking stream)
         if (hipMemcpy(ord.data(), A->bwdOrder, sizeof(int) * ord.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
     }
     if (hipMalloc((void **)&A->flowOrder, sizeof(int) * ord.size()) != hipSuccess) return false;
