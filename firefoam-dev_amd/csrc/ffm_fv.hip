@@ -100,6 +100,7 @@ extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, con
         std::vector<int> nat2caller(nNat, -1);
         for (int f = 0; f < F; f++) nat2caller[A->h_callerToNative[f]] = f;
         std::vector<int> hUpNbr(std::max(nNat, 1));
+        FFM_HIP(hipStreamSynchronize(A->ctx->stream));              // (the tables were uploaded on the context's non-blocking stream)
         FFM_HIP(hipMemcpy(hUpNbr.data(), A->upNbr, sizeof(int) * nNat, hipMemcpyDeviceToHost));
         std::vector<int> hUpOff(A->nSlices + 1);
         FFM_HIP(hipMemcpy(hUpOff.data(), A->upOff, sizeof(int) * (A->nSlices + 1), hipMemcpyDeviceToHost));
