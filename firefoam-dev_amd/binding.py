@@ -228,6 +228,8 @@ def lib():
         "ffm_plume_set_solvers": ([vp, C.c_int], C.c_int),
         "ffm_plume_set_radiation": ([vp, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
         "ffm_plume_set_radiation_model": ([vp, C.c_double, C.c_double, C.c_double], C.c_int),
+        "ffm_plume_set_initial_state": ([vp, C.POINTER(C.c_void_p), hp, hp, hp, C.c_double], C.c_int),
+        "ffm_plume_override_mv_weights": ([vp, hp], C.c_int),
         "ffm_plume_ncells": ([vp], C.c_int),
         "ffm_plume_nfaces": ([vp], C.c_int),
         "ffm_plume_get_field": ([vp, C.c_char_p, hp], C.c_int),
@@ -624,6 +626,23 @@ class Plume:
     def set_radiation_model(self, absorption, Ehrr1, Ehrr2):
         """the reference's absorption / emission model and radiation->Sh in the enthalpy equation (ffm_plume_set_radiation_model)"""
         _check(lib().ffm_plume_set_radiation_model(self.h, float(absorption), float(Ehrr1), float(Ehrr2)), "ffm_plume_set_radiation_model")
+
+    def set_initial_state(self, Y, h, Yamb, Yin, hAmb):
+        """start state (Y[5][N], h[N] in natural cell order) and the species' / enthalpy's ambient and inflow values; redoes the
+        hydrostatic initialisation (ffm_plume_set_initial_state)"""
+        Y = [np.ascontiguousarray(y, np.float64) for y in Y]; h = np.ascontiguousarray(h, np.float64)
+        if len(Y) != 5 or any(y.shape != (self.nCells,) for y in Y) or h.shape != (self.nCells,):
+            raise ValueError("set_initial_state: five species fields and h of nCells values each")
+        yp = (C.c_void_p * 5)(*[y.ctypes.data for y in Y])
+        a = np.ascontiguousarray(Yamb, np.float64); b = np.ascontiguousarray(Yin, np.float64)
+        _check(lib().ffm_plume_set_initial_state(self.h, yp, _hp(h), _hp(a), _hp(b), float(hAmb)), "ffm_plume_set_initial_state")
+
+    def override_mv_weights(self, w):
+        """the next step's species / h convection weights, natural face order (ffm_plume_override_mv_weights; tests)"""
+        w = np.ascontiguousarray(w, np.float64)
+        if w.shape != (self.nFaces,):
+            raise ValueError("override_mv_weights: one weight per internal face")
+        _check(lib().ffm_plume_override_mv_weights(self.h, _hp(w)), "ffm_plume_override_mv_weights")
 
     def set_tight(self, on=True):
         _check(lib().ffm_plume_set_tight(self.h, 1 if on else 0), "ffm_plume_set_tight")

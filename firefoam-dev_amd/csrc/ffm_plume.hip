@@ -91,6 +91,9 @@ struct ffm_plume {
     int nx = 0, ny = 0, nz = 0, N = 0, nOwn = 0, F = 0, nNat = 0, B = 0;   // N = owned + ghost cells
     double h = 0.05, dt = 1e-3, rdt = 1e3, time = 0.0;
     std::vector<int> newToOld;             // library cell order -> natural blockMesh cell id
+    std::vector<int> faceNewToOld;         // library (caller-side) face order -> natural blockMesh face id
+    bool mvOverride = false;               // tests: the next step convects the species and h with weights handed in (ffm_plume_override_mv_weights)
+    double hAmb = 0.0;                     // inletOutlet reference value of h on the open patches
     std::vector<double *> pool;            // every device buffer, for destroy
     // fields
     double *Y[NSP], *Y0[NSP], *T, *hs, *hs0, *U[3], *U0[3], *p, *p0, *p_rgh, *p_rgh0, *psi, *psi0, *rho, *rho0, *K, *K0, *dpdt;
@@ -634,7 +637,8 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         const double *rho = P->rho, *fuel = P->Y[2], *o2 = P->Y[0];
         forN(P, N, [=] __device__(long i) { const double w = rho[i] * fmin(fuel[i], o2[i] / S_O2) / TAU; wFuel[i] = w; Qdot[i] = w * HC; Yt[i] = 0.0; });
     }
-    if (P->mvSelection) {
+    if (P->mvSelection && P->mvOverride) P->mvOverride = false;      // weights of this step were handed in: wMv stays as uploaded
+    else if (P->mvSelection) {
         // ---- mvConvection: the common limiter over the five species and h, from the fields as they are now
         int sp4[NSP - 1], n4 = 0;
         for (int i = 0; i < NSP; i++) if (i != INERT) sp4[n4++] = i;
@@ -843,7 +847,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     for (int k = 0; k < nz; k++) for (int j = 0; j < ny; j++) for (int i = 0; i < nx; i++) hint[cellOf(i, j, k)] = ffm_tile_label(j / tileEdge, k / tileEdge);
     std::vector<int> c2(N), f2(F);
     { FfmStageTimer tm_("plume_create: renumber_hint"); FFM_TRY(ffm_renumber_hint((int)nOwn, (int)nGhost, F, l.data(), u.data(), hint.data(), c2.data(), f2.data())); }
-    P->newToOld = c2;
+    P->newToOld = c2; P->faceNewToOld = f2;
     std::vector<int> oldToNew(N);
     for (long c = 0; c < N; c++) oldToNew[c2[c]] = (int)c;
     std::vector<int> l2(F), u2(F); std::vector<signed char> fd2(F), sg2(F);
@@ -1071,6 +1075,54 @@ extern "C" int ffm_plume_set_radiation_model(ffm_plume *P, double absorption, do
     if (!P->radE) { P->radE = dalloc(P, P->N); P->radShSu = dalloc(P, P->N); P->radShSp = dalloc(P, P->N); }
     if (!P->radE || !P->radShSu || !P->radShSp) return FFM_ERR_HIP;
     P->radA = absorption; P->Ehrr1 = Ehrr1; P->Ehrr2 = Ehrr2; P->radCoupled = true;
+    return FFM_OK;
+}
+// Start state and boundary values other than the quiescent ambient / pure-fuel inflow (tests: a state in which no transported
+// field is uniform, tests/test_plume_gpu.py).  Y[5], h: cell fields in natural blockMesh order of the (single) block; Yamb / Yin:
+// the inletOutlet and inlet values of the species, hAmb the inletOutlet value of h.  Only before the first step: the hydrostatic
+// initialisation (solver/phrghEqn.H) is redone from the new state.
+extern "C" int ffm_plume_set_initial_state(ffm_plume *P, const double *const *Y, const double *h, const double *Yamb, const double *Yin, double hAmb)
+{
+    if (!P || !Y || !h || !Yamb || !Yin) return FFM_ERR_ARG;
+    if (P->stepNo != 0 || P->N != P->nOwn) { ffm_set_error("plume: the start state can be set on a single block before the first step only"); return FFM_ERR_ARG; }
+    PL_HIP(hipSetDevice(P->ctx->device));
+    const int N = P->N, B = P->B;
+    std::vector<double> v(N);
+    auto up = [&](double *dst, const double *nat) -> int {
+        for (int c = 0; c < N; c++) v[c] = nat[P->newToOld[c]];
+        return ffm_memcpy_h2d(P->ctx, dst, v.data(), sizeof(double) * N);
+    };
+    for (int i = 0; i < NSP; i++) FFM_TRY(up(P->Y[i], Y[i]));
+    FFM_TRY(up(P->hs, h));
+    P->hAmb = hAmb;
+    const double *kind = P->kind_d; double *rH = P->refH;
+    for (int i = 0; i < NSP; i++) {
+        double *r = P->refY[i]; const double a = Yamb[i], b = Yin[i];
+        forN(P, B, [=] __device__(long k) { r[k] = kind[k] < 0.5 ? b : kind[k] > 1.5 ? a : 0.0; });
+    }
+    forN(P, B, [=] __device__(long k) { rH[k] = kind[k] < 0.5 ? CP * (T_IN - TREF) : kind[k] > 1.5 ? hAmb : 0.0; });
+    double *p = P->p, *ph = P->ph_rgh;
+    forN(P, N, [=] __device__(long c) { p[c] = PREF; ph[c] = 0.0; });
+    P->log.clear();
+    standin_thermo(P);
+    mul(P, P->rho, P->psi, P->p, N);
+    FFM_TRY(hydrostatic_init(P));
+    PL_HIP(hipStreamSynchronize(P->ctx->stream));
+    return FFM_OK;
+}
+
+// Tests (the deciding test of the multi-step parity question): the NEXT ffm_plume_step convects the species and h with these face
+// weights instead of evaluating the multivariateSelection limiter; w[F] in natural blockMesh face order of the (single) block.
+extern "C" int ffm_plume_override_mv_weights(ffm_plume *P, const double *w)
+{
+    if (!P || !w) return FFM_ERR_ARG;
+    if (!P->mvSelection || P->N != P->nOwn) { ffm_set_error("plume: weights can be handed in on a single block with the common limiter only"); return FFM_ERR_ARG; }
+    PL_HIP(hipSetDevice(P->ctx->device));
+    std::vector<double> v(std::max<long>(P->nNat, 1), 0.0);
+    const std::vector<int> &c2n = P->A->h_callerToNative;
+    for (int f = 0; f < P->F; f++) v[c2n[f]] = w[P->faceNewToOld[f]];
+    FFM_TRY(ffm_memcpy_h2d(P->ctx, P->wMv, v.data(), sizeof(double) * P->nNat));
+    P->mvOverride = true;
     return FFM_OK;
 }
 extern "C" int ffm_plume_set_solvers(ffm_plume *P, int stecklerSelection) { if (!P) return FFM_ERR_ARG; P->stecklerSolvers = stecklerSelection != 0; return FFM_OK; }

@@ -878,9 +878,12 @@ int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double
             FFM_TRY(ffm_halo_update(A, psi, bP, A->ifBou, +1.0));
             bUse = bP;
         }
+        // decomposed block: every sweep starts from the neighbour ranks' current values, whatever form the sweep takes (the
+        // reference's smoothers update the interfaces before every sweep: GaussSeidelSmoother.C, initMatrixInterfaces /
+        // updateMatrixInterfaces inside the sweep loop) -- the single-workgroup, dataflow and per-level forms read psi of the ghost cells
+        if (!A->ghNbrRank.empty()) FFM_TRY(ffm_ghost_exchange(A, psi));
         if (A->sweepMode == 2 && ffm_tile_gs_usable(A)) {
-            if (!A->ghNbrRank.empty()) {        // decomposed block: refresh the ghost values, move their terms into bPrime
-                FFM_TRY(ffm_ghost_exchange(A, psi));
+            if (!A->ghNbrRank.empty()) {        // move the ghost cells' terms into bPrime
                 if (bUse == b) { hipLaunchKernelGGL(k_copy, dim3(sgrid(N)), dim3(256), 0, s, N, bP, b); bUse = bP; }
                 FFM_TRY(ffm_tile_gs_ghost_terms(A, psi, bP));
             }

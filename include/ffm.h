@@ -432,6 +432,13 @@ int ffm_plume_set_radiation(ffm_plume *plume, int solverFreq, int nPhi, int nThe
  * EEqn gets radiation->Sh(thermo, he) = Ru - fvm::Sp(4 Rp T^3/Cpv, he) - Rp T^3 (T - 4 he/Cpv), Rp = 4 a sigma, Ru = a G - E
  * (radiationModel.C:229-244; solver/YEEqn.H:101).  Without this call the rays keep the round-1 stand-in (a = 0.1, no E, no Sh). */
 int ffm_plume_set_radiation_model(ffm_plume *plume, double absorption, double Ehrr1, double Ehrr2);
+/* tests: a start state and boundary values other than the quiescent ambient / pure-fuel inflow -- Y[5] and h as cell fields in
+ * natural blockMesh order, Yamb / Yin the inletOutlet and inlet values of the species, hAmb the inletOutlet value of h; redoes
+ * the hydrostatic initialisation (solver/phrghEqn.H).  Single block, before the first step.                                   */
+int ffm_plume_set_initial_state(ffm_plume *plume, const double *const *Y, const double *h, const double *Yamb, const double *Yin, double hAmb);
+/* tests: the next step convects the species and h with the face weights w[F] (natural face order) instead of evaluating the
+ * multivariateSelection limiter of solver/YEEqn.H:1-10 -- separates the limiter's conditioning from everything else in a step */
+int ffm_plume_override_mv_weights(ffm_plume *plume, const double *w);
 int ffm_plume_ncells(const ffm_plume *p);
 int ffm_plume_nfaces(const ffm_plume *p);
 int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);

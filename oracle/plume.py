@@ -149,9 +149,36 @@ def ray_set(nPhi=2, nTheta=4):
     return rays
 
 
+def conditioned_state(m, Y_amb, h_amb, eps=1e-3):
+    """A start state in which no transported field is uniform anywhere: every specie and h carries a smooth, monotone variation of
+    relative size eps over the box (its own direction and curvature per field, so that no two fields are multiples of one another),
+    the inert specie takes the remainder.  For the multi-step parity tests: the limiter r = 2 (d.gradc)/(phi_N - phi_P) - 1 of
+    NVDTVD is then formed from differences ~1e-5 of the field instead of solver noise, i.e. well-conditioned on every face."""
+    lo, hi = m.C.min(axis=0), m.C.max(axis=0)
+    s = (m.C - lo) / np.where(hi > lo, hi - lo, 1.0)
+    x, y, z = s[:, 0], s[:, 1], s[:, 2]
+    dirs = np.array([[1.0, 0.6, 0.8], [0.7, 1.0, 0.5], [0.5, 0.8, 1.0], [0.9, 0.5, 0.7], [0.0, 0.0, 0.0], [0.8, 0.9, 0.6]])
+    shape = lambda a: (a[0] * x + a[1] * y + a[2] * z) + 0.25 * (a[2] * x * x + a[0] * y * y + a[1] * z * z)
+    Y = np.empty((len(SPECIES), m.nCells))
+    for i in range(len(SPECIES)):
+        if i != INERT:
+            Y[i] = Y_amb[i] * (1.0 + eps * shape(dirs[i]))
+    Y[INERT] = 1.0 - sum(Y[i] for i in range(len(SPECIES)) if i != INERT)
+    return Y, h_amb * (1.0 + eps * shape(dirs[5]))
+
+
+# composition / enthalpy of the conditioned case (tests): no exact zeros, inflow and ambient values distinct in every field
+Y_AMB_COND = np.array([0.22, 0.012, 0.006, 0.015, 0.747])
+Y_IN_COND = np.array([0.03, 0.02, 0.88, 0.025, 0.045])
+H_AMB_COND = CP * 2.0                                  # ambient at Tref + 2 K
+
+
 class Plume:
-    def __init__(self, n, h=0.05, dt=1e-3, solvers=None, mesh=None):
+    def __init__(self, n, h=0.05, dt=1e-3, solvers=None, mesh=None, conditioned=False):
+        """conditioned: the start state and boundary values of conditioned_state() / Y_AMB_COND / Y_IN_COND / H_AMB_COND instead of
+        the quiescent ambient with pure-fuel inflow"""
         self.m = m = mesh if mesh is not None else make_mesh(n, h)
+        self.Y_amb, self.Y_in, self.h_amb = (Y_AMB_COND, Y_IN_COND, H_AMB_COND) if conditioned else (Y_AMB, Y_IN, 0.0)
         self.dt, self.rDeltaT = dt, 1.0 / dt
         self.sol = solvers or Solvers()
         N = m.nCells
@@ -162,6 +189,9 @@ class Plume:
         self.Y = np.tile(Y_AMB[:, None], (1, N))
         self.T = np.full(N, TREF)
         self.h = CP * (self.T - TREF)
+        if conditioned:
+            self.Y, self.h = conditioned_state(m, self.Y_amb, self.h_amb)
+            self.T = TREF + self.h / CP
         self.U = np.zeros((3, N))
         self.p = np.full(N, PREF)
         self.p_rgh = np.zeros(N)
@@ -375,24 +405,25 @@ class Plume:
         # the inert one included, and h; solver/createFields.H `fields`), computed when the scheme is constructed, i.e. from the fields
         # at the start of YEEqn.H -- so that all species are interpolated with the same weights.  Pinned by the golden log through
         # oracle/steckler_case.py (tests/test_steckler_whole_log_cpu.py).  mv_selection = False: one limiter per field (round 1).
-        bch = self.bc_scalar(CP * (T_IN - TREF) if self.inlet_h is None else self.inlet_h, 0.0, floor_fixed=0.0)
+        bch = self.bc_scalar(CP * (T_IN - TREF) if self.inlet_h is None else self.inlet_h, self.h_amb, floor_fixed=0.0)
         if self.mv_selection:
             lim = fv.limited_limiter(m, "limitedLinear", self.phi, self.h, fv.grad(m, self.h, bch.values(m, self.h)), 1.0)
             Ytb = [np.zeros(p.size) for p in m.patches]
             for i in range(len(SPECIES)):
                 if i == INERT:
                     continue
-                Yb = self.bc_scalar(Y_IN[i], Y_AMB[i]).values(m, self.Y[i])
+                Yb = self.bc_scalar(self.Y_in[i], self.Y_amb[i]).values(m, self.Y[i])
                 Ytb = [a + np.maximum(b, 0.0) for a, b in zip(Ytb, Yb)]
                 lim = np.minimum(lim, fv.limited_limiter(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0))
             Nb = [np.maximum(1.0 - b, 0.0) for b in Ytb]           # the inert specie's patch values: Y[inertIndex] == 1 - Yt; .max(0)
             lim = np.minimum(lim, fv.limited_limiter(m, "limitedLinear01", self.phi, self.Y[INERT], fv.grad(m, self.Y[INERT], Nb), 1.0))
             w_mv = lim * m.weights + (1.0 - lim) * fv.pos0(self.phi)
+            self.w_mv_last = w_mv               # tests hand these to the device (ffm_plume_override_mv_weights): the deciding test
         Yt = np.zeros(m.nCells)
         for i in range(len(SPECIES)):
             if i == INERT:
                 continue
-            bc = self.bc_scalar(Y_IN[i], Y_AMB[i])
+            bc = self.bc_scalar(self.Y_in[i], self.Y_amb[i])
             Yb = bc.values(m, self.Y[i])
             w = w_mv if self.mv_selection else fv.limited_weights(m, "limitedLinear01", self.phi, self.Y[i], fv.grad(m, self.Y[i], Yb), 1.0)
             E = fv.fvm_ddt(m, rdt, self.rho, self.rho0, self.Y0[i])

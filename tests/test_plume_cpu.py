@@ -20,3 +20,27 @@ def test_limited_weights_of_a_noise_field_are_ill_conditioned():
     other.h = other.h + 1e-19 * np.random.default_rng(1).standard_normal(other.h.shape)
     ref.step(); other.step()
     assert 1e-8 < rel_l2(other.h, ref.h) < 1e-5
+
+
+def test_the_conditioned_start_state_is_well_conditioned():
+    """The counterpart: in the conditioned case (oracle/plume.py:conditioned_state -- every specie and h varies smoothly by 1e-3 of
+    its value over the box, inflow and ambient values distinct, no exact zeros) the limiters are formed from differences of the
+    fields, not of solver noise, and a relative perturbation of 1e-14 of the transported fields after the second step stays at that
+    level over the following steps.  Two evaluations of the same formulas that differ in rounding must therefore agree to 1e-8 there
+    (tests/test_plume_multistep_gpu.py holds the device to it); a larger difference would be a defect, not conditioning."""
+    from oracle import plume
+    ref = plume.Plume((12, 16, 12), conditioned=True)
+    for Yi in ref.Y:
+        assert Yi.min() > 1e-3 and np.ptp(Yi) > 1e-6
+    assert np.ptp(ref.h) > 1e-4 * np.abs(ref.h).max()
+    ref.step(); ref.step()
+    other = copy.deepcopy(ref)
+    rng = np.random.default_rng(1)
+    other.h = other.h * (1.0 + 1e-14 * rng.standard_normal(other.h.shape))
+    other.Y = other.Y * (1.0 + 1e-14 * rng.standard_normal(other.Y.shape))
+    for _ in range(4):
+        ref.step(); other.step()
+        assert [pf["nIterations"] for _, pf in ref.sol.log] == [pf["nIterations"] for _, pf in other.sol.log]
+    f, g = ref.fields(), other.fields()
+    for name in ("h", "T", "rho", "Ux", "Uy", "Uz", "O2", "H2O", "C3H8", "CO2", "N2"):
+        assert rel_l2(g[name], f[name]) < 1e-11, (name, rel_l2(g[name], f[name]))

@@ -371,3 +371,100 @@ def test_reference_phrghEqn_reproduces_the_golden_log_on_the_device(O, ffm, ctx,
         assert abs(float(g_[2]) - float(w_[2])) <= 1e-6 * float(w_[2]) and abs(float(g_[3]) - float(w_[3])) <= 1e-6 * float(w_[3])
     assert out.splitlines()[0] == golden_lines[0]                      # the first line: every character
     A.close()
+
+
+def test_reference_equation_files_hold_1e8_over_six_steps_on_the_conditioned_case(O, ffm, ctx):
+    """The multi-step parity question of tests/test_plume_multistep_gpu.py asked of the path the reference's files take: the
+    unchanged solver/rhoEqn.H, UEqn.H, YEEqn.H (with its `Gauss multivariateSelection` common limiter) and pEqn.H over the Foam
+    layer, six consecutive steps on the device-resident state of the conditioned plume case (every specie and h smoothly varying,
+    no exact zeros, inflow and ambient values distinct: the limiter is well-conditioned on every face), every field within 1e-8
+    rel-L2 of the oracle's after EVERY step with identical iteration counts."""
+    from oracle import plume
+    so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
+    if not os.path.exists(so):
+        pytest.skip("libffm_refsnippets.so not built (needs /root/reference at build time)")
+    lib = C.CDLL(so)
+    shape = (12, 16, 12)
+    ref = plume.Plume(shape, conditioned=True); ref.stored_bc = True
+    m = ref.m
+    N, F = m.nCells, m.nFaces
+    B = sum(p.size for p in m.patches)
+    cOrd, fOrd = ffm.renumber_levels(N, m.l, m.u)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(N, m.l, m.u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, N, l2, u2)
+    patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
+    mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
+    mesh.set_face_centres(m.Cf[fOrd].T.copy())
+    dp = C.POINTER(C.c_double)
+    keep = []
+
+    def P(a):
+        a = np.ascontiguousarray(a, np.float64); keep.append(a)
+        return a.ctypes.data_as(dp)
+
+    def PP(arrs):
+        arrs = [np.ascontiguousarray(a, np.float64) for a in arrs]; keep.append(arrs)
+        arr = (dp * len(arrs))(*[a.ctypes.data_as(dp) for a in arrs]); keep.append(arr)
+        return arr
+    cell = lambda a: np.asarray(a)[..., cOrd]
+    face = lambda a: np.asarray(a)[fOrd]
+    bnd = lambda lst: np.concatenate(lst)
+    per = lambda fn: bnd([fn(p) for p in m.patches])
+    is_open = lambda p: p.name not in ("inlet", "floor")
+    fU = np.concatenate([per(lambda p, d=d: np.where(np.abs(p.Sf[:, d]) > 0, 0.0, -1.0) if is_open(p) else np.ones(p.size)) for d in range(3)])
+    refU = np.concatenate([per(lambda p, d=d: np.full(p.size, plume.U_IN if (p.name == "inlet" and d == 1) else 0.0)) for d in range(3)])
+    fixesU = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0))
+    fY = per(lambda p: np.full(p.size, 1.0 if p.name == "inlet" else (0.0 if p.name == "floor" else -1.0)))
+    refY = [per(lambda p, i=i: np.full(p.size, ref.Y_in[i] if p.name == "inlet" else (ref.Y_amb[i] if is_open(p) else 0.0))) for i in range(5)]
+    fH = per(lambda p: np.full(p.size, -1.0 if is_open(p) else 1.0))
+    refH = per(lambda p: np.full(p.size, plume.CP * (plume.T_IN - plume.TREF) if p.name == "inlet" else (ref.h_amb if is_open(p) else 0.0)))
+    fluxMask = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0))
+    totalMask = per(lambda p: np.full(p.size, 1.0 if is_open(p) else 0.0))
+    ghfb = bnd([p.Cf @ plume.G - ref.ghRef for p in m.patches])
+    out = dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), Y=[np.empty(N) for _ in range(5)],
+               T=np.empty(N), K=np.empty(N), dpdt=np.empty(N), phi=np.empty(F), phib=np.empty(B), p_rghB=np.empty(B))
+    nit = (C.c_int * 32)()
+    cs = SnippetCase(
+        deltaT=ref.dt, RR=plume.RR, Cp=plume.CP, Tref=plume.TREF, pRef=plume.PREF, mu=plume.MU, Pr=plume.PR, sO2=plume.S_O2, HC=plume.HC,
+        tau=plume.TAU, nSpecies=5, inertIndex=plume.INERT, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
+        rho=P(cell(ref.rho)), U=P(cell(ref.U)), p=P(cell(ref.p)), p_rgh=P(cell(ref.p_rgh)), h=P(cell(ref.h)), Y=PP([cell(ref.Y[i]) for i in range(5)]),
+        K=P(cell(ref.K)), dpdt=P(cell(ref.dpdt)), phiF=P(face(ref.phi)), phiB=P(bnd(ref.phib)),
+        gh=P(cell(ref.gh)), ghfF=P(face(ref.ghf)), ghfB=P(ghfb),
+        fU=P(fU), refU=P(refU), fixesU=P(fixesU), fY=P(fY), refY=PP(refY), fH=P(fH), refH=P(refH),
+        fluxMaskP=P(fluxMask), totalMaskP=P(totalMask), ph_rgh_b=P(bnd(ref.ph_rgh_b)), p_rghB=P(bnd(ref.p_rgh_b)),
+        rhoOut=out["rho"].ctypes.data_as(dp), UOut=out["U"].ctypes.data_as(dp), pOut=out["p"].ctypes.data_as(dp),
+        p_rghOut=out["p_rgh"].ctypes.data_as(dp), hOut=out["h"].ctypes.data_as(dp),
+        TOut=out["T"].ctypes.data_as(dp), KOut=out["K"].ctypes.data_as(dp), dpdtOut=out["dpdt"].ctypes.data_as(dp),
+        phiOutF=out["phi"].ctypes.data_as(dp), phiOutB=out["phib"].ctypes.data_as(dp), p_rghBOut=out["p_rghB"].ctypes.data_as(dp),
+        nIterOut=nit, nIterCap=32)
+    yout = (dp * 5)(*[a.ctypes.data_as(dp) for a in out["Y"]]); keep.append(yout)
+    cs.YOut = yout
+    os.environ["FFM_FOAM_QUIET"] = "1"
+    lib.firefoam_snippets_create.restype = C.c_void_p
+    lib.firefoam_snippets_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(SnippetCase)]
+    lib.firefoam_snippets_advance.restype = C.c_int
+    lib.firefoam_snippets_advance.argtypes = [C.c_void_p, C.POINTER(SnippetCase), C.c_int]
+    lib.firefoam_snippets_destroy.argtypes = [C.c_void_p]
+    solver = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(cs))
+    inv = np.empty(N, np.int64); inv[cOrd] = np.arange(N)
+    finv = np.empty(F, np.int64); finv[fOrd] = np.arange(F)
+    worst = 0.0
+    for step in range(6):
+        n = lib.firefoam_snippets_advance(solver, C.byref(cs), 1)
+        ref.step()
+        its_ref = [pf["nIterations"] for _, pf in ref.sol.log]
+        assert list(nit[:n]) == its_ref, (step, list(nit[:n]), its_ref)
+        f = ref.fields()
+        got = {"rho": out["rho"], "p": out["p"], "T": out["T"], "h": out["h"], "K": out["K"], "Ux": out["U"][0], "Uy": out["U"][1], "Uz": out["U"][2]}
+        for i, sname in enumerate(plume.SPECIES):
+            got[sname] = out["Y"][i]
+        errs = {name: rel_l2(a[inv], f[name]) for name, a in got.items()}
+        errs["phi"] = rel_l2(out["phi"][finv], ref.phi)
+        bad = {k: v for k, v in errs.items() if not v < 1e-8}
+        assert not bad, (step, bad)
+        e = np.linalg.norm(out["p_rgh"][inv] - f["p_rgh"]) / np.linalg.norm(f["p_rgh"] - f["p_rgh"].mean())
+        assert e < 1e-7, (step, "p_rgh", e)
+        worst = max(worst, max(errs.values()))
+    lib.firefoam_snippets_destroy(solver)
+    print("reference files, conditioned case, worst rel-L2 over six steps: %.2e" % worst)
+    A.close()
