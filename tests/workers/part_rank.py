@@ -60,7 +60,7 @@ else:
         out = A.smooth(ctx.to_device(sub.field(O.hash_u(0xF5, np.arange(N)))), ctx.to_device(sub.field(source)), nSweeps=2,
                        smoother="symGaussSeidel" if precond == "SYMGS" else "GaussSeidel")
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), psi=out.cpu().numpy()[:sub.nOwned], gcell=sub.gcell[:sub.nOwned], nIter=2,
-                 initialResidual=0.0, nGhost=sub.nGhost, nNbr=len(sub.nbrRank), sweepMode=A.sweep_mode() if hasattr(A, "sweep_mode") else -1)
+                 initialResidual=0.0, nGhost=sub.nGhost, nNbr=len(sub.nbrRank), sweepMode=A.sweep_mode)
         A.close(); ctx.close()
         sys.exit(0)
     psi_d = ctx.zeros(sub.nOwned + sub.nGhost)
