@@ -141,6 +141,11 @@ def lib():
         "ffm_pyro_phiGas_d": ([vp], C.c_void_p),
         "ffm_pyro_couple_d": ([vp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp], C.c_int),
         "ffm_pyro_qSurf_d": ([vp], C.c_void_p),
+        "ffm_pyro_set_model": ([vp, C.c_int, C.c_int, C.c_int], C.c_int),
+        "ffm_pyro_set_back": ([vp, C.c_int, C.c_double, C.c_double], C.c_int),
+        "ffm_pyro_set_surface_radiation": ([vp] + [C.c_double] * 4, C.c_int),
+        "ffm_pyro_evolve_d": ([vp, C.c_double, dp, dp, dp, dp, C.c_double, C.c_double], C.c_int),
+        "ffm_pyro_gas_side_d": ([vp, dp, dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp], C.c_int),
         "ffm_pyro_destroy": ([vp], C.c_int),
         "ffm_thermo_create": ([vp, C.c_int] + [hp] * 8 + [C.c_double, C.POINTER(vp)], C.c_int),
         "ffm_thermo_correct_d": ([vp, C.c_long, C.POINTER(vp), dp, dp, dp, dp, dp, dp], C.c_int),
@@ -804,6 +809,37 @@ class PyrolysisPanel:
         _check(lib().ffm_pyro_couple_d(self.h, P(map), P(Tgas_cell), P(kappaDelta), P(qin), float(emissivity), float(absorptivity), P(rho_b), P(magSf),
                                        P(nf[0]), P(nf[1]), P(nf[2]), float(hocSolid), float(qFuel), P(refT), P(U[0]), P(U[1]), P(U[2])), "ffm_pyro_couple_d")
         self.ctx.sync()             # refT and U are the caller's tensors: complete before torch's stream reads them
+
+    def set_model(self, model="reactingOneDim", alphaScheme="linear", kappaScheme="linear", back=None, radiation=None):
+        """the region's dictionaries: pyrolysisModel (reactingOneDim | reactingOneDim21), the two laplacian schemes (linear | harmonic),
+        back face None | ("fixed", T) | ("constH", h, Tinf), radiation None | dict(v=(absorptivity, emissivity), char=(...))"""
+        if model not in ("reactingOneDim", "reactingOneDim21"):
+            raise ValueError("pyrolysisModel %r is not built" % model)
+        _check(lib().ffm_pyro_set_model(self.h, 1 if model == "reactingOneDim21" else 0, 1 if alphaScheme == "harmonic" else 0,
+                                        1 if kappaScheme == "harmonic" else 0), "ffm_pyro_set_model")
+        if back is None:
+            _check(lib().ffm_pyro_set_back(self.h, 0, 0.0, 298.15), "ffm_pyro_set_back")
+        elif back[0] == "fixed":
+            _check(lib().ffm_pyro_set_back(self.h, 1, 0.0, float(back[1])), "ffm_pyro_set_back")
+        else:
+            _check(lib().ffm_pyro_set_back(self.h, 2, float(back[1]), float(back[2])), "ffm_pyro_set_back")
+        if radiation is not None:
+            (aV, eV), (aC, eC) = radiation["v"], radiation["char"]
+            _check(lib().ffm_pyro_set_surface_radiation(self.h, float(aV), float(eV), float(aC), float(eC)), "ffm_pyro_set_surface_radiation")
+
+    def evolve(self, dt, Tgas_cell, kappaDelta, qin, emissivity=1.0, absorptivity=1.0, map=None):
+        """evolveRegion with the coupled wall condition evaluated inside the step (ffm_pyro_evolve_d); torch CUDA tensors"""
+        self.ctx._ready()
+        P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _check(lib().ffm_pyro_evolve_d(self.h, float(dt), P(map), P(Tgas_cell), P(kappaDelta), P(qin), float(emissivity), float(absorptivity)), "ffm_pyro_evolve_d")
+
+    def gas_side(self, rho_b, magSf, nf, hocSolid, qFuel, refT, U, emissivity=None, map=None):
+        """the gas-side patch values from the panel's new state (ffm_pyro_gas_side_d)"""
+        self.ctx._ready()
+        P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        _check(lib().ffm_pyro_gas_side_d(self.h, P(map), P(rho_b), P(magSf), P(nf[0]), P(nf[1]), P(nf[2]), float(hocSolid), float(qFuel), P(refT),
+                                         P(U[0]), P(U[1]), P(U[2]), P(emissivity)), "ffm_pyro_gas_side_d")
+        self.ctx.sync()
 
     def step_coupled(self, dt, Tback=None):
         """one step with the heat flux of the last couple()"""

@@ -459,7 +459,7 @@ int ffm_pyro_create(ffm_ctx *ctx, int nCol, int nLay, double thickness, double f
 int ffm_pyro_set_solids(ffm_pyro *p, const double *virgin /* rho Cp kappa Hf */, const double *charred);
 int ffm_pyro_set_reaction(ffm_pyro *p, double A, double Ta, double Tcrit, double n);
 int ffm_pyro_step(ffm_pyro *p, double deltaT, const double *qSurf_d, int backFixed, double Tback);
-/* name: rho, Yw, T, h -> host [nCol][nLay]; Tsurf, phiGas -> host [nCol] */
+/* name: rho, Yw, T, h, alpha -> host [nCol][nLay]; Tsurf, phiGas, qSurf, Twall -> host [nCol] */
 int ffm_pyro_get(ffm_pyro *p, const char *name, double *out);
 const double *ffm_pyro_surface_T_d(const ffm_pyro *p);
 const double *ffm_pyro_phiGas_d(const ffm_pyro *p);
@@ -474,6 +474,36 @@ int ffm_pyro_couple_d(ffm_pyro *p, const int *map_d, const double *TgasCell_d, c
                       const double *nfx_d, const double *nfy_d, const double *nfz_d, double hocSolid, double qFuel,
                       double *refT_d, double *Ux_d, double *Uy_d, double *Uz_d);
 const double *ffm_pyro_qSurf_d(const ffm_pyro *p);
+/* Selections of the region's dictionaries.
+ * ffm_pyro_set_model: reactingOneDim21 != 0 selects lib/regionModels/pyrolysisModels/reactingOneDim21/reactingOneDim21.C (solveEnergy
+ *   :319-368: fvm::ddt(rho,h) - fvm::laplacian(alpha,h) + fvc::laplacian(alpha,h) - fvc::laplacian(kappa,T) == chemistryQdot +
+ *   RRs(0) T Cp0 + RRs(1) T Cp1; evolveRegion :777-815), the pyrolysisModel of cases/wallFireSpread2D/constant/pyrolysisZones:23,
+ *   instead of reactingOneDim (== chemistryQdot - fvm::Sp(RRg, h)); harmonicAlpha / harmonicKappa: `Gauss harmonic` instead of
+ *   `Gauss linear` for laplacian(thermo:alpha,h) / laplacian(kappa,T) (system/panelRegion/fvSchemes of the two cases).
+ * ffm_pyro_set_back: the back face of T -- 0 zeroGradient, 1 fixedValue Tinf, 2 constHTemperature (lib/fvPatchFields/
+ *   constHTemperatureFvPatchScalarField/constHTemperatureFvPatchScalarField.C:156-180; cases/wallFireSpread2D/0/panelRegion/T:25-31).
+ * ffm_pyro_set_surface_radiation: greyMeanSolidAbsorptionEmission (cases/wallFireSpread2D/constant/panelRegion/radiationProperties:
+ *   19-31): absorptivity / emissivity of the exposed face = the solids' values weighted with their volume fractions in the exposed
+ *   layer; used by ffm_pyro_evolve_d instead of its constants and handed to the gas side by ffm_pyro_gas_side_d.                      */
+int ffm_pyro_set_model(ffm_pyro *p, int reactingOneDim21, int harmonicAlpha, int harmonicKappa);
+int ffm_pyro_set_back(ffm_pyro *p, int mode, double h, double Tinf);
+int ffm_pyro_set_surface_radiation(ffm_pyro *p, double absorptivityVirgin, double emissivityVirgin, double absorptivityChar, double emissivityChar);
+/* pyrolysisModel::evolve() of one region with its exposed face coupled to the gas region (solver/fireFoam.C:90-93): evolveRegion with
+ * the solid branch of turbulentTemperatureRadiationQinCoupledMixedFvPatchScalarField::updateCoeffs (:176-296) evaluated INSIDE the
+ * step, where OpenFOAM evaluates it (construction of hEqn: old cell temperature, stored wall value, surface properties and
+ * kappa(*this) of the composition after solveSpeciesMass); the wall value and qSurf of the step are stored.  Gas-side arrays
+ * (cell temperature next to the wall, kappaEff*deltaCoeffs, incident radiation qin or NULL) are indexed by boundary face,
+ * column i <-> face map_d[i] (NULL: i).  emissivity / absorptivity: constants used unless ffm_pyro_set_surface_radiation was called. */
+int ffm_pyro_evolve_d(ffm_pyro *p, double deltaT, const int *map_d, const double *TgasCell_d, const double *kappaDelta_d, const double *qin_d,
+                      double emissivity, double absorptivity);
+/* what the gas region's wall patch reads from the panel after its evolve: refT_d (fluid branch of the coupled condition, :297-303),
+ * U_b (flowRateInletVelocityPyrolysisCoupledFvPatchVectorField::updateCoeffs :127-248) and, if emissivity_d is given and the surface
+ * radiation model is set, the wall emissivity of greyDiffusiveRadiation with `emissivityMode solidRadiation`
+ * (packages/thermophysicalModels/radiation/derivedFvPatchFields/radiationCoupledBase/radiationCoupledBase.C:150-182).  Only the
+ * mapped entries are written.                                                                                                      */
+int ffm_pyro_gas_side_d(ffm_pyro *p, const int *map_d, const double *rho_b_d, const double *magSf_d, const double *nfx_d, const double *nfy_d,
+                        const double *nfz_d, double hocSolid, double qFuel, double *refT_d, double *Ux_d, double *Uy_d, double *Uz_d,
+                        double *emissivity_d);
 int ffm_pyro_destroy(ffm_pyro *p);
 
 /* ------------------------------------------------------- thermo, combustion, LES (N2) */

@@ -69,3 +69,72 @@ def test_coupled_patch_conditions_balance():
     expect = 10.0 * (900.0 - 400.0) + 0.8 * 3e4 - 0.9 * PY.SIGMA_SB * 400.0 ** 4
     assert np.allclose(q, expect, rtol=1e-14)
     assert np.allclose((Tw - 400.0) * (2.0 / p.dx) * p.kappa()[:, 0], q, rtol=1e-12)
+
+
+WALLFIRE = dict(model="reactingOneDim21", alphaScheme="linear", kappaScheme="harmonic", back=("constH", 0.0, 293.0),
+                radiation=dict(v=(0.17, 0.17), char=(0.85, 0.85)))      # cases/wallFireSpread2D: the selections tests/golden/wallfire_case_data.json holds
+
+
+def test_reactingOneDim21_energy_equation_differs_only_in_its_sources():
+    """reactingOneDim21 (config 5's model, reactingOneDim21.C:331-342) against reactingOneDim (:306-353 of the packages/ version) on the
+    same state: identical chemistry, continuity, species; the energy matrices differ by V*RRg on the diagonal (the - fvm::Sp(RRg, h) the
+    variant drops) and the sources by V*(RRs(0) T Cp0 + RRs(1) T Cp1); below Tcrit the two models are the same."""
+    from oracle import pyrolysis as PY
+    a = PY.Panel(4, 8, area=0.01, T0=650.0, model="reactingOneDim", kappaScheme="harmonic")
+    b = PY.Panel(4, 8, area=0.01, T0=650.0, model="reactingOneDim21", kappaScheme="harmonic")
+    q = np.array([0.0, 1e4, 2e4, 3e4])
+    ra, rb = a.step(0.05, q), b.step(0.05, q)
+    assert np.array_equal(a.rho, b.rho) and np.array_equal(a.Yw, b.Yw) and ra["RRg"].min() > 0
+    assert np.allclose(ra["diag"] - rb["diag"], a.V * ra["RRg"], rtol=1e-12)
+    T0 = 650.0
+    sr = PY.CHAR.rho / PY.WOOD.rho; omega = ra["RRg"] / (1.0 - sr)
+    assert np.allclose(rb["src"] - ra["src"], a.V * (-omega * T0 * PY.WOOD.Cp + sr * omega * T0 * PY.CHAR.Cp), rtol=1e-10)
+    assert not np.allclose(a.h, b.h, rtol=1e-6)
+    c = PY.Panel(4, 8, area=0.01, T0=300.0, model="reactingOneDim"); d = PY.Panel(4, 8, area=0.01, T0=300.0, model="reactingOneDim21")
+    c.step(0.05, q); d.step(0.05, q)
+    assert np.array_equal(c.h, d.h)
+
+
+def test_constHTemperature_back_face_and_the_harmonic_conductivity():
+    """constHTemperature (constHTemperatureFvPatchScalarField.C:156-180): h = 0 is an insulated back face (valueFraction ~1e-15), a large
+    h holds it at Tinf, and a finite h lies in between.  Harmonic interpolation equals linear interpolation in a uniform solid."""
+    from oracle import pyrolysis as PY
+    q = np.full(2, 2.0e3)
+    ins = PY.Panel(2, 8, area=0.02, T0=300.0, kappaScheme="harmonic", alphaScheme="harmonic", back=("constH", 0.0, 250.0))
+    adi = PY.Panel(2, 8, area=0.02, T0=300.0, kappaScheme="linear", back=None)
+    hot = PY.Panel(2, 8, area=0.02, T0=300.0, back=("constH", 1e12, 250.0)); fix = PY.Panel(2, 8, area=0.02, T0=300.0, back=("fixed", 250.0))
+    mid = PY.Panel(2, 8, area=0.02, T0=300.0, back=("constH", 40.0, 250.0))
+    E0 = (mid.rho * mid.h * mid.V).sum(axis=1)
+    for _ in range(40):
+        for p in (ins, adi, hot, fix, mid):
+            p.step(0.05, q)
+    assert np.allclose(ins.h, adi.h, rtol=1e-12) and np.allclose(hot.h, fix.h, rtol=1e-9)
+    assert np.all(mid.T[:, -1] < ins.T[:, -1]) and np.all(mid.T[:, -1] > fix.T[:, -1])
+    E1 = (mid.rho * mid.h * mid.V).sum(axis=1)
+    assert np.all(E1 - E0 < q * mid.A * 0.05 * 40)                  # heat leaves through the back face
+    Ef = (fix.rho * fix.h * fix.V).sum(axis=1)
+    assert np.all(Ef < E1)                                         # and more of it when the face is held at Tinf
+
+
+def test_coupled_evolve_of_the_wallfire_panel():
+    """evolve(): the coupled wall condition evaluated inside the step with the surface emissivity / absorptivity of
+    greyMeanSolidAbsorptionEmission (volume-fraction weighted: 0.17 for the virgin solid towards 0.85 for char).  The flux handed to
+    the energy equation is the condition's -nbrTotalFlux, the stored wall value the cell value plus refGrad over half a layer, and
+    what the gas side reads afterwards is the NEW solid state."""
+    from oracle import pyrolysis as PY
+    p = PY.Panel(6, 8, area=0.01, T0=293.0, **WALLFIRE)
+    Tg = np.linspace(900.0, 1400.0, 6); kD = np.full(6, 12.0); qin = np.linspace(2e4, 6e4, 6)
+    a0, e0 = p.surface_radiation()
+    assert np.allclose(a0, 0.17) and np.allclose(e0, 0.17)
+    Tw0, Tc0 = p.Twall.copy(), p.T[:, 0].copy()
+    p.evolve(0.05, Tg, kD, qin)
+    expect = -(kD * (Tc0 - Tg) - 0.17 * qin + 0.17 * PY.SIGMA_SB * Tw0 ** 4)
+    assert np.allclose(p.qSurf, expect, rtol=1e-14)
+    assert np.allclose((p.Twall - p.T[:, 0]) * (2.0 / p.dx) * (PY.WOOD.kappa), p.qSurf, rtol=1e-12)      # kappa() of the virgin solid
+    for _ in range(1500):
+        p.evolve(0.05, Tg, kD, qin)
+    a1, e1 = p.surface_radiation()
+    assert p.Yw[:, 0].max() < 0.9 and np.all(e1 > 0.5) and np.all(e1 <= 0.85) and np.all(np.diff(e1) > 0)      # charring: emissivity towards char's (volume fractions)
+    nf = np.tile(np.array([[0.0, 0.0, -1.0]]), (6, 1))
+    refT, U, emis = p.gas_side(np.full(6, 0.5), np.full(6, 0.01), nf, 1.66e7, 4.6e7)
+    assert np.array_equal(refT, p.T[:, 0]) and np.array_equal(emis, e1) and np.all((U * nf).sum(axis=1) <= 0)

@@ -78,3 +78,73 @@ def test_gas_side_coupling_of_the_pyrolysis_panel(ffm, ctx):
     hocPyr = (hocSolid * PY.WOOD.rho - PY.HOC_CHAR * PY.CHAR.rho) / (PY.WOOD.rho - PY.CHAR.rho)
     assert np.allclose(-inflow * rhob[fmap] * magSf[fmap], dev.field("phiGas") * hocPyr / qFuel, rtol=1e-12, atol=0)
     dev.close()
+
+
+WALLFIRE = dict(model="reactingOneDim21", alphaScheme="linear", kappaScheme="harmonic", back=("constH", 0.0, 293.0),
+                radiation=dict(v=(0.17, 0.17), char=(0.85, 0.85)))      # cases/wallFireSpread2D (tests/golden/wallfire_case_data.json)
+
+
+@pytest.mark.parametrize("sel", [WALLFIRE, dict(model="reactingOneDim", alphaScheme="harmonic", kappaScheme="harmonic", back=("constH", 25.0, 298.15)),
+                                 dict(model="reactingOneDim21", alphaScheme="harmonic", kappaScheme="linear", back=("fixed", 320.0))])
+def test_pyrolysis_model_selections_match_oracle(ffm, ctx, sel):
+    """ffm_pyro_set_model / _set_back: BASELINE config 5's reactingOneDim21 with `Gauss harmonic` conductivity and the
+    constHTemperature back face (first case: exactly the selections of cases/wallFireSpread2D), config 1's reactingOneDim with both
+    laplacians harmonic (cases/pyrolysis1D/system/panelRegion/fvSchemes:37-38) and a convecting back face, and a mixed selection --
+    600 steps through heating, onset and charring with a given surface flux, every field against the oracle."""
+    from oracle import pyrolysis as PY
+    nCol = 257
+    ref = PY.Panel(nCol, 8, thickness=0.0127, area=0.01, T0=293.0, **sel)
+    dev = ffm.PyrolysisPanel(ctx, nCol, 8, thickness=0.0127, area=0.01, T0=293.0)
+    dev.set_model(**sel)
+    q = 3.5e4 * (1.0 + 0.6 * np.sin(0.21 * np.arange(nCol)) ** 2)
+    qd = ctx.to_device(q)
+    for step in range(600):
+        ref.step(0.05, q); dev.step(0.05, qd)
+        if step % 100 == 99 or step == 0:
+            for name, r in (("rho", ref.rho), ("Yw", ref.Yw), ("T", ref.T), ("h", ref.h), ("alpha", ref.alpha)):
+                d = dev.field(name)
+                assert np.abs(d - r).max() <= 1e-11 * np.abs(r).max(), (step, name, np.abs(d - r).max())
+            assert np.abs(dev.field("phiGas") - ref.massGas).max() <= 1e-10 * max(ref.massGas.max(), 1e-300)
+    assert ref.Yw.min() < 0.5
+    dev.close()
+
+
+def test_wallfire_panel_coupled_evolve_matches_oracle(ffm, ctx):
+    """ffm_pyro_evolve_d + ffm_pyro_gas_side_d with the selections of cases/wallFireSpread2D: the coupled wall condition inside the
+    step (composition-dependent absorptivity / emissivity of greyMeanSolidAbsorptionEmission, kappa() = Cp()*alpha_), then what the gas
+    patch reads from the NEW solid state -- wall temperature, pyrolysate inflow, wall emissivity for greyDiffusiveRadiation -- through a
+    permutation map, 500 steps from cold to a charred surface, against the oracle."""
+    import torch
+    from oracle import pyrolysis as PY
+    nCol, B = 300, 420
+    ref = PY.Panel(nCol, 8, thickness=0.0127, area=0.01, T0=293.0, **WALLFIRE)
+    dev = ffm.PyrolysisPanel(ctx, nCol, 8, thickness=0.0127, area=0.01, T0=293.0)
+    dev.set_model(**WALLFIRE)
+    rng = np.random.default_rng(5)
+    fmap = rng.permutation(B)[:nCol].astype(np.int32)
+    i = np.arange(B)
+    Tg = 700.0 + 700.0 * np.sin(0.05 * i) ** 2; kD = 8.0 + 4.0 * np.cos(0.11 * i) ** 2; qin = 5.0e4 * (1.0 + 0.5 * np.sin(0.023 * i))
+    rhob = 0.4 + 0.3 * np.cos(0.07 * i) ** 2; magSf = np.full(B, 0.01)
+    nf = np.stack([np.zeros(B), np.zeros(B), np.full(B, -1.0)], axis=1)
+    hocSolid, qFuel = 1.66e7, 4.6e7
+    D = lambda x: ctx.to_device(np.ascontiguousarray(x, np.float64))
+    d = dict(Tg=D(Tg), kD=D(kD), qin=D(qin), rhob=D(rhob), magSf=D(magSf), nf=[D(nf[:, c]) for c in range(3)],
+             refT=D(np.full(B, -1.0)), U=[D(np.full(B, 7.0)) for _ in range(3)], emis=D(np.full(B, 1.0)), map=torch.from_numpy(fmap).cuda())
+    for step in range(500):
+        ref.evolve(0.05, Tg[fmap], kD[fmap], qin[fmap])
+        dev.evolve(0.05, d["Tg"], d["kD"], d["qin"], map=d["map"])
+        if step % 50 == 0 or step == 499:
+            refT, U, emis = ref.gas_side(rhob[fmap], magSf[fmap], nf[fmap], hocSolid, qFuel)
+            dev.gas_side(d["rhob"], d["magSf"], d["nf"], hocSolid, qFuel, d["refT"], d["U"], emissivity=d["emis"], map=d["map"])
+            assert np.abs(dev.field("qSurf") - ref.qSurf).max() <= 1e-11 * np.abs(ref.qSurf).max(), step
+            assert np.abs(dev.field("Twall") - ref.Twall).max() <= 1e-11 * ref.Twall.max(), step
+            for name, r in (("rho", ref.rho), ("Yw", ref.Yw), ("T", ref.T), ("h", ref.h), ("alpha", ref.alpha)):
+                assert np.abs(dev.field(name) - r).max() <= 1e-10 * np.abs(r).max(), (step, name)
+            rT = d["refT"].cpu().numpy(); em = d["emis"].cpu().numpy(); Ud = np.stack([u.cpu().numpy() for u in d["U"]], axis=1)
+            assert np.abs(rT[fmap] - refT).max() <= 1e-11 * refT.max()
+            assert np.abs(em[fmap] - emis).max() <= 1e-12
+            assert np.abs(Ud[fmap] - U).max() <= 1e-10 * max(np.abs(U).max(), 1e-300)
+            other = np.setdiff1d(np.arange(B), fmap)
+            assert np.all(rT[other] == -1.0) and np.all(Ud[other] == 7.0) and np.all(em[other] == 1.0)
+    assert ref.Yw[:, 0].min() < 0.9 and ref.massGas.max() > 0 and ref.surface_radiation()[1].max() > 0.3
+    dev.close()
