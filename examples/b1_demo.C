@@ -454,3 +454,38 @@ extern "C" int b1_thermo_handle(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, ffm_t
     rho.v.toHost(outC + (size_t)5*N); rho.b.toHost(outB + (size_t)5*B);
     return 0;
 }
+
+// ---- the fvDOM handle (include/fireFoamHandles.H) on any mesh: nCalls calls of radiation->correct() with a given temperature field
+// (cells + boundary faces), emission E, absorption a, wall emissivities, fvDOMCoeffs nPhi / nTheta / maxIter / convergence and the
+// div(Ji,Ii_h) scheme (0 upwind, 5 linearUpwind); Ii by PBiCGStab + DILU to IiTol.  Out: I [nRay][N], G [N], qin / qem / qr [B],
+// iters[nCalls] = iterations of fvDOM::calculate per call, nSolves = number of ray solves of the LAST call.  Returns nRay.
+// tests/test_fvdom_gpu.py compares with oracle/fvdom.py.
+extern "C" int b1_fvdom(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, int emptyDirections, int nPhi, int nTheta, int maxIter, double tolerance, int scheme,
+                        double a, double IiTol, const double* T, const double* Tb, const double* E, const double* emissivity, int nCalls,
+                        double* IOut, double* GOut, double* qinOut, double* qemOut, double* qrOut, int* iters, int* nSolves)
+{
+    fvMesh mesh(ctx, ldu, msh, 1.0);
+    for (int d = 0; d < 3; d++) if (emptyDirections & (1 << d)) mesh.solutionD[d] = -1;
+    mesh.divSchemes["div(Ji,Ii_h)"] = {scheme, 1, 0, 1};
+    mesh.solvers["Ii"] = mesh.solvers["IiFinal"] = {FFM_PBICGSTAB, FFM_DILU, IiTol, 0, 0, 1000, 1};
+    const label N = mesh.nCells, B = mesh.nBoundary;
+    volScalarField Tf("T", mesh); Tf.v.assignHost(T); Tf.b.assignHost(Tb);
+    volScalarField Qdot("Qdot", mesh); Qdot.v.assignHost(E);                 // E = RadFraction*Qdot with RadFraction = Ehrr1 = Ehrr2 = 1
+    surfaceScalarField phi(mesh);
+    mesh.store("phi", phi); mesh.store("Qdot", Qdot);
+    std::vector<double> zeroB(B, 0.0);
+    fvDOM dom(mesh, Tf, nPhi, nTheta, 1, a, 5.670367e-8, 1.0, 1.0, zeroB.data());
+    dom.setIteration(maxIter, tolerance);
+    dom.emissivity().assignHost(emissivity);
+    const bool quiet = std::getenv("FFM_FOAM_QUIET") != nullptr; (void)quiet;
+    for (int c = 0; c < nCalls; c++) {
+        mesh.log.clear();
+        dom.correct();
+        iters[c] = dom.lastIterations_;
+    }
+    *nSolves = (int)mesh.log.size();
+    for (label i = 0; i < dom.nRay(); i++) dom.I_[i].v.toHost(IOut + (size_t)i*N);
+    dom.G_.v.toHost(GOut); dom.qin_.toHost(qinOut); dom.qem_.toHost(qemOut); dom.qr_.toHost(qrOut);
+    FFM_FOAM_CHK(ffm_ctx_sync(ctx));
+    return dom.nRay();
+}

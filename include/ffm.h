@@ -401,6 +401,21 @@ int ffm_fvm_scalar_transport_multi_w(ffm_mesh *m, int nf, const double *w_f, dou
 int ffm_fvm_lust_source3(ffm_mesh *m, double rDeltaT, const double *phi_f, const double *rho0, const double *const *U0,
                          const double *const *gx, const double *const *gy, const double *const *gz, double *const *source);
 
+/* ------------------------------------------------------- fvDOM wall condition (N1) */
+/* greyDiffusiveRadiationMixedFvPatchScalarField::updateCoeffs (reference packages/thermophysicalModels/radiation/derivedFvPatchFields/
+ * greyDiffusiveRadiation/greyDiffusiveRadiationMixedFvPatchScalarField.C:150-230) of ray `ray` on every boundary face: with n the face
+ * normal, nAve = n & dAve and Iw the ray's stored patch values,
+ *   qr[ray] = Iw nAve;  Ir = sum over the rays of their qin (this ray's own, reset by radiativeIntensityRay::correct, counts 0);
+ *   faces the ray leaves the wall through ((-n & d) > 0): valueFraction 1, refValue (Ir (1 - e) + e sigma T_b^4)/pi, qem[ray] = refValue nAve, qin[ray] = 0
+ *   the others: valueFraction 0 (zeroGradient), qem[ray] = 0, qin[ray] = Iw nAve.
+ * qin_all / qem_all / qr_all: device arrays [nRay][nBoundary] the rays share; emissivity_b NULL = 1 everywhere.  The iteration of
+ * fvDOM::calculate (fvDOM/fvDOM.C:547-584) is host code above this (include/fireFoamHandles.H: fvDOM::correct).               */
+int ffm_fvdom_wall_coeffs_d(ffm_mesh *mesh, int nRay, int ray, const double *d3, const double *dAve3, double sigma, const double *Iw_b,
+                            const double *emissivity_b, const double *T_b, double *qin_all, double *qem_all, double *qr_all,
+                            double *valueFraction_b, double *refValue_b);
+/* fvDOM::updateG, boundary fluxes (fvDOM.C:740-750): out_b[k] = sum over the rays, in ray order, of all[ray][k] */
+int ffm_fvdom_sum_rays_d(ffm_mesh *mesh, int nRay, const double *all, double *out_b);
+
 /* ------------------------------------------------------- synthetic plume case */
 /* Host-side driver (C++ over the entry points above) of one fireFoam time step on
  * the synthetic buoyant-plume box of SURVEY 8(d): rhoEqn, UEqn, YEEqn, 2 x pEqn in
