@@ -53,6 +53,16 @@ struct snippetCase          // host arrays: cell fields [N] in the library's cel
     // firefoam_snippets_time_step) with the mapped patch conditions of lib/fvPatchFieldsPyrolysis between the two regions;
     // pyroQin [B]: incident radiative flux on the wall faces
     ffm_pyro* pyro; int pyroCols; const int* pyroMap; const double* pyroQin; double pyroEmissivity, pyroAbsorptivity, pyroHocSolid, pyroQFuel;
+    // fvdomReal != 0: the reference's fvDOM itself (handle `fvDOM` of include/fireFoamHandles.H: the iteration of calculate(), grey-diffusive
+    // walls) as the radiation model, with fvDOMCoeffs nPhi / nTheta / maxIter / convergence, solverFreq = radiationFreq, constRadFractionEmission
+    // (a = kAbs, Ehrr1, Ehrr2, radScaling over the faces of radMlrMask) and the div(Ji,Ii_h) scheme radDivScheme (0 upwind, 5 linearUpwind):
+    // cases/wallFireSpread2D/constant/radiationProperties:28-60, system/fvSchemes:66.  radEmissivity [B]: the walls' `lookup` emissivities.
+    // pyroInStep != 0: the panel is evolved in the reference's order of evaluation (coupled wall condition inside the solid's step, gas
+    // patches from the new solid state); with fvdomReal the solid reads the model's qin and writes its surface emissivity into the
+    // model's wall emissivities (emissivityMode solidRadiation); pyroMaxDi: controlDict maxDi
+    int fvdomReal, radNPhi, radNTheta, radMaxIter, radDivScheme; double radTolerance, radEhrr1, radEhrr2; const double* radMlrMask; const double* radMlrMask2; const double* radEmissivity;
+    double* qinOut; int* radItersOut;
+    int pyroInStep; double pyroMaxDi;
 };
 
 // ---- what solver/createFields.H declares, as the members of one object so that the state stays on the device from one time
@@ -97,7 +107,7 @@ struct snippetSolver
     Time runTime;
     struct { bool adjustTimeStep; scalar maxCo, maxDeltaT; } timeControls;
     pyrolysisModelCollection pyrolysis;
-    const scalar maxDi;                                         // solver/readPyrolysisTimeControls.H:32
+    scalar maxDi;                                               // solver/readPyrolysisTimeControls.H:32
     const bool solvePyrolysisRegion = true, solvePrimaryRegion = true;      // solver/createFields.H:134-145
 
     static pimpleDict pimpleOf()
@@ -170,7 +180,20 @@ struct snippetSolver
         turbulence = autoPtr<compressible::turbulenceModel>(new constantViscosity(mesh, cs->mu, cs->Pr));
         std::vector<scalar> nu(cs->nu, cs->nu + cs->nSpecies);
         combustion = autoPtr<combustionModels::psiCombustionModel>(new singleStepEDC(thermo, rho, cs->fuelIndex, cs->o2Index, cs->sO2, cs->tau, cs->HC, nu));
-        if (cs->radiationFreq > 0) {
+        if (cs->radiationFreq > 0 && cs->fvdomReal) {
+            mesh.divSchemes["div(Ji,Ii_h)"] = {cs->radDivScheme, 1, 0, 1};
+            if (cs->wallFireSelection) { solverControls g; g.solver = FFM_GAMG; g.preconditioner = FFM_DILU; g.tolerance = 1e-4; g.relTol = 0; mesh.solvers["Ii"] = mesh.solvers["IiFinal"] = g; }   // fvSolution:160-170
+            else mesh.solvers["Ii"] = mesh.solvers["IiFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-4, 0, 0, 1000, 1};
+            fvDOM* dom = new fvDOM(mesh, T, cs->radNPhi, cs->radNTheta, cs->radiationFreq, cs->kAbs, cs->sigmaSB, cs->radEhrr1, cs->radEhrr2, cs->radMlrMask);
+            dom->setIteration(cs->radMaxIter, cs->radTolerance);
+            if (cs->radMlrMask2) dom->setSecondMlrMask(cs->radMlrMask2);
+            if (cs->radEmissivity) dom->emissivity().assignHost(cs->radEmissivity);
+            const scalar Cp = cs->Cp;
+            dom->Cpv = [this, Cp]() { return uniformField("Cpv", mesh, Cp); };
+            radiation = autoPtr<radiation::radiationModel>(dom);
+            mesh.store("Qdot", Qdot);
+        }
+        else if (cs->radiationFreq > 0) {
             mesh.divSchemes["div(Ji,Ii_h)"] = {0, 1, 0, 1};                                     // Gauss upwind (fvSchemes:60)
             mesh.solvers["Ii"] = mesh.solvers["IiFinal"] = {FFM_PBICGSTAB, FFM_DILU, 1e-4, 0, 0, 1000, 1};
             radiation = autoPtr<radiation::radiationModel>(new fvDOMStandIn(mesh, T, 2, 4, cs->radiationFreq, cs->kAbs, cs->sigmaSB, cs->Tref, cs->dAve, cs->omega));
@@ -184,6 +207,13 @@ struct snippetSolver
             // gas side of the wall: kappaEff = Cp*alphaEff (the stand-in thermo's constant Cp), he = Cp*(T - Tref)
             pyrolysis.kappaDelta = [this, Cp]() { return binary(FFM_OP_MUL, scalarOp(FFM_OP_MUL, turbulence->alphaEff().b, Cp), mesh.boundaryGeometry(5)); };
             pyrolysis.heOfT = [Cp, Tref](const dField& Tw) { return scalarOp(FFM_OP_MUL, scalarOp(FFM_OP_SUB, Tw, Tref), Cp); };
+            pyrolysis.setCoupledInStep(cs->pyroInStep != 0);
+            if (cs->pyroMaxDi > 0) { pyrolysis.setMaxDi(cs->pyroMaxDi); maxDi = pyrolysis.maxDiff(); }
+            if (cs->pyroInStep && cs->radiationFreq > 0 && cs->fvdomReal) {
+                fvDOM* dom = static_cast<fvDOM*>(&radiation());
+                pyrolysis.qinOfRadiation = [dom]() -> const dField& { return dom->qin_; };
+                pyrolysis.wallEmissivity = &dom->emissivity();
+            }
         }
         thermo.correct();                                           // T, psi of the start state
         U.correctBoundaryConditions(); thermo.he().correctBoundaryConditions();
@@ -278,7 +308,13 @@ struct snippetSolver
         for (int d = 0; d < 3; d++) U.v[d].toHost(cs->UOut + (size_t)d*N);
         forAll(Y, i) { Y[i].v.toHost(cs->YOut[i]); }
         FFM_FOAM_CHK(ffm_faces_from_native(msh, phi.v.data(), cs->phiOutF)); phi.b.toHost(cs->phiOutB);
-        if (cs->radiationFreq > 0 && cs->GOut) static_cast<fvDOMStandIn&>(radiation()).G_.v.toHost(cs->GOut);
+        if (cs->radiationFreq > 0 && cs->fvdomReal) {
+            fvDOM& dom = static_cast<fvDOM&>(radiation());
+            if (cs->GOut) dom.G_.v.toHost(cs->GOut);
+            if (cs->qinOut) dom.qin_.toHost(cs->qinOut);
+            if (cs->radItersOut) *cs->radItersOut = dom.lastIterations_;
+        }
+        else if (cs->radiationFreq > 0 && cs->GOut) static_cast<fvDOMStandIn&>(radiation()).G_.v.toHost(cs->GOut);
     }
     int iterations(const snippetCase* cs, bool skipRho)
     {

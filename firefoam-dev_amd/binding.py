@@ -141,6 +141,7 @@ def lib():
         "ffm_pyro_phiGas_d": ([vp], C.c_void_p),
         "ffm_pyro_couple_d": ([vp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp], C.c_int),
         "ffm_pyro_qSurf_d": ([vp], C.c_void_p),
+        "ffm_pyro_diff_no": ([vp, C.c_double, hp], C.c_int),
         "ffm_pyro_set_model": ([vp, C.c_int, C.c_int, C.c_int], C.c_int),
         "ffm_pyro_set_back": ([vp, C.c_int, C.c_double, C.c_double], C.c_int),
         "ffm_pyro_set_surface_radiation": ([vp] + [C.c_double] * 4, C.c_int),
@@ -840,6 +841,13 @@ class PyrolysisPanel:
         _check(lib().ffm_pyro_gas_side_d(self.h, P(map), P(rho_b), P(magSf), P(nf[0]), P(nf[1]), P(nf[2]), float(hocSolid), float(qFuel), P(refT),
                                          P(U[0]), P(U[1]), P(U[2]), P(emissivity)), "ffm_pyro_gas_side_d")
         self.ctx.sync()
+
+    def diff_no(self, dt):
+        """solidRegionDiffNo() (ffm_pyro_diff_no)"""
+        self.ctx._ready()
+        out = np.zeros(1)
+        _check(lib().ffm_pyro_diff_no(self.h, float(dt), _hp(out)), "ffm_pyro_diff_no")
+        return float(out[0])
 
     def step_coupled(self, dt, Tback=None):
         """one step with the heat flux of the last couple()"""

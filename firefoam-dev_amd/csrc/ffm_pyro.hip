@@ -336,6 +336,39 @@ extern "C" int ffm_pyro_couple_d(ffm_pyro *P, const int *map_d, const double *Tg
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
+// reactingOneDim21::solidRegionDiffNo (reactingOneDim21.C:697-714): DiNum = max over the internal faces of
+// sqr(deltaCoeffs)*interpolate(kappa())/interpolate(Cp()*rho)*deltaT (linear interpolation: interpolationSchemes default linear)
+__global__ void k_pyro_diff_no(int nCol, int nLay, PyroConst k, const double *__restrict__ rho_, const double *__restrict__ Yw_, const double *__restrict__ alpha_,
+                               double *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nCol) return;
+    double m = 0.0, kapP = 0.0, crP = 0.0;
+    for (int i = 0; i < nLay; i++) {
+        const size_t o = (size_t)i * nCol + c;
+        const double Cp = Yw_[o] * k.CpW + (1.0 - Yw_[o]) * k.CpC, kap = Cp * alpha_[o], cr = Cp * rho_[o];
+        if (i > 0) m = fmax(m, (1.0 / k.dx) * (1.0 / k.dx) * (0.5 * kapP + 0.5 * kap) / (0.5 * crP + 0.5 * cr));
+        kapP = kap; crP = cr;
+    }
+    out[c] = m;
+}
+extern "C" int ffm_reduce_max(ffm_ctx *, const double *, long, double *);
+extern "C" int ffm_pyro_diff_no(ffm_pyro *P, double deltaT, double *out)
+{
+    if (!P || !out) return FFM_ERR_ARG;
+    FFM_HIP(hipSetDevice(P->ctx->device));
+    double *tmp = nullptr;
+    FFM_TRY(ffm_malloc_uninit(P->ctx, sizeof(double) * P->nCol, (void **)&tmp));
+    hipLaunchKernelGGL(k_pyro_diff_no, dim3((P->nCol + 255) / 256), dim3(256), 0, P->ctx->stream, P->nCol, P->nLay, P->k, (const double *)P->rho, (const double *)P->Yw,
+                       (const double *)P->alpha, tmp);
+    FFM_HIP(hipGetLastError());
+    double m = 0.0;
+    FFM_TRY(ffm_reduce_max(P->ctx, tmp, P->nCol, &m));
+    FFM_TRY(ffm_free(P->ctx, tmp));
+    *out = m * deltaT;
+    return FFM_OK;
+}
+
 extern "C" const double *ffm_pyro_qSurf_d(const ffm_pyro *P) { return P ? P->qSurf : nullptr; }
 
 extern "C" const double *ffm_pyro_surface_T_d(const ffm_pyro *P) { return P ? P->Tsurf : nullptr; }

@@ -519,6 +519,9 @@ int ffm_pyro_evolve_d(ffm_pyro *p, double deltaT, const int *map_d, const double
 int ffm_pyro_gas_side_d(ffm_pyro *p, const int *map_d, const double *rho_b_d, const double *magSf_d, const double *nfx_d, const double *nfy_d,
                         const double *nfz_d, double hocSolid, double qFuel, double *refT_d, double *Ux_d, double *Uy_d, double *Uz_d,
                         double *emissivity_d);
+/* reactingOneDim21::solidRegionDiffNo (reactingOneDim21.C:697-714; solver/solidRegionDiffusionNo.H): max over the region's internal faces of
+ * deltaCoeffs^2 interpolate(kappa())/interpolate(Cp() rho) * deltaT -- the diffusion number solver/setMultiRegionDeltaT.H limits with maxDi */
+int ffm_pyro_diff_no(ffm_pyro *p, double deltaT, double *out);
 int ffm_pyro_destroy(ffm_pyro *p);
 
 /* ------------------------------------------------------- thermo, combustion, LES (N2) */

@@ -105,7 +105,8 @@ class WallFireSolvers(Solvers):
                     p_rghFinal=dict(solver="GAMG", pre="GaussSeidel", tolerance=1e-6, relTol=0.0),
                     U=dict(solver="PBICG", pre="DILU", tolerance=1e-7, relTol=0.0),
                     Yi=dict(solver="PBICG", pre="DILU", tolerance=1e-8, relTol=0.0),
-                    h=dict(solver="PBICG", pre="DILU", tolerance=1e-8, relTol=0.0))
+                    h=dict(solver="PBICG", pre="DILU", tolerance=1e-8, relTol=0.0),
+                    Ii=dict(solver="GAMG", pre="DILU", tolerance=1e-4, relTol=0.0))          # fvSolution:160-170
 
     def __init__(self, cellOrder, faceOrder, l2, u2, Sf2):
         Solvers.__init__(self)
@@ -118,7 +119,8 @@ class WallFireSolvers(Solvers):
         c = self.CONTROLS[kind]
         if c["solver"] != "GAMG":
             return Solvers.solve(self, kind, name, mesh, diag, upper, lower, source, psi0)
-        G = self.gamg.GAMGSolver(self.agg, diag[self.cOrd], upper[self.fOrd], None, smoother=c["pre"])
+        asym = lower is not None and kind == "Ii"
+        G = self.gamg.GAMGSolver(self.agg, diag[self.cOrd], upper[self.fOrd], lower[self.fOrd] if asym else None, smoother=c["pre"])
         x, perf = G.solve(psi0[self.cOrd], source[self.cOrd], tolerance=c["tolerance"], relTol=c["relTol"])
         psi = np.empty_like(x); psi[self.cOrd] = x
         self.log.append((name, perf))
@@ -218,11 +220,14 @@ class Plume:
 
     rad_coupled, rad_a = False, K_ABS
 
+    rad_patches = (("inlet",), ("inlet",))     # constRadFractionEmissionCoeffs patch1 / patch2 (cases/steckler: both the burner)
+
     def rad_fraction(self):
-        q = [p.name for p in self.m.patches].index("inlet")
-        mlr = -float(np.sum(self.phib[q]))
+        names = [p.name for p in self.m.patches]
+        mlr1 = -float(sum(np.sum(self.phib[names.index(n)]) for n in self.rad_patches[0])) if self.rad_patches[0] else 0.0
+        mlr2 = -float(sum(np.sum(self.phib[names.index(n)]) for n in self.rad_patches[1])) if self.rad_patches[1] else 0.0
         e1, e2 = self.Ehrr
-        return max(min(e1, e2), (mlr * e1 + mlr * e2) / max(1e-15, mlr + mlr))
+        return max(min(e1, e2), (mlr1 * e1 + mlr2 * e2) / max(1e-15, mlr1 + mlr2))
 
     def set_radiation(self, solverFreq=100, nPhi=2, nTheta=4, ordered=True):
         """cases/steckler/constant/radiationProperties:32-40: nPhi 2, nTheta 4 (32 rays), solverFreq 100"""
@@ -334,9 +339,12 @@ class Plume:
         CoNum = 0.5 * (sumPhi / m.V).max() * self.dt
         self.meanCoNum = 0.5 * (sumPhi.sum() / m.V.sum()) * self.dt
         self.CoNum = CoNum
-        DiNum = SMALL                                            # == -GREAT -> SMALL
+        # solidRegionDiffusionNo.H: DiNum = pyrolysis.solidRegionDiffNo() (-GREAT without a region -> SMALL); maxDi = pyrolysis.maxDiff()
+        DiNum = getattr(self, "solid_DiNum", None)
+        DiNum = SMALL if DiNum is None else DiNum
+        maxDi = getattr(self, "maxDi", GREAT)
         TFactorFluid = self.maxCo / (CoNum + SMALL)
-        TFactorSolid = GREAT / (DiNum + SMALL)
+        TFactorSolid = maxDi / (DiNum + SMALL)
         TFactorFilm = self.maxCo / (0.0 + SMALL)
         dt = min(self.dt * min(min(TFactorFluid, min(TFactorFilm, TFactorSolid)), 1.2), self.maxDeltaT)
         maxDeltaTFact = self.maxCo / (CoNum + SMALL)
@@ -470,7 +478,33 @@ class Plume:
         self.time += self.dt
         self.stepNo += 1
 
+    fvdom = None
+
+    def set_fvdom(self, nPhi, nTheta, solverFreq, maxIter, tolerance, a, Ehrr1, Ehrr2, divScheme="upwind"):
+        """the reference's fvDOM itself (oracle/fvdom.py: calculate()'s iteration, greyDiffusiveRadiation walls with their emissivities --
+        self.fvdom.emissivity, per patch -- the 2-D ray set where the mesh has an empty z direction) as radiation->correct(), with
+        constRadFractionEmission (a, E = RadFraction*Qdot) and radiation->Sh in the enthalpy equation; the rays are solved by the
+        solver selection's "Ii" entry.  Wall temperatures: the thermo stand-in's zero-gradient boundary values."""
+        from . import fvdom
+        m = self.m
+
+        def solve(name, d, upper, lower, s, psi0):
+            psi = self.sol.solve("Ii", name, m, d, upper, lower, s, psi0)
+            return psi, self.sol.log[-1][1]
+        self.fvdom = fvdom.FvDOM(m, nPhi, nTheta, solve, maxIter=maxIter, tolerance=tolerance, divScheme=divScheme,
+                                 solutionD=getattr(m, "solutionD", (1, 1, 1)))
+        self.radFreq, self.rays = solverFreq, self.fvdom.rays
+        self.set_radiation_model(a, Ehrr1, Ehrr2)
+
     def radiation_correct(self):
+        if self.fvdom is not None:
+            self.radE = self.rad_fraction() * self.Qdot_field
+            self.fvdom.calculate(self.T, self.zg(self.T), self.rad_a, self.radE)
+            self.G, self.I = self.fvdom.G, self.fvdom.I
+            return
+        self._radiation_correct_standin()
+
+    def _radiation_correct_standin(self):
         """One fvDOM sweep: per ray  fvm::div(Ji, Ii) + fvm::Sp(k*omega, Ii) == 1/pi*omega*(k*sigma*T^4), div scheme upwind
         (cases/steckler/system/fvSchemes:60), inflow faces fixed to the ambient black-body intensity, outflow zeroGradient
         (stand-in for greyDiffusiveRadiation); then G = sum_i Ii*omega_i (fvDOM::updateG)."""

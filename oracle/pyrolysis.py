@@ -207,6 +207,13 @@ class Panel:
         emis = self.surface_radiation()[1] if self.radiation is not None else None
         return self.T[:, 0].copy(), nf * U[:, None], emis
 
+    def diff_no(self, dt):
+        """reactingOneDim21::solidRegionDiffNo (reactingOneDim21.C:697-714): max over the internal faces of
+        sqr(deltaCoeffs)*interpolate(kappa())/interpolate(Cp()*rho)*deltaT (linear interpolation)"""
+        kap, cr = self.kappa(), self.Cp() * self.rho
+        r = (1.0 / self.dx) * (1.0 / self.dx) * (0.5 * kap[:, :-1] + 0.5 * kap[:, 1:]) / (0.5 * cr[:, :-1] + 0.5 * cr[:, 1:])
+        return float(r.max()) * dt
+
     def surface_T(self):
         """temperature of the exposed layer's cell"""
         return self.T[:, 0].copy()

@@ -33,7 +33,10 @@ class SnippetCase(C.Structure):
                 + [("adjustTimeStep", C.c_int), ("maxCo", C.c_double), ("maxDeltaT", C.c_double), ("dtOut", dp), ("emptyDirections", C.c_int)]
                 + [("wallFireSelection", C.c_int), ("gamg", C.c_void_p)]
                 + [("pyro", C.c_void_p), ("pyroCols", C.c_int), ("pyroMap", C.POINTER(C.c_int)), ("pyroQin", dp)]
-                + [(k, C.c_double) for k in ("pyroEmissivity", "pyroAbsorptivity", "pyroHocSolid", "pyroQFuel")])
+                + [(k, C.c_double) for k in ("pyroEmissivity", "pyroAbsorptivity", "pyroHocSolid", "pyroQFuel")]
+                + [(k, C.c_int) for k in ("fvdomReal", "radNPhi", "radNTheta", "radMaxIter", "radDivScheme")]
+                + [(k, C.c_double) for k in ("radTolerance", "radEhrr1", "radEhrr2")] + [("radMlrMask", dp), ("radMlrMask2", dp), ("radEmissivity", dp)]
+                + [("qinOut", dp), ("radItersOut", C.POINTER(C.c_int)), ("pyroInStep", C.c_int), ("pyroMaxDi", C.c_double)])
 
 
 @pytest.mark.parametrize("shape,empty", [((10, 12, 9), ()), ((1, 24, 20), ("xmin", "xmax"))])

@@ -25,6 +25,35 @@ pytestmark = pytest.mark.gpu
 
 
 def test_gas_region_and_pyrolysis_panel_in_one_time_loop(O, ffm, ctx):
+    """round 2's form: reactingOneDim columns, both sides of the coupled wall condition from the state before the step, a given
+    incident radiation"""
+    _run(O, ffm, ctx, (1, 24, 20), ("xmin", "xmax"), None, 6)
+
+
+def test_config5_selections_from_the_case_files(O, ffm, ctx):
+    """BASELINE config 5 with the selections of the reference's own case files (tests/golden/wallfire_case_data.json, made by
+    tests/golden/make_wallfire_case_data.py from cases/wallFireSpread2D/constant/{pyrolysisZones,radiationProperties}, constant/panelRegion/*,
+    system/panelRegion/fvSchemes, 0/panelRegion/T, 0/IDefault, system/controlDict ...; tests/test_dictionary_cpu.py reads the same entries
+    with include/ffmDictionary.H where the reference is mounted):
+      * pyrolysisModel reactingOneDim21 (lib/regionModels/pyrolysisModels/reactingOneDim21), laplacian(kappa,T) Gauss harmonic, the
+        constHTemperature back face, the solids / reaction / layer count / thickness of the case, evolved in the reference's order
+        (coupled wall condition inside the solid's step, gas patches from the new solid state), solidRegionDiffNo() and maxDi in the
+        time-step control (solver/solidRegionDiffusionNo.H, setMultiRegionDeltaT.H -- the reference's files, unchanged);
+      * radiationModel fvDOM with nPhi 2 / nTheta 2 on the 2-D mesh (8 rays in the x-y plane), maxIter 5, convergence 1e-3, solverFreq
+        (shortened from the case's 10 to 2 so that the test's steps cross three radiation solves), div(Ji,Ii_h) Gauss linearUpwind, Ii by
+        GAMG + DILU, constRadFractionEmission with Ehrr1 0.6 / Ehrr2 0.3 and radScaling over patch1 (no burner in the synthetic geometry)
+        and patch2 = the panel patch; the panel patch's wall emissivity `solidRadiation` (0.17 virgin -> 0.85 char by volume
+        fractions), every other patch 1; the solid reads the model's qin (neighbourFieldRadiativeName qin).
+    Device (the reference's unchanged equation files + the handles of include/fireFoamHandles.H) = oracle (oracle/plume.py +
+    oracle/pyrolysis.py + oracle/fvdom.py) step by step.  PARITY UNPINNED by reference data: the reference ships no output of this
+    case; what is pinned is each ingredient's restatement (fvDOM's emissivity-1 path and GAMG by the steckler log)."""
+    import json
+    sel = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wallfire_case_data.json")))
+    assert sel["pyrolysis"]["pyrolysisModel"] == "reactingOneDim21" and sel["radiation"]["radiationModel"] == "fvDOM"
+    _run(O, ffm, ctx, (20, 24, 1), ("zmin", "zmax"), sel, 7)
+
+
+def _run(O, ffm, ctx, shape, empty, sel, nSteps):
     from oracle import plume, pyrolysis as PY
     so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
     if not os.path.exists(so):
@@ -34,7 +63,6 @@ def test_gas_region_and_pyrolysis_panel_in_one_time_loop(O, ffm, ctx):
     lib.firefoam_snippets_create.restype = C.c_void_p; lib.firefoam_snippets_create.argtypes = argt
     lib.firefoam_snippets_time_step.restype = C.c_int; lib.firefoam_snippets_time_step.argtypes = [C.c_void_p, C.POINTER(SnippetCase), C.c_int]
     lib.firefoam_snippets_destroy.argtypes = [C.c_void_p]
-    shape, empty = (1, 24, 20), ("xmin", "xmax")
     gasMesh = plume.make_mesh(shape, empty=empty)
     m = gasMesh
     N, F = m.nCells, m.nFaces
@@ -57,10 +85,32 @@ def test_gas_region_and_pyrolysis_panel_in_one_time_loop(O, ffm, ctx):
     fmap = (start + np.arange(nCol)).astype(np.int32)
     area = float(pw.magSf[0]); assert np.allclose(pw.magSf, area)
     T0 = 600.0                                                    # above the reaction's critical temperature: pyrolysis from the first step
-    solid = PY.Panel(nCol, 8, thickness=0.0127, area=area, T0=T0)
-    dev = ffm.PyrolysisPanel(ctx, nCol, 8, thickness=0.0127, area=area, T0=T0)
+    if sel is None:
+        solid = PY.Panel(nCol, 8, thickness=0.0127, area=area, T0=T0)
+        dev = ffm.PyrolysisPanel(ctx, nCol, 8, thickness=0.0127, area=area, T0=T0)
+    else:
+        py, so = sel["pyrolysis"], sel["solids"]
+        assert (so["v"]["rho"], so["v"]["Cp"], so["v"]["kappa"], so["v"]["Hf"]) == (PY.WOOD.rho, PY.WOOD.Cp, PY.WOOD.kappa, PY.WOOD.Hf)      # the oracle's constants are the case's
+        assert (so["char"]["rho"], so["char"]["Cp"], so["char"]["kappa"], so["char"]["Hf"]) == (PY.CHAR.rho, PY.CHAR.Cp, PY.CHAR.kappa, PY.CHAR.Hf)
+        assert sel["reaction"] == dict(A=PY.REACTION["A"], Ta=PY.REACTION["Ta"], Tcrit=PY.REACTION["Tcrit"], order=PY.REACTION["n"])
+        bk = sel["panelT"]["back"]; assert bk["type"] == "constHTemperature"
+        msel = dict(model=py["pyrolysisModel"], alphaScheme=sel["panelSchemes"]["laplacian(thermo:alpha,h)"], kappaScheme=sel["panelSchemes"]["laplacian(kappa,T)"],
+                    back=("constH", bk["h"], bk["Tinf"]),
+                    radiation=dict(v=(so["v"]["absorptivity"], so["v"]["emissivity"]), char=(so["char"]["absorptivity"], so["char"]["emissivity"])))
+        solid = PY.Panel(nCol, py["nLayers"], thickness=py["thickness"], area=area, T0=T0, **msel)
+        dev = ffm.PyrolysisPanel(ctx, nCol, py["nLayers"], thickness=py["thickness"], area=area, T0=T0)
+        dev.set_model(**msel)
     qin = np.zeros(B); qin[fmap] = 3.0e4 * (1.0 + 0.3 * np.sin(0.7 * np.arange(nCol)))      # incident radiation on the wall faces [W/m2]
     e, a, hocSolid, qFuel = 0.9, 0.85, 1.66e7, 4.6e7              # cases/wallFireSpread2D/0/U:62 hocSolid; propane qFuel
+    if sel is not None:
+        hocSolid = sel["hocSolid"]
+        rd, ct = sel["radiation"], sel["controls"]
+        ref.set_fvdom(rd["nPhi"], rd["nTheta"], 2, rd["maxIter"], rd["convergence"], 0.0, rd["Ehrr1"], rd["Ehrr2"], divScheme=rd["div(Ji,Ii_h)"])
+        ref.rad_patches = ((), ("inlet",))                        # patch1: the burner (absent here); patch2: the panel patch
+        assert len(ref.fvdom.rays) == 8 and rd["wallEmissivity"][".*"] == ["lookup", 1.0] and rd["wallEmissivity"]["region0_to_panelRegion_panel"][0] == "solidRadiation"
+        ref.fvdom.emissivity[qw] = solid.surface_radiation()[1]
+        ref.set_time_controls(ct["maxCo"], ct["maxDeltaT"])
+        ref.dt = ref.dt                                            # the synthetic case starts from its own deltaT (1 ms); maxDeltaT / maxCo / maxDi are the case's
     nfw = pw.Sf / pw.magSf[:, None]
     kDw = (plume.MU / plume.PR * plume.CP) * pw.deltaCoeffs       # kappaEff*deltaCoeffs of the gas side (constant-property stand-in)
 
@@ -108,19 +158,47 @@ def test_gas_region_and_pyrolysis_panel_in_one_time_loop(O, ffm, ctx):
     cs.adjustTimeStep = 0; cs.maxCo = 0.3; cs.maxDeltaT = 0.05; cs.dtOut = dtOut.ctypes.data_as(dp)
     cs.pyro = dev.h; cs.pyroCols = nCol; cs.pyroMap = fmap.ctypes.data_as(C.POINTER(C.c_int)); cs.pyroQin = P(qin)
     cs.pyroEmissivity = e; cs.pyroAbsorptivity = a; cs.pyroHocSolid = hocSolid; cs.pyroQFuel = qFuel
+    radIters, qinDev = C.c_int(0), np.zeros(B)
+    if sel is not None:
+        emis0 = np.ones(B); emis0[fmap] = solid.surface_radiation()[1]
+        maskPanel = np.zeros(B); maskPanel[fmap] = 1.0
+        cs.adjustTimeStep = 1; cs.maxCo = ct["maxCo"]; cs.maxDeltaT = ct["maxDeltaT"]
+        cs.pyroInStep = 1; cs.pyroMaxDi = ct["maxDi"]
+        cs.fvdomReal = 1; cs.radiationFreq = 2; cs.radNPhi = rd["nPhi"]; cs.radNTheta = rd["nTheta"]; cs.radMaxIter = rd["maxIter"]; cs.radTolerance = rd["convergence"]
+        cs.radDivScheme = {"upwind": 0, "linearUpwind": 5}[rd["div(Ji,Ii_h)"]]; cs.kAbs = 0.0; cs.sigmaSB = plume.SIGMA_SB
+        cs.radEhrr1 = rd["Ehrr1"]; cs.radEhrr2 = rd["Ehrr2"]; cs.radMlrMask = P(np.zeros(B)); cs.radMlrMask2 = P(maskPanel); cs.radEmissivity = P(emis0)
+        cs.qinOut = qinDev.ctypes.data_as(dp); cs.radItersOut = C.pointer(radIters); cs.nIterCap = 96
+        nit = (C.c_int * 96)(); cs.nIterOut = nit
     os.environ["FFM_FOAM_QUIET"] = "1"
     solver = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(cs))
     inv0 = np.empty(N, np.int64); inv0[cOrd] = np.arange(N)
     Tw = np.full(nCol, T0)                                        # the wall value starts at the solid's temperature (ffm_pyro_create)
-    nSteps = 6
+    radSolves = 0
     for k in range(nSteps):
-        # oracle: the mapped conditions with the gas state at the start of the step, the columns, then the gas region
-        q, Tw, refT, Uw = PY.couple(solid, Tw, ref.T[pw.faceCells], kDw, qin[fmap], e, a, ref.rho[pw.faceCells], pw.magSf, nfw, hocSolid, qFuel)
-        solid.step(ref.dt, q)
+        if sel is None:
+            # oracle: the mapped conditions with the gas state at the start of the step, the columns, then the gas region
+            q, Tw, refT, Uw = PY.couple(solid, Tw, ref.T[pw.faceCells], kDw, qin[fmap], e, a, ref.rho[pw.faceCells], pw.magSf, nfw, hocSolid, qFuel)
+            solid.step(ref.dt, q)
+        else:
+            # the reference's loop: deltaT from the Courant number of the gas AND the diffusion number of the solid (maxDi), then
+            # pyrolysis.evolve() with the radiation model's qin, then the gas patches from the new solid state
+            ref.solid_DiNum, ref.maxDi = solid.diff_no(ref.dt), ct["maxDi"]
+            ref.set_delta_t(); ref.adjust = False
+            solid.evolve(ref.dt, ref.T[pw.faceCells], kDw, ref.fvdom.qin[qw])
+            q = solid.qSurf
+            refT, Uw, emisW = solid.gas_side(ref.rho[pw.faceCells], pw.magSf, nfw, hocSolid, qFuel)
+            ref.fvdom.emissivity[qw] = emisW
         ref.inlet_U = Uw; ref.inlet_h = plume.CP * (refT - plume.TREF)
         ref.step()
-        n = lib.firefoam_snippets_time_step(solver, C.byref(cs), 1 if k == nSteps - 1 else 0)
-        assert abs(dtOut[0] - ref.dt) <= 1e-12 * ref.dt
+        if sel is not None:
+            ref.adjust = True
+        n = lib.firefoam_snippets_time_step(solver, C.byref(cs), 1 if (k == nSteps - 1 or sel is not None) else 0)
+        assert abs(dtOut[0] - ref.dt) <= 1e-9 * ref.dt, (k, dtOut[0], ref.dt)
+        if sel is not None and k % 2 == 0:
+            radSolves += 1
+            assert radIters.value == ref.fvdom.nIterations, (k, radIters.value, ref.fvdom.nIterations)
+            w = ref.fvdom.qin[qw]
+            assert np.abs(qinDev[fmap] - w).max() <= 1e-6 * max(np.abs(w).max(), 1e-300), (k, np.abs(qinDev[fmap] - w).max(), np.abs(w).max())
         assert list(nit[:n]) == [pf["nIterations"] for _, pf in ref.sol.log], (k, list(nit[:n]), [pf["nIterations"] for _, pf in ref.sol.log])
         assert np.abs(dev.field("qSurf") - q).max() <= 1e-9 * np.abs(q).max(), k
         assert np.abs(dev.field("T") - solid.T).max() <= 1e-9 * solid.T.max(), k
