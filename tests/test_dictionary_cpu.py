@@ -181,3 +181,53 @@ def test_field_files_are_written_and_read_back(tmp_path, nCmpt):
     assert "(\n" + first + "\n" in text
     assert "    burner\n    {\n        type            fixedValue;\n        value           uniform " in text
     assert "        inletValue      uniform " in text and text.rstrip().endswith("// ************************************************************************* //")
+
+
+def test_config5_selections_read_by_the_dictionary_reader_equal_the_fixture():
+    """tests/golden/wallfire_case_data.json (the model selections the config-5 GPU tests run with; the GPU box has no case files) against
+    the reference's own files read by include/ffmDictionary.H: the pyrolysis model and its coefficients, the panel region's schemes,
+    solids, surface radiation and back-face condition, the gas region's fvDOM coefficients, emissivity modes and time controls."""
+    import json
+    lib, _ = _lib()
+    lib.b1_dict_lookup.restype = C.c_int
+    lib.b1_dict_lookup.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+    sel = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wallfire_case_data.json")))
+
+    def look(rel, key):
+        buf = C.create_string_buffer(512)
+        assert lib.b1_dict_lookup(os.path.join(REF, "wallFireSpread2D", rel).encode(), key.encode(), buf, 512) >= 0, (rel, key)
+        return buf.value.decode()
+    py = sel["pyrolysis"]
+    model = look("constant/pyrolysisZones", "pyrolysis/pyrolysisModel")
+    assert model == py["pyrolysisModel"] == "reactingOneDim21"
+    for k in ("gasHSource", "qrHSource", "moveMesh", "useChemistrySolvers"):
+        assert look("constant/pyrolysisZones", "pyrolysis/%sCoeffs/%s" % (model, k)) == py[k]
+    assert int(look("system/extrudeToRegionMeshDict", "nLayers")) == py["nLayers"]
+    assert float(look("system/extrudeToRegionMeshDict", "linearNormalCoeffs/thickness")) == py["thickness"]
+    for name, d in sel["solids"].items():
+        assert float(look("constant/panelRegion/thermo.solid", name + "/equationOfState/rho")) == d["rho"]
+        assert float(look("constant/panelRegion/thermo.solid", name + "/thermodynamics/Cp")) == d["Cp"]
+        assert float(look("constant/panelRegion/thermo.solid", name + "/thermodynamics/Hf")) == d["Hf"]
+        assert float(look("constant/panelRegion/thermo.solid", name + "/transport/kappa")) == d["kappa"]
+        assert float(look("constant/panelRegion/radiationProperties", "greyMeanSolidAbsorptionEmissionCoeffs/%s/emissivity" % name)) == d["emissivity"]
+        assert float(look("constant/panelRegion/radiationProperties", "greyMeanSolidAbsorptionEmissionCoeffs/%s/absorptivity" % name)) == d["absorptivity"]
+    for k, v in sel["panelSchemes"].items():
+        assert look("system/panelRegion/fvSchemes", "laplacianSchemes/" + k).split()[:2] == ["Gauss", v]
+    bk = sel["panelT"]["back"]
+    assert look("0/panelRegion/T", "boundaryField/panel_top/type") == bk["type"]
+    assert look("0/panelRegion/T", "boundaryField/panel_top/Tinf").split()[-1] == "293" and float(look("0/panelRegion/T", "boundaryField/panel_top/h").split()[-1]) == bk["h"]
+    assert look("0/panelRegion/T", "boundaryField/region0_to_panelRegion_panel/emissivityMode") == sel["panelT"]["coupled"]["emissivityMode"]
+    assert look("0/panelRegion/T", "boundaryField/region0_to_panelRegion_panel/neighbourFieldRadiativeName") == "qin"
+    rd = sel["radiation"]
+    assert look("constant/radiationProperties", "radiationModel") == rd["radiationModel"]
+    for k in ("nPhi", "nTheta", "maxIter"):
+        assert int(look("constant/radiationProperties", "fvDOMCoeffs/" + k)) == rd[k]
+    assert float(look("constant/radiationProperties", "fvDOMCoeffs/convergence")) == rd["convergence"] and int(look("constant/radiationProperties", "solverFreq")) == rd["solverFreq"]
+    assert look("constant/radiationProperties", "absorptionEmissionModel") == rd["absorptionEmissionModel"]
+    for k in ("Ehrr1", "Ehrr2"):
+        assert float(look("constant/radiationProperties", "constRadFractionEmissionCoeffs/" + k)) == rd[k]
+    assert look("system/fvSchemes", "divSchemes/div(Ji,Ii_h)").split()[:2] == ["Gauss", rd["div(Ji,Ii_h)"]]
+    assert look("0/IDefault", "boundaryField/region0_to_panelRegion_panel/emissivityMode") == "solidRadiation"
+    assert float(look("0/U", "boundaryField/region0_to_panelRegion_panel/hocSolid")) == sel["hocSolid"]
+    for k in ("maxCo", "maxDi", "maxDeltaT", "deltaT"):
+        assert float(look("system/controlDict", k)) == sel["controls"][k]

@@ -53,8 +53,35 @@ def test_config5_selections_from_the_case_files(O, ffm, ctx):
     _run(O, ffm, ctx, (20, 24, 1), ("zmin", "zmax"), sel, 7)
 
 
-def _run(O, ffm, ctx, shape, empty, sel, nSteps):
+@pytest.mark.parametrize("shape,h", [((355, 710, 1), 0.004), ((1420, 2840, 1), 0.001)])
+def test_config5_at_its_size_with_the_panel_attached(O, ffm, ctx, shape, h):
+    """BASELINE config 5's size -- a 2-D gas region of 1420 x 2840 x 1 = 4.03 M cells (z empty) -- with the case's selections and the
+    pyrolysing panel behind the wall patch (710 columns x 8 layers), three time steps of the reference's loop on the device; no oracle
+    at this size: property checks (finite and bounded fields, the panel's mass balance, the radiation model irradiating the panel, every
+    solve within maxIter).  The start state is the ambient at rest with p = pRef + rho gh."""
+    import json
+    sel = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wallfire_case_data.json")))
+    _run(O, ffm, ctx, shape, ("zmin", "zmax"), sel, 3, compare=False, h=h)
+
+
+class _NoSolve:
+    """stands in for the oracle's solver selection where only the mesh and the start state of oracle/plume.py are wanted"""
+    def __init__(self):
+        self.log = []
+
+    def solve(self, kind, name, mesh, diag, upper, lower, source, psi0):
+        self.log.append((name, dict(nIterations=0, initialResidual=0.0, finalResidual=0.0)))
+        return psi0
+
+
+def _run(O, ffm, ctx, shape, empty, sel, nSteps, compare=True, h=0.05):
+    import time
     from oracle import plume, pyrolysis as PY
+    t00 = time.time()
+
+    def stage(what):
+        if not compare:
+            print("  [%7.1f s] %s" % (time.time() - t00, what), flush=True)
     so = os.path.join(os.path.dirname(ffm.libpath()), "libffm_refsnippets.so")
     if not os.path.exists(so):
         pytest.skip("libffm_refsnippets.so not built (needs /root/reference at build time)")
@@ -63,7 +90,7 @@ def _run(O, ffm, ctx, shape, empty, sel, nSteps):
     lib.firefoam_snippets_create.restype = C.c_void_p; lib.firefoam_snippets_create.argtypes = argt
     lib.firefoam_snippets_time_step.restype = C.c_int; lib.firefoam_snippets_time_step.argtypes = [C.c_void_p, C.POINTER(SnippetCase), C.c_int]
     lib.firefoam_snippets_destroy.argtypes = [C.c_void_p]
-    gasMesh = plume.make_mesh(shape, empty=empty)
+    gasMesh = plume.make_mesh(shape, h=h, empty=empty)
     m = gasMesh
     N, F = m.nCells, m.nFaces
     B = sum(p.size for p in m.patches)
@@ -73,8 +100,14 @@ def _run(O, ffm, ctx, shape, empty, sel, nSteps):
     patches = [(oldToNew[p.faceCells].astype(np.int32), p.Sf.T.copy(), p.deltaCoeffs) for p in m.patches]
     mesh = ffm.fvMesh(A, m.V[cOrd], m.C[cOrd].T.copy(), m.Sf[fOrd].T.copy(), m.magSf[fOrd], m.weights[fOrd], m.deltaCoeffs[fOrd], patches)
     mesh.set_face_centres(m.Cf[fOrd].T.copy())
+    stage("device mesh built")
     G5 = ffm.GAMG(ctx, A, l2, u2, Sf=m.Sf[fOrd])
-    ref = plume.Plume(shape, mesh=gasMesh, solvers=plume.WallFireSolvers(cOrd, fOrd, l2, u2, m.Sf[fOrd]))
+    stage("GAMG agglomeration built (%d levels)" % G5.nLevels if hasattr(G5, "nLevels") else "GAMG agglomeration built")
+    # (the size runs start from the conditioned state of oracle/plume.py: in a gas at rest with uniform temperature the rays that leave
+    # only ambient walls have a UNIFORM solution, for which OpenFOAM's residual normalisation degenerates -- normFactor ~ round-off --
+    # and the ray solves run to maxIter on noise; no fire has such a state after its first instants)
+    ref = plume.Plume(shape, h=h, mesh=gasMesh, solvers=plume.WallFireSolvers(cOrd, fOrd, l2, u2, m.Sf[fOrd]) if compare else _NoSolve(),
+                      conditioned=not compare)
     ref.stored_bc = True; ref.divU_scheme = ("filteredLinear2V", 0.2, 0.05)
 
     # ---- the panel: one column behind every face of the wall patch (the plume's `inlet` patch plays the pyrolysing wall)
@@ -133,14 +166,14 @@ def _run(O, ffm, ctx, shape, empty, sel, nSteps):
     fU = np.concatenate([per(lambda p, d=d: np.where(np.abs(p.Sf[:, d]) > 0, 0.0, -1.0) if is_open(p) else np.ones(p.size)) for d in range(3)])
     fixesU = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0))
     fY = per(lambda p: np.full(p.size, 1.0 if p.name == "inlet" else (0.0 if p.name == "floor" else -1.0)))
-    refY = [per(lambda p, i=i: np.full(p.size, plume.Y_IN[i] if p.name == "inlet" else (plume.Y_AMB[i] if is_open(p) else 0.0))) for i in range(5)]
+    refY = [per(lambda p, i=i: np.full(p.size, ref.Y_in[i] if p.name == "inlet" else (ref.Y_amb[i] if is_open(p) else 0.0))) for i in range(5)]
     fH = per(lambda p: np.full(p.size, -1.0 if is_open(p) else 1.0))
+    Z = per(lambda p: np.full(p.size, ref.h_amb if is_open(p) else 0.0))
     fluxMask = per(lambda p: np.full(p.size, 0.0 if is_open(p) else 1.0)); totalMask = 1.0 - fluxMask
     ghfb = bnd([p.Cf @ plume.G - ref.ghRef for p in m.patches])
     out = dict(rho=np.empty(N), U=np.empty((3, N)), p=np.empty(N), p_rgh=np.empty(N), h=np.empty(N), Y=[np.empty(N) for _ in range(5)],
                T=np.empty(N), K=np.empty(N), dpdt=np.empty(N), phi=np.empty(F), phib=np.empty(B), p_rghB=np.empty(B))
     nit, dtOut = (C.c_int * 32)(), np.zeros(1)
-    Z = np.zeros(B)
     cs = SnippetCase(
         deltaT=ref.dt, RR=plume.RR, Cp=plume.CP, Tref=plume.TREF, pRef=plume.PREF, mu=plume.MU, Pr=plume.PR, sO2=plume.S_O2, HC=plume.HC,
         tau=plume.TAU, nSpecies=5, inertIndex=plume.INERT, fuelIndex=2, o2Index=0, W=P(plume.WMOL), nu=P(plume.NU),
@@ -170,10 +203,32 @@ def _run(O, ffm, ctx, shape, empty, sel, nSteps):
         cs.qinOut = qinDev.ctypes.data_as(dp); cs.radItersOut = C.pointer(radIters); cs.nIterCap = 96
         nit = (C.c_int * 96)(); cs.nIterOut = nit
     os.environ["FFM_FOAM_QUIET"] = "1"
+    stage("start state ready")
     solver = lib.firefoam_snippets_create(ctx.h, A.h, mesh.h, C.byref(cs))
+    stage("solver object created")
     inv0 = np.empty(N, np.int64); inv0[cOrd] = np.arange(N)
     Tw = np.full(nCol, T0)                                        # the wall value starts at the solid's temperature (ffm_pyro_create)
     radSolves = 0
+    if not compare:
+        gas, m0 = np.zeros(nCol), (dev.field("rho") * solid.V).sum(axis=1)
+        for k in range(nSteps):
+            t0 = time.time()
+            n = lib.firefoam_snippets_time_step(solver, C.byref(cs), 1 if k == nSteps - 1 else 0)
+            print("config 5 at %d cells with the panel: step %d  %.2f s  deltaT %.3g  %d solves, iterations %s" % (N, k, time.time() - t0, dtOut[0], n, list(nit[:n])), flush=True)
+            assert 0 < n <= 96 and max(nit[:n]) < 1000
+            gas += dev.field("phiGas") * dtOut[0]
+        lib.firefoam_snippets_destroy(solver)
+        lost = m0 - (dev.field("rho") * solid.V).sum(axis=1)
+        assert np.allclose(lost, gas, rtol=1e-9) and lost.min() > 0                       # the panel's mass balance: what it lost entered the gas region
+        for name in ("rho", "T", "p", "h"):
+            assert np.isfinite(out[name]).all(), name
+        assert np.isfinite(out["U"]).all() and all(np.isfinite(y).all() for y in out["Y"])
+        assert 0.3 < out["rho"].min() and out["rho"].max() < 1.5 and out["T"].min() > 280.0 and out["T"].max() <= T0 + 5.0
+        assert out["T"][inv0][pw.faceCells].max() > plume.TREF + 0.5                       # the hot wall heats the gas cell layer
+        assert radIters.value >= 1 and qinDev[fmap].min() >= 0 and qinDev[fmap].max() > 0  # the walls' and the flame's radiation reaches the panel
+        assert abs(sum(y for y in out["Y"]) - 1.0).max() < 1e-10
+        G5.close(); dev.close(); mesh.close(); A.close()
+        return
     for k in range(nSteps):
         if sel is None:
             # oracle: the mapped conditions with the gas state at the start of the step, the columns, then the gas region
@@ -200,10 +255,16 @@ def _run(O, ffm, ctx, shape, empty, sel, nSteps):
             w = ref.fvdom.qin[qw]
             assert np.abs(qinDev[fmap] - w).max() <= 1e-6 * max(np.abs(w).max(), 1e-300), (k, np.abs(qinDev[fmap] - w).max(), np.abs(w).max())
         assert list(nit[:n]) == [pf["nIterations"] for _, pf in ref.sol.log], (k, list(nit[:n]), [pf["nIterations"] for _, pf in ref.sol.log])
-        assert np.abs(dev.field("qSurf") - q).max() <= 1e-9 * np.abs(q).max(), k
-        assert np.abs(dev.field("T") - solid.T).max() <= 1e-9 * solid.T.max(), k
-        assert np.abs(dev.field("phiGas") - solid.massGas).max() <= 1e-9 * max(solid.massGas.max(), 1e-300), k
+        # config 5: the wall flux contains a*qin of rays solved to 1e-4 (GAMG, fvSolution:160-170) in two implementations: 1e-6
+        tq = 1e-9 if sel is None else 1e-6
+        assert np.abs(dev.field("qSurf") - q).max() <= tq * np.abs(q).max(), k
+        assert np.abs(dev.field("T") - solid.T).max() <= tq * solid.T.max(), k
+        assert np.abs(dev.field("phiGas") - solid.massGas).max() <= 10 * tq * max(solid.massGas.max(), 1e-300), k
+        if sel is not None:
+            assert abs(dev.diff_no(ref.dt) - solid.diff_no(ref.dt)) <= 1e-9 * solid.diff_no(ref.dt)
     lib.firefoam_snippets_destroy(solver)
+    if sel is not None:
+        assert radSolves >= 3 and max(np.abs(b).max() for b in ref.fvdom.qin) > 0          # the flame and the walls irradiate the panel
     # the coupling acted in both directions
     assert solid.massGas.min() > 0 and solid.Yw[:, 0].max() < 1.0                    # the wood pyrolyses ...
     f = ref.fields()
@@ -215,7 +276,9 @@ def _run(O, ffm, ctx, shape, empty, sel, nSteps):
     # same weights on faces with negligible flux): velocity and transported scalars agree to 1e-5
     errs = {name: rel_l2(got[inv0], f[name]) for name, got in (("rho", out["rho"]), ("T", out["T"]), ("h", out["h"]), ("Uy", out["U"][1]), ("Uz", out["U"][2]),
                                                                ("O2", out["Y"][0]), ("C3H8", out["Y"][2]))}
-    bad = {k: v for k, v in errs.items() if not v < 1e-5}
+    # (config 5: seven steps with deltaT growing 1.44-fold per step towards maxDeltaT; the velocity follows a pressure solved by GAMG to
+    # 1e-5 / relTol 0.01, fvSolution:36-47: 5e-5)
+    bad = {k: v for k, v in errs.items() if not v < (5e-5 if (sel is not None and k.startswith("U")) else 1e-5)}
     assert not bad, (bad, errs)
     assert np.linalg.norm(out["p_rgh"][inv0] - f["p_rgh"]) / np.linalg.norm(f["p_rgh"] - f["p_rgh"].mean()) < 1e-4
     G5.close(); dev.close(); mesh.close(); A.close()
