@@ -242,6 +242,8 @@ def lib():
         "ffm_plume_nsolves": ([vp], C.c_int),
         "ffm_plume_get_solve": ([vp, C.c_int, C.c_char_p, C.POINTER(Perf)], C.c_int),
         "ffm_plume_ldu": ([vp], vp),
+        "ffm_plume_mesh": ([vp], vp),
+        "ffm_fv_multivariate_weights_tiled": ([vp, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_double, C.c_double, dp] + [C.POINTER(C.c_void_p)] * 2 + [dp], C.c_int),
         "ffm_comm_unique_id": ([vp], C.c_int),
         "ffm_comm_init": ([vp, C.c_int, C.c_int, vp], C.c_int),
         "ffm_comm_init_host": ([vp, C.c_int, C.c_int, vp, HOST_ALLREDUCE_FN, HOST_EXCHANGE_FN], C.c_int),
@@ -672,6 +674,13 @@ class Plume:
 
     def ldu_handle(self):
         return lib().ffm_plume_ldu(self.h)
+
+    def mesh(self):
+        """the case's device mesh as an fvMesh wrapper (not owned: do not close it); tests call operators on it"""
+        m = fvMesh.__new__(fvMesh)
+        m.ctx, m.h, m.ldu = self.ctx, C.c_void_p(lib().ffm_plume_mesh(self.h)), None
+        m.nNative, m.nBoundary = lib().ffm_mesh_nnative(m.h), lib().ffm_mesh_nboundary(m.h)
+        return m
 
 
 class Thermo:

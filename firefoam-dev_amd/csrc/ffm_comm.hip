@@ -197,12 +197,12 @@ extern "C" int ffm_ldu_set_interfaces(ffm_ldu *A, int nPatches, const int *patch
     FFM_HIP(hipMalloc((void **)&A->ifItem, ti));
     FFM_HIP(hipHostMalloc((void **)&A->haloSend_h, tb, hipHostMallocDefault));
     FFM_HIP(hipHostMalloc((void **)&A->haloRecv_h, tb, hipHostMallocDefault));
-    FFM_HIP(hipMemcpy(A->ifFaceCells, fc.data(), sizeof(int) * total, hipMemcpyHostToDevice));
-    FFM_HIP(hipMemcpy(A->ifBou, bou.data(), sizeof(double) * total, hipMemcpyHostToDevice));
-    FFM_HIP(hipMemcpy(A->ifInt, in.data(), sizeof(double) * total, hipMemcpyHostToDevice));
-    FFM_HIP(hipMemcpy(A->ifCell, cells.data(), sizeof(int) * cells.size(), hipMemcpyHostToDevice));
-    FFM_HIP(hipMemcpy(A->ifCellStart, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice));
-    FFM_HIP(hipMemcpy(A->ifItem, order.data(), sizeof(int) * total, hipMemcpyHostToDevice));
+    FFM_TRY(ffm_h2d(A->ctx, A->ifFaceCells, fc.data(), sizeof(int) * total));
+    FFM_TRY(ffm_h2d(A->ctx, A->ifBou, bou.data(), sizeof(double) * total));
+    FFM_TRY(ffm_h2d(A->ctx, A->ifInt, in.data(), sizeof(double) * total));
+    FFM_TRY(ffm_h2d(A->ctx, A->ifCell, cells.data(), sizeof(int) * cells.size()));
+    FFM_TRY(ffm_h2d(A->ctx, A->ifCellStart, start.data(), sizeof(int) * start.size()));
+    FFM_TRY(ffm_h2d(A->ctx, A->ifItem, order.data(), sizeof(int) * total));
     return FFM_OK;
 }
 
@@ -301,7 +301,7 @@ extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRa
         std::vector<int> oldToNew(A->nCells), mapped(std::max(nSend, 1));
         for (int i = 0; i < A->nCells; i++) oldToNew[A->h_newToOldCell[i]] = i;
         for (int i = 0; i < nSend; i++) mapped[i] = oldToNew[sendCells[i]];
-        FFM_HIP(hipMemcpy(A->ghSendCells, mapped.data(), sizeof(int) * nSend, hipMemcpyHostToDevice));
+        FFM_TRY(ffm_h2d(A->ctx, A->ghSendCells, mapped.data(), sizeof(int) * nSend));
     }
     FFM_HIP(hipHostMalloc((void **)&A->ghSendBuf_h, sizeof(double) * std::max(nSend, 1), hipHostMallocDefault));
     FFM_HIP(hipHostMalloc((void **)&A->ghRecvBuf_h, sizeof(double) * std::max(A->ghRecvOff[nNbr], 1), hipHostMallocDefault));

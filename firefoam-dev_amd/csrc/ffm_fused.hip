@@ -16,6 +16,7 @@
 #include "ffm_mesh.hpp"
 
 constexpr int FUSE_MAX = 4;
+#define CHECK_M(m) if (!(m)) { ffm_set_error("null mesh"); return FFM_ERR_ARG; }
 
 struct GradMulti {
     const double *vf[FUSE_MAX], *vb[FUSE_MAX];
@@ -98,6 +99,8 @@ struct ScalarEqns {
     double rdt, twoByk, lo, hi;
     int scheme;                                                          // 2 limitedLinear, 3 limitedLinear01
     const double *wGiven;                                                // GIVENW: the face weights (a multivariate scheme's common ones)
+    int nOffDiag;                                                        // GIVENW: fields 0 .. nOffDiag-1 write their off-diagonals (with common weights and one
+                                                                         // diffusivity every field's are the same: the caller shares field 0's, or an earlier pass')
 };
 
 // Occupancy: the fused four-field kernel is bound by the latency of its neighbour gathers; capped at 128 VGPRs (4 waves per SIMD,
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, ((NF > 1 && !GIVENW) ? 4 : 1)) void k_scalar_e
                 dDiv -= lo;
                 dLap -= gu[s];
                 lo = lo - gu[s]; up = up - gu[s];
-                a.upper[i][U.f[s]] = up; a.lower[i][U.f[s]] = lo;
+                if (!GIVENW || i < a.nOffDiag) { a.upper[i][U.f[s]] = up; a.lower[i][U.f[s]] = lo; }
             }
             double d = a.rdt * rhoc * V;
             d = d + dDiv;
@@ -265,6 +268,152 @@ __global__ __launch_bounds__(256) void k_mv_weights(MeshView q, MvWeights a)
     }
 }
 
+// ---- the same weights with the cell fields staged through LDS on the tile numbering -------------------------------
+// k_grad_multi (the Gauss gradients of the nf fields) + k_mv_weights in ONE pass, bit for bit: a workgroup walks a run of consecutive
+// entries (dependency levels of at most 256 cells) of one tile; the nf cell values and the cell centre of the entries e-1, e, e+1 sit
+// in an LDS window (three buffers, entry e+1 loaded while entry e is computed), so the six neighbours of a cell -- which on the tile
+// numbering lie in the entries next to its own -- are served from LDS: every cell value is read from memory once per run instead
+// of once by the cell and once by each neighbour.  A cell forms its own gradients in registers (the limiter of a face needs the
+// UPWIND cell's gradient, and every face is written by its upwind cell), so the eighteen gradient arrays are neither written nor read.
+// Neighbours outside the window (other tiles: ~12 % of the faces) are read from memory.  Single block only (no ghost cells).
+constexpr int MVT_ENT = 256, MVT_FLD = 6, MVT_RUN = 32;
+struct MvTile {
+    const double *vf[MVT_FLD], *vb[MVT_FLD];
+    int scheme[MVT_FLD], nf;
+    const double *phi, *Cx, *Cy, *Cz;
+    double twoByk, lo, hi;
+    double *out;
+    const int4 *seg, *rec;
+};
+template <int W>
+__global__ __launch_bounds__(256) void k_mv_tile(MeshView q, MvTile a)
+{
+    __shared__ double ring[MVT_FLD + 3][3 * MVT_ENT];
+    __shared__ int4 shRec[3];
+    const int4 sg = a.seg[blockIdx.x];
+    const int gBeg = sg.x, ea = sg.y, eb = sg.z, gEnd = sg.w;
+    const int t = threadIdx.x;
+    const int nf = a.nf;
+    auto stage = [&](int ee) {          // cell values + centres of entry ee -> buffer ee % 3
+        if (ee < gBeg || ee >= gEnd) { if (t == 0) shRec[(ee + 3) % 3] = make_int4(0, 0, 0, 0); return; }
+        const int4 R = a.rec[ee];
+        const int c0 = R.x, cnt = R.y & 0xFFFF;
+        if (t == 0) shRec[ee % 3] = make_int4(c0, cnt, 0, 0);
+        if (t < cnt) {
+            const int c = c0 + t, o = (ee % 3) * MVT_ENT + t;
+            for (int i = 0; i < nf; i++) ring[i][o] = a.vf[i][c];
+            ring[MVT_FLD][o] = a.Cx[c]; ring[MVT_FLD + 1][o] = a.Cy[c]; ring[MVT_FLD + 2][o] = a.Cz[c];
+        }
+    };
+    stage(ea - 1); stage(ea);
+    for (int ee = ea; ee < eb; ee++) {
+        stage(ee + 1);
+        __syncthreads();
+        const int4 Rm = shRec[(ee + 2) % 3], R0 = shRec[ee % 3], Rp = shRec[(ee + 1) % 3];
+        if (t < R0.y) {
+            const int c = R0.x + t, own = (ee % 3) * MVT_ENT + t;
+            RowEnt<W> L, U; load_lower<W>(q.v, c, L); load_upper<W>(q.v, c, U);
+            // LDS slot of a neighbour cell, or -1: outside the window
+            auto slotOf = [&](int nb) -> int {
+                if (nb >= Rm.x && nb < Rm.x + Rm.y) return ((ee + 2) % 3) * MVT_ENT + (nb - Rm.x);
+                if (nb >= Rp.x && nb < Rp.x + Rp.y) return ((ee + 1) % 3) * MVT_ENT + (nb - Rp.x);
+                return -1;
+            };
+            const double cx = ring[MVT_FLD][own], cy = ring[MVT_FLD + 1][own], cz = ring[MVT_FLD + 2][own];
+            double fl[2 * W], lim[2 * W], dx[2 * W], dy[2 * W], dz[2 * W], wl[W], wu[W], sx[2 * W], sy[2 * W], sz[2 * W];
+            int sl[2 * W];
+            bool mine[2 * W];
+#pragma unroll
+            for (int s = 0; s < W; s++) {
+                sl[s] = L.on[s] ? slotOf(L.nb[s]) : own; sl[W + s] = U.on[s] ? slotOf(U.nb[s]) : own;
+                // lower face: owner = L.nb[s], neighbour = c; upwind is c when the flux is not positive.  d = C[neighbour] - C[owner]
+                fl[s] = L.on[s] ? a.phi[L.f[s]] : 0.0; mine[s] = L.on[s] && !(fl[s] > 0);
+                const double lx = sl[s] >= 0 ? ring[MVT_FLD][sl[s]] : a.Cx[L.nb[s]], ly = sl[s] >= 0 ? ring[MVT_FLD + 1][sl[s]] : a.Cy[L.nb[s]],
+                             lz = sl[s] >= 0 ? ring[MVT_FLD + 2][sl[s]] : a.Cz[L.nb[s]];
+                dx[s] = cx - lx; dy[s] = cy - ly; dz[s] = cz - lz;
+                // upper face: owner = c, neighbour = U.nb[s]; upwind is c when the flux is positive
+                fl[W + s] = U.on[s] ? a.phi[U.f[s]] : 0.0; mine[W + s] = U.on[s] && fl[W + s] > 0;
+                const double ux = sl[W + s] >= 0 ? ring[MVT_FLD][sl[W + s]] : a.Cx[U.nb[s]], uy = sl[W + s] >= 0 ? ring[MVT_FLD + 1][sl[W + s]] : a.Cy[U.nb[s]],
+                             uz = sl[W + s] >= 0 ? ring[MVT_FLD + 2][sl[W + s]] : a.Cz[U.nb[s]];
+                dx[W + s] = ux - cx; dy[W + s] = uy - cy; dz[W + s] = uz - cz;
+                lim[s] = lim[W + s] = 1.0;
+                // face geometry of the gradient (k_grad_multi)
+                wl[s] = q.w[L.f[s]]; wu[s] = q.w[U.f[s]];
+                sx[s] = q.Sfx[L.f[s]]; sy[s] = q.Sfy[L.f[s]]; sz[s] = q.Sfz[L.f[s]];
+                sx[W + s] = q.Sfx[U.f[s]]; sy[W + s] = q.Sfy[U.f[s]]; sz[W + s] = q.Sfz[U.f[s]];
+            }
+            const double V = q.V[c];
+            const int j = q.cellB[c];
+#pragma unroll 1
+            for (int i = 0; i < nf; i++) {
+                const double *__restrict__ vf = a.vf[i];
+                const double P = ring[i][own];
+                double vl[W], vu[W];
+#pragma unroll
+                for (int s = 0; s < W; s++) { vl[s] = sl[s] >= 0 ? ring[i][sl[s]] : vf[L.nb[s]]; vu[s] = sl[W + s] >= 0 ? ring[i][sl[W + s]] : vf[U.nb[s]]; }
+                // ---- fvc::grad of field i at c (k_grad_multi, same order: lower faces, upper faces, boundary faces)
+                double ax = 0, ay = 0, az = 0;
+#pragma unroll
+                for (int s = 0; s < W; s++) if (L.on[s]) {
+                    const double ff = wl[s] * vl[s] + (1.0 - wl[s]) * P;
+                    ax -= sx[s] * ff; ay -= sy[s] * ff; az -= sz[s] * ff;
+                }
+#pragma unroll
+                for (int s = 0; s < W; s++) if (U.on[s]) {
+                    const double ff = wu[s] * P + (1.0 - wu[s]) * vu[s];
+                    ax += sx[W + s] * ff; ay += sy[W + s] * ff; az += sz[W + s] * ff;
+                }
+                if (j >= 0) for (int tt = q.bcStart[j]; tt < q.bcStart[j + 1]; tt++) {
+                    const int k = q.bcItem[tt]; const double b = a.vb[i][k];
+                    ax += q.bSfx[k] * b; ay += q.bSfy[k] * b; az += q.bSfz[k] * b;
+                }
+                const double gxc = ax / V, gyc = ay / V, gzc = az / V;
+                // ---- the limiter of field i on the faces whose upwind cell is c (k_mv_weights)
+                const int sch = a.scheme[i];
+#pragma unroll
+                for (int s = 0; s < W; s++) {
+                    if (mine[s]) {          // P = owner's value (the other cell), N = c's
+                        const double l = mv_limiter(sch, a.twoByk, a.lo, a.hi, fl[s], vl[s], P, dx[s] * gxc + dy[s] * gyc + dz[s] * gzc);
+                        lim[s] = i == 0 ? l : fmin(lim[s], l);
+                    }
+                    if (mine[W + s]) {      // P = c's value, N = the other cell's
+                        const double l = mv_limiter(sch, a.twoByk, a.lo, a.hi, fl[W + s], P, vu[s], dx[W + s] * gxc + dy[W + s] * gyc + dz[W + s] * gzc);
+                        lim[W + s] = i == 0 ? l : fmin(lim[W + s], l);
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < W; s++) {
+                if (mine[s]) { const int e = L.f[s]; const double p0 = fl[s] >= 0 ? 1.0 : 0.0; a.out[e] = lim[s] * q.w[e] + (1.0 - lim[s]) * p0; }
+                if (mine[W + s]) { const int e = U.f[s]; const double p0 = fl[W + s] >= 0 ? 1.0 : 0.0; a.out[e] = lim[W + s] * q.w[e] + (1.0 - lim[W + s]) * p0; }
+            }
+        }
+        __syncthreads();            // entry ee is done: its e-1 buffer may be overwritten by the next stage()
+    }
+}
+
+// ffm_fvc_grad_multi over the nf fields + ffm_fv_multivariate_weights in one LDS-staged pass (bit for bit); FFM_ERR_UNSUPPORTED where the
+// mesh has no tile plan / is one block of a decomposed mesh / nf > 6 -- the caller then runs the two-pass form
+extern "C" int ffm_fv_multivariate_weights_tiled(ffm_mesh *m, int nf, const int *schemes, double k, double lo, double hi, const double *phi_f,
+                                                 const double *const *vf, const double *const *vb, double *out_w)
+{
+    CHECK_M(m);
+    if (nf < 1 || !schemes || !phi_f || !vf || !vb || !out_w) return FFM_ERR_ARG;
+    FfmFvSegs sg;
+    if (nf > MVT_FLD || m->A->maxW > 3 || getenv("FFM_NO_TILE_FV") || !ffm_tile_fv_segments(m->A, MVT_RUN, &sg)) return FFM_ERR_UNSUPPORTED;
+    MvTile a;
+    for (int i = 0; i < MVT_FLD; i++) {
+        const int qq = i < nf ? i : 0;
+        if (i < nf && ((schemes[qq] != 2 && schemes[qq] != 3) || !vf[qq] || (m->B && !vb[qq]))) return FFM_ERR_ARG;
+        a.vf[i] = vf[qq]; a.vb[i] = vb[qq]; a.scheme[i] = schemes[qq];
+    }
+    a.nf = nf; a.phi = phi_f; a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.out = out_w;
+    a.seg = sg.seg; a.rec = sg.rec;
+    hipLaunchKernelGGL(k_mv_tile<3>, dim3(sg.nSeg), dim3(256), 0, m->ctx->stream, mview(m), a);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
 struct LustSource {
     const double *gx[3], *gy[3], *gz[3], *U0[3];
     double *src[3];
@@ -315,7 +464,6 @@ __global__ __launch_bounds__(256) void k_lust_source(MeshView q, LustSource a)
 }
 
 // ------------------------------------------------------------------ entry points (internal + C ABI) ---
-#define CHECK_M(m) if (!(m)) { ffm_set_error("null mesh"); return FFM_ERR_ARG; }
 
 extern "C" int ffm_fvc_grad_multi(ffm_mesh *m, int nf, const double *const *vf, const double *const *vb, double *const *gx,
                                   double *const *gy, double *const *gz)
@@ -361,7 +509,7 @@ extern "C" int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, d
     }
     a.rho = rho; a.rho0 = rho0; a.phi = phi_f; a.phib = phi_b; a.gamma = gamma_f; a.gammab = gamma_b;
     a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.bMagSf = m->bMagSf; a.bDelta = m->bDelta;
-    a.rdt = rDeltaT; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.scheme = scheme; a.wGiven = nullptr;
+    a.rdt = rDeltaT; a.twoByk = 2.0 / std::max(k, 1e-15); a.lo = lo; a.hi = hi; a.scheme = scheme; a.wGiven = nullptr; a.nOffDiag = nf;
 #define SE(NF) FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_scalar_eqns<W, NF>), mview(m), a))
     switch (nf) { case 1: SE(1); break; case 2: SE(2); break; case 3: SE(3); break; default: SE(4); break; }
 #undef SE
@@ -404,7 +552,7 @@ extern "C" int ffm_fvm_scalar_transport_multi_w(ffm_mesh *m, int nf, const doubl
     ScalarEqns a;
     for (int i = 0; i < FUSE_MAX; i++) {
         const int q = i < nf ? i : 0;
-        if (i < nf && (!vf0[q] || !diag[q] || !upper[q] || !lower[q] || !source[q] || (m->B && (!f[q] || !ref[q] || !refGrad[q])))) return FFM_ERR_ARG;
+        if (i < nf && (!vf0[q] || !diag[q] || !source[q] || (m->B && (!f[q] || !ref[q] || !refGrad[q])))) return FFM_ERR_ARG;
         a.vf[i] = a.gx[i] = a.gy[i] = a.gz[i] = nullptr; a.vf0[i] = vf0[q];
         a.f[i] = f[q]; a.ref[i] = ref[q]; a.refGrad[i] = refGrad[q];
         a.su[i] = su ? su[q] : nullptr;
@@ -416,6 +564,9 @@ extern "C" int ffm_fvm_scalar_transport_multi_w(ffm_mesh *m, int nf, const doubl
     a.rho = rho; a.rho0 = rho0; a.phi = phi_f; a.phib = phi_b; a.gamma = gamma_f; a.gammab = gamma_b;
     a.Cx = m->C[0]; a.Cy = m->C[1]; a.Cz = m->C[2]; a.bMagSf = m->bMagSf; a.bDelta = m->bDelta;
     a.rdt = rDeltaT; a.twoByk = 2.0; a.lo = 0.0; a.hi = 1.0; a.scheme = 0; a.wGiven = w_f;
+    // off-diagonals: every field with non-null upper AND lower writes its own; the fields after the first null pair share what was written
+    a.nOffDiag = 0;
+    for (int i = 0; i < nf; i++) { if (upper[i] && lower[i]) { if (a.nOffDiag != i) return FFM_ERR_ARG; a.nOffDiag = i + 1; } else if ((upper[i] == nullptr) != (lower[i] == nullptr)) return FFM_ERR_ARG; }
 #define SEW(NF) FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS((k_scalar_eqns<W, NF, true>), mview(m), a))
     switch (nf) { case 1: SEW(1); break; case 2: SEW(2); break; case 3: SEW(3); break; default: SEW(4); break; }
 #undef SEW

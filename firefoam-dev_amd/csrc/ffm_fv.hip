@@ -26,9 +26,7 @@
 
 template <class T> static int up(ffm_ctx *c, T **d, const std::vector<T> &v)
 {
-    FFM_HIP(hipMalloc((void **)d, sizeof(T) * std::max<size_t>(v.size(), 1)));
-    if (!v.empty()) FFM_HIP(hipMemcpy(*d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
-    return FFM_OK;
+    return ffm_upload_vec(c, d, v);
 }
 
 extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, const double *Sf, const double *magSf,
@@ -101,9 +99,9 @@ extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, con
         for (int f = 0; f < F; f++) nat2caller[A->h_callerToNative[f]] = f;
         std::vector<int> hUpNbr(std::max(nNat, 1));
         FFM_HIP(hipStreamSynchronize(A->ctx->stream));              // (the tables were uploaded on the context's non-blocking stream)
-        FFM_HIP(hipMemcpy(hUpNbr.data(), A->upNbr, sizeof(int) * nNat, hipMemcpyDeviceToHost));
+        FFM_TRY(ffm_d2h(A->ctx, hUpNbr.data(), A->upNbr, sizeof(int) * nNat));
         std::vector<int> hUpOff(A->nSlices + 1);
-        FFM_HIP(hipMemcpy(hUpOff.data(), A->upOff, sizeof(int) * (A->nSlices + 1), hipMemcpyDeviceToHost));
+        FFM_TRY(ffm_d2h(A->ctx, hUpOff.data(), A->upOff, sizeof(int) * (A->nSlices + 1)));
         for (int sl = 0; sl < A->nSlices; sl++) {
             const int wdt = (hUpOff[sl + 1] - hUpOff[sl]) / 64;
             for (int s = 0; s < wdt; s++) for (int lane = 0; lane < 64; lane++) {

@@ -49,12 +49,7 @@ struct Level {              // matrix k (0 = the caller's matrix); maps lead to 
     double *src = nullptr, *corr = nullptr, *acf = nullptr, *pre = nullptr, *tmp = nullptr;
 };
 
-template <class T> int up(T **d, const std::vector<T> &v)
-{
-    FFM_HIP(hipMalloc((void **)d, sizeof(T) * std::max<size_t>(v.size(), 1)));
-    if (!v.empty()) FFM_HIP(hipMemcpy(*d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
-    return FFM_OK;
-}
+template <class T> int up(ffm_ctx *c, T **d, const std::vector<T> &v) { return ffm_upload_vec(c, d, v); }
 int dalloc(double **d, size_t n) { FFM_HIP(hipMalloc((void **)d, sizeof(double) * std::max<size_t>(n, 1))); return FFM_OK; }
 
 // ------------------------------------------------------------------ host: agglomeration
@@ -290,7 +285,7 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
         if (finest->sweepMode == 2 && finest->grpCell && finest->nGroups > 0 && !(e && atoi(e) == 0)) {
             std::vector<int> gc((size_t)finest->nGroups + 1);
             FFM_HIP(hipStreamSynchronize(ctx->stream));              // the table was uploaded on the context's (non-blocking) stream
-            FFM_HIP(hipMemcpy(gc.data(), finest->grpCell, sizeof(int) * gc.size(), hipMemcpyDeviceToHost));
+            FFM_TRY(ffm_d2h(ctx, gc.data(), finest->grpCell, sizeof(int) * gc.size()));
             hint.assign(nCells, 0);
             for (int g = 0; g < finest->nGroups; g++)
                 for (int n = gc[g]; n < gc[g + 1] && n < nCells; n++) hint[finest->identity ? n : finest->h_newToOldCell[n]] = g;
@@ -336,15 +331,15 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
         // ---- maps.  Caller-order CSRs for the coefficients
         std::vector<int> st, it;
         group_by(nCoarse, nFine, cmap, st, it);
-        if ((rc = up(&Lf.cStart, st)) || (rc = up(&Lf.cItem, it))) return fail(rc);
+        if ((rc = up(ctx, &Lf.cStart, st)) || (rc = up(ctx, &Lf.cItem, it))) return fail(rc);
         std::vector<int> key(nF);
         for (int f = 0; f < nF; f++) key[f] = fra[f] < 0 ? -1 - fra[f] : -1;
         group_by(nCoarse, nF, key, st, it);
-        if ((rc = up(&Lf.iStart, st)) || (rc = up(&Lf.iItem, it))) return fail(rc);
+        if ((rc = up(ctx, &Lf.iStart, st)) || (rc = up(ctx, &Lf.iItem, it))) return fail(rc);
         std::vector<int> val(nF);
         for (int f = 0; f < nF; f++) { key[f] = fra[f] >= 0 ? fra[f] : -1; val[f] = f | (flip[f] ? (int)0x80000000 : 0); }
         group_by(nCF, nF, key, st, it, &val);
-        if ((rc = up(&Lf.fStart, st)) || (rc = up(&Lf.fItem, it))) return fail(rc);
+        if ((rc = up(ctx, &Lf.fStart, st)) || (rc = up(ctx, &Lf.fItem, it))) return fail(rc);
         // internal-order maps for the vectors: fine internal i = oldToNew_f[caller], coarse likewise
         const std::vector<int> &n2oF = Lf.A->h_newToOldCell, &n2oC = Lc.A->h_newToOldCell;
         std::vector<int> o2nF(nFine), o2nC(nCoarse);
@@ -355,7 +350,7 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
         // restrict lists: per coarse internal cell its fine cells ascending in CALLER index, stored as internal indices
         for (int c = 0; c < nFine; c++) { keyI[c] = o2nC[cmap[c]]; valI[c] = o2nF[c]; }
         group_by(nCoarse, nFine, keyI, st, it, &valI);
-        if ((rc = up(&Lf.rStart, st)) || (rc = up(&Lf.rItem, it)) || (rc = up(&Lf.toCoarse, toC))) return fail(rc);
+        if ((rc = up(ctx, &Lf.rStart, st)) || (rc = up(ctx, &Lf.rItem, it)) || (rc = up(ctx, &Lf.toCoarse, toC))) return fail(rc);
         // coarse level storage
         if ((rc = dalloc(&Lc.diag, nCoarse)) || (rc = dalloc(&Lc.upper, nCF)) || (rc = dalloc(&Lc.lower, nCF)) || (rc = dalloc(&Lc.dInt, nCoarse)) ||
             (rc = dalloc(&Lc.src, nCoarse)) || (rc = dalloc(&Lc.corr, nCoarse)) || (rc = dalloc(&Lc.acf, nCoarse)) || (rc = dalloc(&Lc.pre, nCoarse)) ||
@@ -389,9 +384,9 @@ extern "C" int ffm_gamg_get_level_coeffs(ffm_gamg *G, int level, double *diag, d
     if (!G || level < 0 || level >= (int)G->lev.size() || !G->haveMatrix) return FFM_ERR_ARG;
     const Level &L = G->lev[level];
     FFM_HIP(hipStreamSynchronize(G->ctx->stream));
-    if (diag) FFM_HIP(hipMemcpy(diag, L.diag, sizeof(double) * L.nCells, hipMemcpyDeviceToHost));
-    if (upper) FFM_HIP(hipMemcpy(upper, L.upper, sizeof(double) * L.nFaces, hipMemcpyDeviceToHost));
-    if (lower) FFM_HIP(hipMemcpy(lower, G->symmetric ? L.upper : L.lower, sizeof(double) * L.nFaces, hipMemcpyDeviceToHost));
+    if (diag) FFM_TRY(ffm_d2h(G->ctx, diag, L.diag, sizeof(double) * L.nCells));
+    if (upper) FFM_TRY(ffm_d2h(G->ctx, upper, L.upper, sizeof(double) * L.nFaces));
+    if (lower) FFM_TRY(ffm_d2h(G->ctx, lower, G->symmetric ? L.upper : L.lower, sizeof(double) * L.nFaces));
     return FFM_OK;
 }
 
@@ -450,7 +445,7 @@ extern "C" int ffm_gamg_set_matrix_native_d(ffm_gamg *G, const double *diag_d, c
     FFM_HIP(hipSetDevice(G->ctx->device));
     hipStream_t s = G->ctx->stream;
     if (!G->faceToNative) {
-        FFM_TRY(up(&G->faceToNative, L0.A->h_callerToNative));
+        FFM_TRY(up(G->ctx, &G->faceToNative, L0.A->h_callerToNative));
         FFM_TRY(dalloc(&G->upC, L0.nFaces)); FFM_TRY(dalloc(&G->loC, L0.nFaces));
     }
     G->symmetric = lowerNative_d == nullptr;

@@ -11,6 +11,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <algorithm>
 #include <unordered_map>
 
 #include "../../include/ffm.h"
@@ -80,6 +81,35 @@ struct ffm_ctx {
     std::unordered_map<void *, size_t> poolSize;
     size_t poolCachedBytes = 0, poolCapBytes = (size_t)96 << 30;
 };
+
+// Host <-> device copies, correct by construction: the context's stream is created non-blocking, so a null-stream hipMemcpy neither
+// waits for work queued on it (a pooled block's zero-fill, a kernel that writes the table being read back) nor is waited for by it.
+// Every copy of the library therefore goes through these two -- queued on the context's stream and waited for -- and the bare
+// runtime calls are poisoned for the rest of every translation unit that includes this header.
+inline int ffm_h2d(ffm_ctx *c, void *dst_d, const void *src, size_t bytes)
+{
+    if (!bytes) return FFM_OK;
+    FFM_HIP(hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream));
+    return FFM_OK;
+}
+inline int ffm_d2h(ffm_ctx *c, void *dst, const void *src_d, size_t bytes)
+{
+    if (!bytes) return FFM_OK;
+    FFM_HIP(hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, c->stream)); FFM_HIP(hipStreamSynchronize(c->stream));
+    return FFM_OK;
+}
+inline int ffm_dzero(ffm_ctx *c, void *dst_d, size_t bytes)
+{
+    if (!bytes) return FFM_OK;
+    FFM_HIP(hipMemsetAsync(dst_d, 0, bytes, c->stream));
+    return FFM_OK;
+}
+template <class T> inline int ffm_upload_vec(ffm_ctx *c, T **d, const std::vector<T> &v, size_t minCount = 1)
+{
+    FFM_HIP(hipMalloc((void **)d, sizeof(T) * std::max<size_t>(v.size(), minCount)));
+    return ffm_h2d(c, *d, v.data(), sizeof(T) * v.size());
+}
+#pragma GCC poison hipMemcpy hipMemset
 
 // key of a cached hipGraph of level-scheduled sweeps: EVERY device pointer the captured kernels bake in
 struct SweepGraphKey {
@@ -250,6 +280,8 @@ bool ffm_tile_amul_usable(const ffm_ldu *A);
 int ffm_tile_amul(ffm_ldu *A, const double *x, double *y, int dotSlot);     // returns 1 if the dot product is left to the caller
 void ffm_tile_free(ffm_ldu *A);
 bool ffm_tile_usable(const ffm_ldu *A);
+struct FfmFvSegs { int nSeg; const int4 *seg; const int4 *rec; };
+bool ffm_tile_fv_segments(ffm_ldu *A, int runLength, FfmFvSegs *out);   // single block, tile plan present: FV face passes through LDS (ffm_fused.hip)
 bool ffm_tile_pcg_fusable(const ffm_ldu *A);
 int ffm_tile_pcg_fwd(ffm_ldu *A, double *rA, double *wA, int slot, const double *qA = nullptr);
 bool ffm_tile_amul_pcg_usable(const ffm_ldu *A);

@@ -713,9 +713,9 @@ extern "C" int ffm_ldu_set_coeffs(ffm_ldu *A, const double *diag, const double *
     const size_t nb = sizeof(double) * std::max(A->nCells, 1), fb = sizeof(double) * std::max(A->nFaces, 1);
     FFM_HIP(hipMalloc((void **)&d, nb)); FFM_HIP(hipMalloc((void **)&u, fb));
     if (lower) FFM_HIP(hipMalloc((void **)&l, fb));
-    FFM_HIP(hipMemcpy(d, diag, sizeof(double) * A->nCells, hipMemcpyHostToDevice));
-    if (A->nFaces) FFM_HIP(hipMemcpy(u, upper, sizeof(double) * A->nFaces, hipMemcpyHostToDevice));
-    if (lower && A->nFaces) FFM_HIP(hipMemcpy(l, lower, sizeof(double) * A->nFaces, hipMemcpyHostToDevice));
+    FFM_TRY(ffm_h2d(A->ctx, d, diag, sizeof(double) * A->nCells));
+    if (A->nFaces) FFM_TRY(ffm_h2d(A->ctx, u, upper, sizeof(double) * A->nFaces));
+    if (lower && A->nFaces) FFM_TRY(ffm_h2d(A->ctx, l, lower, sizeof(double) * A->nFaces));
     FFM_HIP(hipDeviceSynchronize());           // the null-stream uploads have landed before the context's (non-blocking) stream reads them
     int rc = ffm_ldu_set_coeffs_d(A, d, u, l);
     hipStreamSynchronize(A->ctx->stream);

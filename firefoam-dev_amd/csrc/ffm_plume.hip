@@ -62,6 +62,8 @@ int ffm_fvm_scalar_transport_multi_w(ffm_mesh *, int, const double *, double, co
                                      const double *const *, double *const *, double *const *, double *const *, double *const *);
 int ffm_fvm_lust_source3(ffm_mesh *, double, const double *, const double *, const double *const *, const double *const *,
                          const double *const *, const double *const *, double *const *);
+int ffm_fv_multivariate_weights_tiled(ffm_mesh *, int, const int *, double, double, double, const double *, const double *const *,
+                                      const double *const *, double *);
 }
 const int *ffm_mesh_bcells(const ffm_mesh *m);
 const double *ffm_mesh_geom(const ffm_mesh *m, int which);
@@ -143,14 +145,14 @@ static double *dalloc(ffm_plume *P, size_t n)
 {
     double *p = nullptr;
     if (hipMalloc((void **)&p, sizeof(double) * std::max<size_t>(n, 1)) != hipSuccess) return nullptr;
-    hipMemset(p, 0, sizeof(double) * std::max<size_t>(n, 1));   // synchronous: uploads below use the null stream
+    if (ffm_dzero(P->ctx, p, sizeof(double) * std::max<size_t>(n, 1)) != FFM_OK) { hipFree(p); return nullptr; }
     P->pool.push_back(p);
     return p;
 }
 static double *dupload(ffm_plume *P, const std::vector<double> &v)
 {
     double *p = dalloc(P, v.size());
-    if (p && !v.empty()) hipMemcpy(p, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice);
+    if (p && !v.empty() && ffm_h2d(P->ctx, p, v.data(), sizeof(double) * v.size()) != FFM_OK) return nullptr;
     return p;
 }
 template <class Fn> static void forN(ffm_plume *P, long n, Fn f)
@@ -649,7 +651,18 @@ extern "C" int ffm_plume_step(ffm_plume *P)
             forN(P, B, [=] __device__(long k) { const double t = ((fmax(b0[k], 0.0) + fmax(b1[k], 0.0)) + fmax(b2[k], 0.0)) + fmax(b3[k], 0.0); Nb[k] = fmax(1.0 - t, 0.0); });
         }
         FFM_TRY(ffm_bc_values(m, P->fH, P->refH, P->zeroB, P->hs, hb));
+        int rcTiled = FFM_ERR_UNSUPPORTED;
         if (P->fused) {
+            // gradients of the six fields + the common limiter in ONE pass with the cell values staged through LDS on the tile numbering
+            // (ffm_fused.hip: k_mv_tile; bit for bit the two gradient passes + ffm_fv_multivariate_weights below)
+            const double *af6[6] = {P->hs, P->Y[sp4[0]], P->Y[sp4[1]], P->Y[sp4[2]], P->Y[sp4[3]], P->Y[INERT]};
+            const double *ab6[6] = {hb, P->spB[0], P->spB[1], P->spB[2], P->spB[3], Nb};
+            const int sch6[6] = {2, 3, 3, 3, 3, 3};
+            rcTiled = ffm_fv_multivariate_weights_tiled(m, 6, sch6, 1.0, 0.0, 1.0, P->phi, af6, ab6, P->wMv);
+            if (rcTiled != FFM_OK && rcTiled != FFM_ERR_UNSUPPORTED) return rcTiled;
+        }
+        if (rcTiled == FFM_OK) { /* done */ }
+        else if (P->fused) {
             const double *vf[6], *vb[4], *cgx[6], *cgy[6], *cgz[6]; double *ggx[4], *ggy[4], *ggz[4]; int sch[6];
             // h first, then the transported species, then the inert one (the minimum does not depend on the order)
             const double *vf2[2] = {P->hs, P->Y[INERT]}, *vb2[2] = {hb, Nb};
@@ -690,9 +703,12 @@ extern "C" int ffm_plume_step(ffm_plume *P)
             vf[j] = P->Y[i]; vb[j] = P->spB[j]; vf0[j] = P->Y0[i]; fq[j] = P->fS; rq[j] = P->refY[i]; gq[j] = P->zeroB; suq[j] = sj;
             ggx[j] = P->gM[j][0]; ggy[j] = P->gM[j][1]; ggz[j] = P->gM[j][2]; cgx[j] = ggx[j]; cgy[j] = ggy[j]; cgz[j] = ggz[j];
         }
+        // with the common weights and one diffusivity the four species have the SAME off-diagonal coefficients (only diag and source
+        // differ, through the patch conditions and the sources): written once, gathered into the sweeps' layout once
+        double *uShared[4] = {P->spU[0], nullptr, nullptr, nullptr}, *lShared[4] = {P->spL[0], nullptr, nullptr, nullptr};
         if (P->mvSelection)
             FFM_TRY(ffm_fvm_scalar_transport_multi_w(m, ns, P->wMv, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf0, fq, rq, gq, suq, nullptr, nullptr,
-                                                     nullptr, P->spD, P->spU, P->spL, P->spS));
+                                                     nullptr, P->spD, uShared, lShared, P->spS));
         else {
         FFM_TRY(ffm_fvc_grad_multi(m, ns, vf, vb, ggx, ggy, ggz));
         for (int j = 0; j < ns; j++) { FFM_TRY(HX(P, ggx[j])); FFM_TRY(HX(P, ggy[j])); FFM_TRY(HX(P, ggz[j])); }
@@ -701,7 +717,8 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         }
         for (int j = 0; j < ns; j++) {
             const int i = sp[j];
-            FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[j], P->spL[j], P->Y[i], P->spS[j]));
+            if (P->mvSelection) FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[0], P->spL[0], P->Y[i], P->spS[j], j > 0));
+            else FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[j], P->spL[j], P->Y[i], P->spS[j]));
             FFM_TRY(HX(P, P->Y[i]));
             double *Yi = P->Y[i];
             forN(P, N, [=] __device__(long c) { const double v = fmax(Yi[c], 0.0); Yi[c] = v; Yt[c] += v; });
@@ -719,7 +736,8 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         double *Yn = P->Y[INERT];
         forN(P, N, [=] __device__(long c) { Yn[c] = fmax(1.0 - Yt[c], 0.0); });
     }
-    if (P->radFreq > 0 && P->stepNo % P->radFreq == 0) FFM_TRY(radiation_correct(P));       // radiation->correct(), solver/YEEqn.H:80
+    bool speciesOffDiagBound = P->fused && P->mvSelection;      // the species' off-diagonals are the matrix' bound (and gathered) ones
+    if (P->radFreq > 0 && P->stepNo % P->radFreq == 0) { FFM_TRY(radiation_correct(P)); speciesOffDiagBound = false; }       // radiation->correct(), solver/YEEqn.H:80
     // EEqn: explicit LHS terms fvc::ddt(rho,K) + fvc::div(phi,K) - dpdt
     {
         FFM_TRY(U_boundary(P, Ub));     // U.correctBoundaryConditions() after the momentum solve
@@ -759,6 +777,10 @@ extern "C" int ffm_plume_step(ffm_plume *P)
             double *ggx[1] = {P->gM[0][0]}, *ggy[1] = {P->gM[0][1]}, *ggz[1] = {P->gM[0][2]};
             const double *cgx[1] = {ggx[0]}, *cgy[1] = {ggy[0]}, *cgz[1] = {ggz[0]}, *su2q[1] = {shSu}, *spq[1] = {shSp};
             double *dd[1] = {P->dWork}, *uu[1] = {P->upper}, *ll[1] = {P->lower}, *ss[1] = {P->sWork};
+            // h is convected with the same weights and diffuses with the same alphaEff (Le = 1: af) as the species: where their
+            // off-diagonals are still the bound ones (no ray solve in between) the enthalpy matrix shares them as well
+            const bool shareH = speciesOffDiagBound;
+            if (shareH) { uu[0] = nullptr; ll[0] = nullptr; }
             if (P->mvSelection)
                 FFM_TRY(ffm_fvm_scalar_transport_multi_w(m, 1, P->wMv, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf0, fq, rq, gq, suq, su2q, spq, expl,
                                                          dd, uu, ll, ss));
@@ -769,7 +791,8 @@ extern "C" int ffm_plume_step(ffm_plume *P)
             FFM_TRY(ffm_fvm_scalar_transport_multi(m, 1, 2, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
                                                    fq, rq, gq, suq, su2q, spq, expl, dd, uu, ll, ss));
             }
-            FFM_TRY(solve_named(P, "h", FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->dWork, P->upper, P->lower, P->hs, P->sWork));
+            if (shareH) FFM_TRY(solve_named(P, "h", FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->dWork, P->spU[0], P->spL[0], P->hs, P->sWork, true));
+            else FFM_TRY(solve_named(P, "h", FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->dWork, P->upper, P->lower, P->hs, P->sWork));
             FFM_TRY(HX(P, P->hs));
         } else
         FFM_TRY(scalar_transport(P, "h", 2, P->hs, P->hs0, P->fH, P->refH, af, afb, Qdot, expl, 1e-8, shSu, shSp, P->mvSelection ? P->wMv : nullptr));
@@ -978,7 +1001,8 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     for (int j = 0; j < 4; j++) {
         for (int d = 0; d < 3; d++) P->gM[j][d] = P->fused ? NN() : nullptr;
         P->spD[j] = P->fused ? NN() : nullptr; P->spS[j] = P->fused ? NN() : nullptr; P->suM[j] = P->fused ? NN() : nullptr;
-        P->spU[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spL[j] = P->fused ? dalloc(P, nNat) : nullptr; P->spB[j] = (P->fused || P->mvSelection) ? dalloc(P, B) : nullptr;
+        const bool ownOffDiag = P->fused && (j == 0 || !P->mvSelection);       // common limiter: the species share one pair of off-diagonal arrays
+        P->spU[j] = ownOffDiag ? dalloc(P, nNat) : nullptr; P->spL[j] = ownOffDiag ? dalloc(P, nNat) : nullptr; P->spB[j] = (P->fused || P->mvSelection) ? dalloc(P, B) : nullptr;
     }
     for (double *p : P->pool) if (!p) { ffm_set_error("plume: out of device memory"); return FFM_ERR_HIP; }
     PL_HIP(hipDeviceSynchronize());
@@ -1056,8 +1080,8 @@ extern "C" int ffm_plume_set_radiation(ffm_plume *P, int solverFreq, int nPhi, i
                 fm[c2n[f]] = swap ? ~c2n[fp] : c2n[fp];
             }
             PL_HIP(hipMalloc((void **)&P->radCm[a], sizeof(int) * N)); PL_HIP(hipMalloc((void **)&P->radFm[a], sizeof(int) * std::max<long>(nNat, 1)));
-            PL_HIP(hipMemcpy(P->radCm[a], cm.data(), sizeof(int) * N, hipMemcpyHostToDevice));
-            PL_HIP(hipMemcpy(P->radFm[a], fm.data(), sizeof(int) * std::max<long>(nNat, 1), hipMemcpyHostToDevice));
+            FFM_TRY(ffm_h2d(P->ctx, P->radCm[a], cm.data(), sizeof(int) * N));
+            FFM_TRY(ffm_h2d(P->ctx, P->radFm[a], fm.data(), sizeof(int) * std::max<long>(nNat, 1)));
         }
         P->radDB = dalloc(P, N); P->radSB = dalloc(P, N); P->radPsiB = dalloc(P, N); P->radUB = dalloc(P, nNat); P->radLB = dalloc(P, nNat);
         if (!P->radDB || !P->radSB || !P->radPsiB || !P->radUB || !P->radLB) return FFM_ERR_HIP;
@@ -1144,7 +1168,7 @@ extern "C" int ffm_plume_get_field(ffm_plume *P, const char *name, double *out)
     if (!src) { ffm_set_error("unknown field %s", name); return FFM_ERR_ARG; }
     std::vector<double> v(P->N);
     PL_HIP(hipStreamSynchronize(P->ctx->stream));
-    PL_HIP(hipMemcpy(v.data(), src, sizeof(double) * P->N, hipMemcpyDeviceToHost));
+    FFM_TRY(ffm_d2h(P->ctx, v.data(), src, sizeof(double) * P->N));
     for (int c = 0; c < P->nOwn; c++) out[P->newToOld[c]] = v[c];      // owned cells, local natural (blockMesh) order
     return FFM_OK;
 }
@@ -1158,3 +1182,4 @@ extern "C" int ffm_plume_get_solve(const ffm_plume *P, int i, char *name16, ffm_
     return FFM_OK;
 }
 extern "C" ffm_ldu *ffm_plume_ldu(ffm_plume *P) { return P ? P->A : nullptr; }
+extern "C" ffm_mesh *ffm_plume_mesh(ffm_plume *P) { return P ? P->mesh : nullptr; }

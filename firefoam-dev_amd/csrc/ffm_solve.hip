@@ -468,8 +468,8 @@ static bool small_usable(ffm_ldu *A)
     }
     if (hipMalloc((void **)&A->smallFwdStart, sizeof(int) * (A->nLevels + 1)) != hipSuccess) return false;
     if (hipMalloc((void **)&A->smallBwdRange, sizeof(int) * br.size()) != hipSuccess) return false;
-    if (hipMemcpy(A->smallFwdStart, A->h_fwdLevelStart.data(), sizeof(int) * (A->nLevels + 1), hipMemcpyHostToDevice) != hipSuccess) return false;
-    if (hipMemcpy(A->smallBwdRange, br.data(), sizeof(int) * br.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (ffm_h2d(A->ctx, A->smallFwdStart, A->h_fwdLevelStart.data(), sizeof(int) * (A->nLevels + 1)) != FFM_OK) return false;
+    if (ffm_h2d(A->ctx, A->smallBwdRange, br.data(), sizeof(int) * br.size()) != FFM_OK) return false;
     A->smallState = 1;
     return true;
 }
@@ -672,10 +672,10 @@ static bool flow_usable(ffm_ldu *A)
         if (k != ord.size()) return false;
     } else {
         if (hipStreamSynchronize(A->ctx->stream) != hipSuccess) return false;        // (uploaded on the context's non-blocking stream)
-        if (hipMemcpy(ord.data(), A->bwdOrder, sizeof(int) * ord.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (ffm_d2h(A->ctx, ord.data(), A->bwdOrder, sizeof(int) * ord.size()) != FFM_OK) return false;
     }
     if (hipMalloc((void **)&A->flowOrder, sizeof(int) * ord.size()) != hipSuccess) return false;
-    if (hipMemcpy(A->flowOrder, ord.data(), sizeof(int) * ord.size(), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (ffm_h2d(A->ctx, A->flowOrder, ord.data(), sizeof(int) * ord.size()) != FFM_OK) return false;
     if (!A->sweepTicket) {
         if (hipMalloc((void **)&A->sweepTicket, 2 * sizeof(unsigned int)) != hipSuccess) return false;
         // on the context's stream: a null-stream hipMemset returns before it has run and is not ordered against that (non-blocking)
@@ -716,7 +716,7 @@ int ffm_flow_check_abort(ffm_ldu *A)
     if (h[1]) {
         ffm_set_error("dataflow sweep timed out waiting for the value of a predecessor cell (abort word set)");
         unsigned int z = 0;
-        hipMemcpy(A->sweepTicket + 1, &z, sizeof(z), hipMemcpyHostToDevice);
+        ffm_h2d(A->ctx, A->sweepTicket + 1, &z, sizeof(z));
         return FFM_ERR_HIP;
     }
     return FFM_OK;
@@ -1201,11 +1201,10 @@ extern "C" int ffm_solve(ffm_ldu *A, int solver, int precond, double tol, double
     double *p = nullptr, *b = nullptr;
     const size_t nb = sizeof(double) * (size_t)std::max(A->nCells, 1);
     FFM_HIP(hipMalloc((void **)&p, nb)); FFM_HIP(hipMalloc((void **)&b, nb));
-    FFM_HIP(hipMemcpy(p, psi, sizeof(double) * A->nOwned, hipMemcpyHostToDevice));
-    FFM_HIP(hipMemcpy(b, source, sizeof(double) * A->nOwned, hipMemcpyHostToDevice));
-    FFM_HIP(hipDeviceSynchronize());           // (null-stream uploads vs the context's non-blocking stream)
+    FFM_TRY(ffm_h2d(A->ctx, p, psi, sizeof(double) * A->nOwned));
+    FFM_TRY(ffm_h2d(A->ctx, b, source, sizeof(double) * A->nOwned));
     int rc = ffm_solve_d(A, solver, precond, tol, relTol, minIter, maxIter, nSweeps, p, b, out);
-    if (!rc && hipMemcpy(psi, p, sizeof(double) * A->nOwned, hipMemcpyDeviceToHost) != hipSuccess) rc = FFM_ERR_HIP;
+    if (!rc) rc = ffm_d2h(A->ctx, psi, p, sizeof(double) * A->nOwned);
     hipFree(p); hipFree(b);
     return rc;
 }

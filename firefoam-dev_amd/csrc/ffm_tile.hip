@@ -89,9 +89,28 @@ struct ffm_tile_plan {
     int nSeg = 0;                   // workgroups of the tiled Amul: a segment = a run of entries of one group
     int4 *aseg = nullptr;           // [nSeg] {group, first entry, end entry, end entry of the group}
     double *amulPartials = nullptr; // [nSeg]
+    int4 *fvSeg = nullptr; int nFvSeg = 0, fvRun = 0;      // segments of the FV face passes (ffm_tile_fv_segments)
     int nTail = 0;                  // cells that own faces towards ghost cells (processed after the tiled kernel, in face order)
     int *tailCell = nullptr, *tailStart = nullptr, *tailFace = nullptr, *tailNbr = nullptr;
 };
+
+// ---- FV face passes on the tile numbering (ffm_fused.hip: k_mv_tile): runs of forward entries of one group, one workgroup each
+// {first entry of the group, first entry of the run, end entry of the run, end entry of the group}; entry records = the forward plan's
+bool ffm_tile_fv_segments(ffm_ldu *A, int runLength, FfmFvSegs *out)
+{
+    ffm_tile_plan *T = A->tile;
+    if (!T || !T->usable || T->grpEntHost.empty() || A->nCells != A->nOwned) return false;
+    if (!T->fvSeg || T->fvRun != runLength) {
+        std::vector<int4> seg;
+        const std::vector<int> &ge = T->grpEntHost;
+        for (int g = 0; g < T->G; g++) for (int a = ge[g]; a < ge[g + 1]; a += runLength) seg.push_back(make_int4(ge[g], a, std::min(a + runLength, ge[g + 1]), ge[g + 1]));
+        if (T->fvSeg) { hipFree(T->fvSeg); T->fvSeg = nullptr; }
+        if (ffm_upload_vec(A->ctx, &T->fvSeg, seg) != FFM_OK) return false;
+        T->nFvSeg = (int)seg.size(); T->fvRun = runLength;
+    }
+    out->nSeg = T->nFvSeg; out->seg = T->fvSeg; out->rec = T->f.rec;
+    return true;
+}
 
 static void free_dir(TileDir &d)
 {
@@ -104,18 +123,13 @@ void ffm_tile_free(ffm_ldu *A)
     free_dir(A->tile->f); free_dir(A->tile->b);
     hipFree(A->tile->mailAll); hipFree(A->tile->trace); hipFree(A->tile->wp); hipFree(A->tile->rDp);
     hipFree(A->tile->arec); hipFree(A->tile->acode); hipFree(A->tile->aext); hipFree(A->tile->aseg); hipFree(A->tile->amulPartials);
-    hipFree(A->tile->upSrcCell); hipFree(A->tile->upNbrCell); hipFree(A->tile->upCoefCell); hipFree(A->tile->diagp);
+    hipFree(A->tile->fvSeg); hipFree(A->tile->upSrcCell); hipFree(A->tile->upNbrCell); hipFree(A->tile->upCoefCell); hipFree(A->tile->diagp);
     hipFree(A->tile->tailCell); hipFree(A->tile->tailStart); hipFree(A->tile->tailFace); hipFree(A->tile->tailNbr);
     delete A->tile; A->tile = nullptr;
 }
 bool ffm_tile_usable(const ffm_ldu *A) { return A->tile && A->tile->usable; }
 
-template <class T> static int upv(T **d, const std::vector<T> &v)
-{
-    FFM_HIP(hipMalloc((void **)d, sizeof(T) * std::max<size_t>(v.size(), 1)));
-    if (!v.empty()) FFM_HIP(hipMemcpy(*d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
-    return FFM_OK;
-}
+template <class T> static int upv(ffm_ctx *c, T **d, const std::vector<T> &v) { return ffm_upload_vec(c, d, v); }
 
 // The tiled sweeps need at most T_W lower and T_W upper neighbours per owned cell (ghost neighbours not counted) and,
 // inside every group, a backward order that is the reverse of the forward order (LduAnalysis::bwdIsReverse).
@@ -213,8 +227,8 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
     if (grpEntOut) *grpEntOut = grpEnt;
     for (int k = 0; k < 2 * T_PF + 2; k++) rec.push_back(make_int4(0, 0, 0, 0));      // read-ahead padding
     for (int k = 0; k < T_THREADS; k++) extSrc.push_back(0);
-    FFM_TRY(upv(&D.grpEnt, grpEnt)); FFM_TRY(upv(&D.rec, rec)); FFM_TRY(upv(&D.extSrc, extSrc)); FFM_TRY(upv(&D.code, code)); FFM_TRY(upv(&D.src, src));
-    if (!fwd) FFM_TRY(upv(&D.nbrCell, nbr));
+    FFM_TRY(upv(A->ctx, &D.grpEnt, grpEnt)); FFM_TRY(upv(A->ctx, &D.rec, rec)); FFM_TRY(upv(A->ctx, &D.extSrc, extSrc)); FFM_TRY(upv(A->ctx, &D.code, code)); FFM_TRY(upv(A->ctx, &D.src, src));
+    if (!fwd) FFM_TRY(upv(A->ctx, &D.nbrCell, nbr));
     return FFM_OK;
 }
 
@@ -286,7 +300,7 @@ static int build_dir_pos(ffm_ldu *A, const std::vector<int> &bl, const std::vect
     D.nEnt = (int)rec.size(); D.nPub = nPub;
     for (int k = 0; k < 2 * T_PF + 2; k++) rec.push_back(make_int4(0, 0, 0, 0));
     for (int k = 0; k < T_THREADS; k++) extSrc.push_back(0);
-    FFM_TRY(upv(&D.grpEnt, grpEnt)); FFM_TRY(upv(&D.rec, rec)); FFM_TRY(upv(&D.extSrc, extSrc)); FFM_TRY(upv(&D.code, code)); FFM_TRY(upv(&D.src, src));
+    FFM_TRY(upv(A->ctx, &D.grpEnt, grpEnt)); FFM_TRY(upv(A->ctx, &D.rec, rec)); FFM_TRY(upv(A->ctx, &D.extSrc, extSrc)); FFM_TRY(upv(A->ctx, &D.code, code)); FFM_TRY(upv(A->ctx, &D.src, src));
     return FFM_OK;
 }
 
@@ -332,9 +346,9 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
         }
         if (ghostSeen) tailStart.push_back((int)tailFace.size());
     }
-    FFM_TRY(upv(&T->upSrcCell, upSrc)); FFM_TRY(upv(&T->upNbrCell, upNb));
+    FFM_TRY(upv(A->ctx, &T->upSrcCell, upSrc)); FFM_TRY(upv(A->ctx, &T->upNbrCell, upNb));
     T->nTail = (int)tailCell.size();
-    FFM_TRY(upv(&T->tailCell, tailCell)); FFM_TRY(upv(&T->tailStart, tailStart)); FFM_TRY(upv(&T->tailFace, tailFace)); FFM_TRY(upv(&T->tailNbr, tailNbr));
+    FFM_TRY(upv(A->ctx, &T->tailCell, tailCell)); FFM_TRY(upv(A->ctx, &T->tailStart, tailStart)); FFM_TRY(upv(A->ctx, &T->tailFace, tailFace)); FFM_TRY(upv(A->ctx, &T->tailNbr, tailNbr));
     T->gsTables = true;
 #define AMUL_GIVE_UP(why) do { if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm: no ring plan for the tiled Amul (%s, entry %d of %d): row kernel\n", why, e, nEnt); return FFM_OK; } while (0)
     // ---- ring plan of the tiled Amul: may give up (too many out-of-window neighbours in one entry), Amul then runs on the row kernel
@@ -382,9 +396,9 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
     }
     for (int k = 0; k < 2 * A_PF + 2; k++) arec.push_back(make_int4(0, 0, 0, 0));
     for (int k = 0; k < 2 * A_XMAX; k++) aext.push_back(make_int2(0, -1));
-    FFM_TRY(upv(&T->arec, arec)); FFM_TRY(upv(&T->aext, aext));
+    FFM_TRY(upv(A->ctx, &T->arec, arec)); FFM_TRY(upv(A->ctx, &T->aext, aext));
     FFM_HIP(hipMalloc((void **)&T->acode, sizeof(unsigned short) * 8 * std::max<size_t>(nOwn, 1)));
-    FFM_HIP(hipMemcpy(T->acode, code.data(), sizeof(unsigned short) * code.size(), hipMemcpyHostToDevice));
+    FFM_TRY(ffm_h2d(A->ctx, T->acode, code.data(), sizeof(unsigned short) * code.size()));
     // segments: enough workgroups to fill the chip, each long enough to amortise the A_WIN entries read twice at either end
     {
         const std::vector<int> &grpEntH = T->grpEntHost;
@@ -395,7 +409,7 @@ static int build_amul(ffm_ldu *A, const std::vector<int> &grpOfCell, const std::
         std::vector<int4> seg;
         for (int g = 0; g < T->G; g++) for (int a = grpEntH[g]; a < grpEntH[g + 1]; a += L) seg.push_back(make_int4(g, a, std::min(a + L, grpEntH[g + 1]), grpEntH[g + 1]));
         T->nSeg = (int)seg.size();
-        FFM_TRY(upv(&T->aseg, seg));
+        FFM_TRY(upv(A->ctx, &T->aseg, seg));
         FFM_HIP(hipMalloc((void **)&T->amulPartials, sizeof(double) * std::max(T->nSeg, 1)));      // x.y of every segment (fused dot)
     }
     T->amulUsable = true;
@@ -825,7 +839,7 @@ int ffm_tile_check_abort(ffm_ldu *A)
     if (h[1]) {
         ffm_set_error("tiled sweep timed out waiting for a value of a predecessor group (abort word set)");
         unsigned int z = 0;
-        hipMemcpy(A->sweepTicket + 1, &z, sizeof(z), hipMemcpyHostToDevice);
+        ffm_h2d(A->ctx, A->sweepTicket + 1, &z, sizeof(z));
         return FFM_ERR_HIP;
     }
     return FFM_OK;
@@ -1158,10 +1172,10 @@ extern "C" int ffm_debug_tile_trace(ffm_ldu *A, unsigned long long *out, int nWo
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
     if (!T->trace) {
         FFM_HIP(hipMalloc((void **)&T->trace, sizeof(unsigned long long) * 4 * T->G));
-        FFM_HIP(hipMemset(T->trace, 0, sizeof(unsigned long long) * 4 * T->G));
+        FFM_TRY(ffm_dzero(A->ctx, T->trace, sizeof(unsigned long long) * 4 * T->G)); FFM_HIP(hipStreamSynchronize(A->ctx->stream));
         return T->G;
     }
-    if (out && nWords > 0) FFM_HIP(hipMemcpy(out, T->trace, sizeof(unsigned long long) * std::min(nWords, 4 * T->G), hipMemcpyDeviceToHost));
+    if (out && nWords > 0) FFM_TRY(ffm_d2h(A->ctx, out, T->trace, sizeof(unsigned long long) * std::min(nWords, 4 * T->G)));
     return T->G;
 }
 
@@ -1169,7 +1183,7 @@ extern "C" int ffm_debug_set_sweep_ticket(ffm_ldu *A, unsigned int value)
 {
     if (!A || !A->sweepTicket) return FFM_ERR_ARG;
     FFM_HIP(hipStreamSynchronize(A->ctx->stream));
-    FFM_HIP(hipMemcpy(A->sweepTicket, &value, sizeof(value), hipMemcpyHostToDevice));
+    FFM_TRY(ffm_h2d(A->ctx, A->sweepTicket, &value, sizeof(value)));
     return FFM_OK;
 }
 

@@ -288,6 +288,13 @@ int ffm_fv_weights_from_limiter(ffm_mesh *m, const double *phi_f, const double *
 int ffm_fv_multivariate_weights(ffm_mesh *m, int nf, const int *schemes, double k, double lo, double hi, const double *phi_f,
                                 const double *const *vf, const double *const *gx, const double *const *gy, const double *const *gz,
                                 double *out_w);
+/* ffm_fvc_grad_multi over the nf <= 6 fields + ffm_fv_multivariate_weights in ONE pass with the cell values staged through LDS on the tile
+ * numbering (a workgroup walks a run of dependency levels of one tile; the values of the levels e-1, e, e+1 sit in an LDS window, a cell
+ * forms its own gradients in registers, a face is written by its upwind cell): bit for bit the two-pass form without the 3 nf gradient
+ * arrays.  vb: the fields' boundary values.  FFM_ERR_UNSUPPORTED where the matrix has no tile plan, the mesh is one block of a decomposed
+ * case, cells have more than 3 lower / upper neighbours or nf > 6: the caller then runs the two-pass form.                            */
+int ffm_fv_multivariate_weights_tiled(ffm_mesh *m, int nf, const int *schemes, double k, double lo, double hi, const double *phi_f,
+                                      const double *const *vf, const double *const *vb, double *out_w);
 
 /* filteredLinear2V k l: the face weights of a VECTOR field, one limiter per face for its three components
  * (`div(phi,U) Gauss filteredLinear2V 0.2 0.05`, cases/wallFireSpread2D/system/fvSchemes:41, cases/pyrolysis1D/system/fvSchemes:39;
@@ -389,7 +396,9 @@ int ffm_fvm_scalar_transport_multi(ffm_mesh *m, int nf, int scheme, double k, do
                                    const double *const *expl3, double *const *diag, double *const *upper,
                                    double *const *lower, double *const *source);
 /* the same pass with the face weights given (a multivariateSelection scheme's common weights: ffm_fv_multivariate_weights) instead of
- * one limiter per field -- what mvConvection->fvmDiv(phi, Yi) of solver/YEEqn.H:44 assembles */
+ * one limiter per field -- what mvConvection->fvmDiv(phi, Yi) of solver/YEEqn.H:44 assembles.  With common weights and one gamma every
+ * field has the SAME off-diagonal coefficients: upper[i] = lower[i] = NULL for the fields i >= n0 (n0 = 0 .. nf) leaves them unwritten,
+ * the caller solves those systems with the arrays of an earlier field (ffm_ldu_bind_coeffs_native_d with offDiagUnchanged). */
 int ffm_fvm_scalar_transport_multi_w(ffm_mesh *m, int nf, const double *w_f, double rDeltaT, const double *rho, const double *rho0,
                                      const double *phi_f, const double *phi_b, const double *gamma_f, const double *gamma_b,
                                      const double *const *vf0, const double *const *f, const double *const *ref,
@@ -460,6 +469,7 @@ int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);
 int ffm_plume_nsolves(const ffm_plume *p);
 int ffm_plume_get_solve(const ffm_plume *p, int i, char *name16, ffm_perf *perf);
 ffm_ldu *ffm_plume_ldu(ffm_plume *p);
+ffm_mesh *ffm_plume_mesh(ffm_plume *p);          /* the case's device mesh (tests: operators on the tile-numbered mesh) */
 
 /* ------------------------------------------------------- pyrolysis region (N3) */
 /* reactingOneDim::evolveRegion (packages/regionModels/pyrolysisModels/reactingOneDim/reactingOneDim.C:686-721) for a panel of

@@ -3,6 +3,7 @@ give, bit for bit, what the chain of per-operator entry points gives (each of wh
 tests/test_fv_operators_gpu.py): same expressions, same order, FMA contraction off.  And the compiled time step built on them
 must equal the one built on the per-operator kernels (FFM_PLUME_UNFUSED) in every field, bitwise."""
 import os
+from ctypes import c_int as C_int
 
 import numpy as np
 import pytest
@@ -232,3 +233,32 @@ def test_time_step_fused_equals_per_operator(ffm, ctx, n):
         for name in FIELDS:
             assert np.array_equal(fused.field(name), plain.field(name)), (step, name)
     fused.close(); plain.close()
+
+
+@pytest.mark.parametrize("n,nf", [((40, 36, 33), 6), ((24, 40, 20), 3), ((50, 34, 34), 6)])
+def test_tiled_multivariate_weights_equal_the_two_pass_form(O, ffm, ctx, n, nf):
+    """ffm_fv_multivariate_weights_tiled (k_mv_tile: gradients + common limiter in one pass, cell values staged through LDS on the tile
+    numbering) == ffm_fvc_grad_multi + ffm_fv_multivariate_weights, bit for bit, on the tile-numbered mesh of the plume case with hashed
+    fields (values outside [0, 1], a field that is constant over most of the mesh, fluxes of both signs and exact zeros)."""
+    case = ffm.Plume(ctx, n)
+    mesh = case.mesh()
+    N, B, nNat = case.nCells, mesh.nBoundary, mesh.nNative
+    dev = ctx.to_device
+    vf = [dev(1.1 * (0.2 + O.hash_u(31 + 7 * i, np.arange(N))) - 0.2) for i in range(nf)]
+    a = 0.2 + O.hash_u(31, np.arange(N)); vf[0] = dev(np.where(a > 0.9, a, 0.25))
+    vb = [dev(0.1 + O.hash_u(133 + i, np.arange(B))) for i in range(nf)]
+    ph = 0.3 * (O.hash_u(32, np.arange(nNat)) - 0.5); ph[::7] = 0.0
+    phi = dev(ph)
+    sch = (C_int * nf)(*([2] + [3] * (nf - 1)))
+    g = [[ctx.zeros(N) for _ in range(3)] for _ in range(nf)]
+    mesh.call("fvc_grad_multi", nf if nf <= 4 else 4, vf[:4], vb[:4], [x[0] for x in g[:4]], [x[1] for x in g[:4]], [x[2] for x in g[:4]])
+    if nf > 4:
+        mesh.call("fvc_grad_multi", nf - 4, vf[4:], vb[4:], [x[0] for x in g[4:]], [x[1] for x in g[4:]], [x[2] for x in g[4:]])
+    two = ctx.zeros(nNat) + 7.0
+    mesh.call("fv_multivariate_weights", nf, sch, 1.0, 0.0, 1.0, phi, vf, [x[0] for x in g], [x[1] for x in g], [x[2] for x in g], two)
+    one = ctx.zeros(nNat) + 7.0
+    mesh.call("fv_multivariate_weights_tiled", nf, sch, 1.0, 0.0, 1.0, phi, vf, vb, one)
+    a, b = one.cpu().numpy(), two.cpu().numpy()
+    assert np.array_equal(a, b), (np.abs(a - b).max(), int((a != b).sum()))
+    assert ((b > 1e-6) & (b < 1 - 1e-6) & (np.abs(b - 0.5) > 1e-6)).mean() > 0.05            # limited faces exist
+    case.close()
