@@ -270,12 +270,15 @@ __global__ __launch_bounds__(256) void k_mv_weights(MeshView q, MvWeights a)
 
 // ---- the same weights with the cell fields staged through LDS on the tile numbering -------------------------------
 // k_grad_multi (the Gauss gradients of the nf fields) + k_mv_weights in ONE pass, bit for bit: a workgroup walks a run of consecutive
-// entries (dependency levels of at most 256 cells) of one tile; the nf cell values and the cell centre of the entries e-1, e, e+1 sit
-// in an LDS window (three buffers, entry e+1 loaded while entry e is computed), so the six neighbours of a cell -- which on the tile
-// numbering lie in the entries next to its own -- are served from LDS: every cell value is read from memory once per run instead
-// of once by the cell and once by each neighbour.  A cell forms its own gradients in registers (the limiter of a face needs the
+// entries (dependency levels of at most 256 cells) of one tile; the nf cell values of the entries e-1, e, e+1 sit in an LDS window
+// (three buffers, entry e+1 loaded while entry e is computed), so the six neighbours of a cell -- which on the tile numbering lie in
+// the entries next to its own -- are served from LDS: every cell value is read from memory once per run instead of once by the
+// cell and once by each neighbour.  A cell forms its own gradients in registers (the limiter of a face needs the
 // UPWIND cell's gradient, and every face is written by its upwind cell), so the eighteen gradient arrays are neither written nor read.
 // Neighbours outside the window (other tiles: ~12 % of the faces) are read from memory.  Single block only (no ghost cells).
+// Measured at 400^3 (profiles/r03*): 11.8-12.7 ms against 17.3 ms for the three passes it replaces (k_grad_multi<3,2> + <3,4> + k_mv_weights);
+// the pass is then bound by its ~5 000 instructions per cell (54 fp64 divisions of the gradients and of NVDTVD::r), not by traffic: holding the
+// centres in LDS as well (217 VGPRs, 2 waves / SIMD) or forcing 3 waves / SIMD (168 VGPRs, 140 B of scratch) changes it by < 4 %.
 constexpr int MVT_ENT = 256, MVT_FLD = 6, MVT_RUN = 32;
 struct MvTile {
     const double *vf[MVT_FLD], *vb[MVT_FLD];
@@ -288,7 +291,7 @@ struct MvTile {
 template <int W>
 __global__ __launch_bounds__(256) void k_mv_tile(MeshView q, MvTile a)
 {
-    __shared__ double ring[MVT_FLD + 3][3 * MVT_ENT];
+    __shared__ double ring[MVT_FLD][3 * MVT_ENT];
     __shared__ int4 shRec[3];
     const int4 sg = a.seg[blockIdx.x];
     const int gBeg = sg.x, ea = sg.y, eb = sg.z, gEnd = sg.w;
@@ -302,7 +305,6 @@ __global__ __launch_bounds__(256) void k_mv_tile(MeshView q, MvTile a)
         if (t < cnt) {
             const int c = c0 + t, o = (ee % 3) * MVT_ENT + t;
             for (int i = 0; i < nf; i++) ring[i][o] = a.vf[i][c];
-            ring[MVT_FLD][o] = a.Cx[c]; ring[MVT_FLD + 1][o] = a.Cy[c]; ring[MVT_FLD + 2][o] = a.Cz[c];
         }
     };
     stage(ea - 1); stage(ea);
@@ -319,38 +321,52 @@ __global__ __launch_bounds__(256) void k_mv_tile(MeshView q, MvTile a)
                 if (nb >= Rp.x && nb < Rp.x + Rp.y) return ((ee + 1) % 3) * MVT_ENT + (nb - Rp.x);
                 return -1;
             };
-            const double cx = ring[MVT_FLD][own], cy = ring[MVT_FLD + 1][own], cz = ring[MVT_FLD + 2][own];
+            const double cx = a.Cx[c], cy = a.Cy[c], cz = a.Cz[c];
             double fl[2 * W], lim[2 * W], dx[2 * W], dy[2 * W], dz[2 * W], wl[W], wu[W], sx[2 * W], sy[2 * W], sz[2 * W];
-            int sl[2 * W];
+            int sl[2 * W], gn[2 * W];       // LDS slot of the neighbour (-1: outside the window) and the cell to load from memory in that case
             bool mine[2 * W];
+            // Neighbours outside the window (other tiles) come from memory.  Their loads are issued for EVERY lane -- the lanes whose
+            // neighbour is in LDS load their own cell, a cache hit -- so that no load sits in a divergent branch: six independent loads
+            // per field, the next field's issued before this field's arithmetic (a dependent chain of 36 exposed latencies otherwise).
 #pragma unroll
             for (int s = 0; s < W; s++) {
                 sl[s] = L.on[s] ? slotOf(L.nb[s]) : own; sl[W + s] = U.on[s] ? slotOf(U.nb[s]) : own;
+                gn[s] = sl[s] >= 0 ? c : L.nb[s]; gn[W + s] = sl[W + s] >= 0 ? c : U.nb[s];
+            }
+            double gcur[2 * W];
+#pragma unroll
+            for (int s = 0; s < 2 * W; s++) gcur[s] = a.vf[0][gn[s]];
+#pragma unroll
+            for (int s = 0; s < W; s++) {
                 // lower face: owner = L.nb[s], neighbour = c; upwind is c when the flux is not positive.  d = C[neighbour] - C[owner]
                 fl[s] = L.on[s] ? a.phi[L.f[s]] : 0.0; mine[s] = L.on[s] && !(fl[s] > 0);
-                const double lx = sl[s] >= 0 ? ring[MVT_FLD][sl[s]] : a.Cx[L.nb[s]], ly = sl[s] >= 0 ? ring[MVT_FLD + 1][sl[s]] : a.Cy[L.nb[s]],
-                             lz = sl[s] >= 0 ? ring[MVT_FLD + 2][sl[s]] : a.Cz[L.nb[s]];
-                dx[s] = cx - lx; dy[s] = cy - ly; dz[s] = cz - lz;
-                // upper face: owner = c, neighbour = U.nb[s]; upwind is c when the flux is positive
                 fl[W + s] = U.on[s] ? a.phi[U.f[s]] : 0.0; mine[W + s] = U.on[s] && fl[W + s] > 0;
-                const double ux = sl[W + s] >= 0 ? ring[MVT_FLD][sl[W + s]] : a.Cx[U.nb[s]], uy = sl[W + s] >= 0 ? ring[MVT_FLD + 1][sl[W + s]] : a.Cy[U.nb[s]],
-                             uz = sl[W + s] >= 0 ? ring[MVT_FLD + 2][sl[W + s]] : a.Cz[U.nb[s]];
-                dx[W + s] = ux - cx; dy[W + s] = uy - cy; dz[W + s] = uz - cz;
                 lim[s] = lim[W + s] = 1.0;
                 // face geometry of the gradient (k_grad_multi)
                 wl[s] = q.w[L.f[s]]; wu[s] = q.w[U.f[s]];
                 sx[s] = q.Sfx[L.f[s]]; sy[s] = q.Sfy[L.f[s]]; sz[s] = q.Sfz[L.f[s]];
                 sx[W + s] = q.Sfx[U.f[s]]; sy[W + s] = q.Sfy[U.f[s]]; sz[W + s] = q.Sfz[U.f[s]];
             }
+#pragma unroll
+            for (int s = 0; s < W; s++) {       // d = C[neighbour] - C[owner]; the cell centres of the neighbours are gathered (cache hits inside a tile)
+                dx[s] = cx - a.Cx[L.nb[s]]; dy[s] = cy - a.Cy[L.nb[s]]; dz[s] = cz - a.Cz[L.nb[s]];
+                dx[W + s] = a.Cx[U.nb[s]] - cx; dy[W + s] = a.Cy[U.nb[s]] - cy; dz[W + s] = a.Cz[U.nb[s]] - cz;
+            }
             const double V = q.V[c];
             const int j = q.cellB[c];
 #pragma unroll 1
             for (int i = 0; i < nf; i++) {
-                const double *__restrict__ vf = a.vf[i];
                 const double P = ring[i][own];
-                double vl[W], vu[W];
+                double vl[W], vu[W], gnext[2 * W];
+                const double *__restrict__ vfn = a.vf[i + 1 < nf ? i + 1 : i];
 #pragma unroll
-                for (int s = 0; s < W; s++) { vl[s] = sl[s] >= 0 ? ring[i][sl[s]] : vf[L.nb[s]]; vu[s] = sl[W + s] >= 0 ? ring[i][sl[W + s]] : vf[U.nb[s]]; }
+                for (int s = 0; s < 2 * W; s++) gnext[s] = vfn[gn[s]];            // the next field's values from memory: in flight during this field's arithmetic
+#pragma unroll
+                for (int s = 0; s < W; s++) {
+                    const int k = sl[s] >= 0 ? sl[s] : own, ku = sl[W + s] >= 0 ? sl[W + s] : own;
+                    const double rl = ring[i][k], ru = ring[i][ku];
+                    vl[s] = sl[s] >= 0 ? rl : gcur[s]; vu[s] = sl[W + s] >= 0 ? ru : gcur[W + s];
+                }
                 // ---- fvc::grad of field i at c (k_grad_multi, same order: lower faces, upper faces, boundary faces)
                 double ax = 0, ay = 0, az = 0;
 #pragma unroll
@@ -381,6 +397,8 @@ __global__ __launch_bounds__(256) void k_mv_tile(MeshView q, MvTile a)
                         lim[W + s] = i == 0 ? l : fmin(lim[W + s], l);
                     }
                 }
+#pragma unroll
+                for (int s = 0; s < 2 * W; s++) gcur[s] = gnext[s];
             }
 #pragma unroll
             for (int s = 0; s < W; s++) {

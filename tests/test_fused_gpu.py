@@ -260,5 +260,6 @@ def test_tiled_multivariate_weights_equal_the_two_pass_form(O, ffm, ctx, n, nf):
     mesh.call("fv_multivariate_weights_tiled", nf, sch, 1.0, 0.0, 1.0, phi, vf, vb, one)
     a, b = one.cpu().numpy(), two.cpu().numpy()
     assert np.array_equal(a, b), (np.abs(a - b).max(), int((a != b).sum()))
-    assert ((b > 1e-6) & (b < 1 - 1e-6) & (np.abs(b - 0.5) > 1e-6)).mean() > 0.05            # limited faces exist
+    real = b[b != 7.0]                                                                  # (padding entries of the native layout keep the fill value)
+    assert ((real > 1e-6) & (real < 1 - 1e-6) & (np.abs(real - 0.5) > 1e-6)).any() and (real == 1.0).any() and (real == 0.0).any()
     case.close()
