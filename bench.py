@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--radiation-freq", type=int, default=100,
                     help="fvDOM stand-in (32 upwind ray solves) every N steps, counted from step 0; 100 = the reference case "
                          "(cases/steckler/constant/radiationProperties:38); 0 = off")
+    ap.add_argument("--no-class-layer", action="store_true", help="skip the extra measurement of the same case through the reference's unchanged equation files")
     ap.add_argument("--transport", choices=["rccl", "host"], default="rccl",
                     help="rccl: one rank per GPU over xGMI (production); host: ranks share GPUs, halo through gloo (rehearsal)")
     args = ap.parse_args()
@@ -102,6 +103,14 @@ def main():
     if args.radiation_freq > 0:
         case.set_radiation(solverFreq=args.radiation_freq)
     setup_s = time.time() - t0
+    # the start state of the case, kept on the host for the class-layer measurement at the end (the SAME case through the reference's
+    # unchanged solver/*.H over include/ffmFoam.H); nothing of it is touched inside the timed region
+    snap = None
+    if rank == 0 and world == 1 and not args.no_class_layer and ffm.snippets.load() is not None:
+        try:
+            snap = ffm.snippets.FromPlume(case)
+        except Exception as e:
+            sys.stderr.write("bench.py: class-layer snapshot failed (%r)\n" % (e,))
     # machine-readable: what carried the halo exchange and the reductions of this run ("none": one rank), and whether that is
     # what was asked for -- an RCCL -> host degradation must not pass for a scaling number
     used_transport = "none" if world == 1 else transport
@@ -181,6 +190,32 @@ def main():
                      "timed_steps_containing_a_sweep": len([k for k in range(args.warmup, args.warmup + args.steps) if k % args.radiation_freq == 0]),
                      "sweep_ms": round(sweep_ms, 1), "amortised_ms_per_step": round(sweep_ms / args.radiation_freq, 2),
                      "ray_iterations_mean": round(sum(rays) / max(len(rays), 1), 1)}
+
+    # ---- the drop-in path: the same case advanced by the reference's own equation files (solver/rhoEqn.H, UEqn.H, YEEqn.H, pEqn.H,
+    # unchanged) over the Foam layer -- one kernel and one temporary per operator -- on the same matrix and mesh, from the same start
+    # state; an extra key, never `value`
+    class_layer = None
+    if snap is not None:
+        try:
+            slib = ffm.snippets.load()
+            os.environ["FFM_FOAM_QUIET"] = "1"
+            solver = slib.firefoam_snippets_create(ctx.h, case.ldu_handle(), case.mesh().h, C.byref(snap.cs))
+            slib.firefoam_snippets_advance(solver, C.byref(snap.cs), 0)          # warm-up (first use of every temporary size)
+            barrier()
+            t1 = time.perf_counter()
+            ncl = 2
+            for _ in range(ncl):
+                nsol = slib.firefoam_snippets_advance(solver, C.byref(snap.cs), 0)
+            barrier()
+            cl_ms = (time.perf_counter() - t1) / ncl * 1e3
+            its = list(snap.nit[:nsol])
+            slib.firefoam_snippets_destroy(solver)
+            class_layer = {"path": "reference solver/{rhoEqn,UEqn,YEEqn,pEqn}.H unchanged over include/ffmFoam.H (libffm_refsnippets.so), same case, same mesh and matrix, start state of the compiled run",
+                           "ms_per_step": round(cl_ms, 2), "steps": ncl, "warmup": 1, "ratio_to_compiled": round(cl_ms / (dt / args.steps * 1e3), 3),
+                           "p_rgh_iterations_last_step": its[-2:]}
+        except Exception as e:
+            class_layer = {"error": repr(e)}
+        snap = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -262,7 +297,7 @@ def main():
                        "transport_solvers": "PBiCGStab+DILU" if args.solvers == "krylov" else "smoothSolver+symGaussSeidel maxIter 10"},
             "transport": used_transport, "transport_requested": "none" if world == 1 else requested_transport,
             "transport_degraded": bool(world > 1 and used_transport != requested_transport),
-            "roofline": roofline, "roofline_dic_sweeps": sweeps, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_dic_sweeps": sweeps, "class_layer": class_layer, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     case.close()

@@ -13,4 +13,5 @@ from .binding import (  # noqa: F401
 )
 from . import hexmesh  # noqa: F401
 from . import decompose  # noqa: F401
+from . import snippets  # noqa: F401  (host binding of the reference's equation files compiled over the Foam layer, where built)
 from . import gloo_comm  # noqa: F401  (host transport over torch.distributed/gloo: several ranks on one GPU, CPU rehearsals)

@@ -241,6 +241,7 @@ def lib():
         "ffm_plume_get_field": ([vp, C.c_char_p, hp], C.c_int),
         "ffm_plume_nsolves": ([vp], C.c_int),
         "ffm_plume_get_solve": ([vp, C.c_int, C.c_char_p, C.POINTER(Perf)], C.c_int),
+        "ffm_plume_get_raw": ([vp, C.c_char_p, hp, C.c_long], C.c_long),
         "ffm_plume_ldu": ([vp], vp),
         "ffm_plume_mesh": ([vp], vp),
         "ffm_fv_multivariate_weights_tiled": ([vp, C.c_int, C.POINTER(C.c_int), C.c_double, C.c_double, C.c_double, dp] + [C.POINTER(C.c_void_p)] * 2 + [dp], C.c_int),
@@ -674,6 +675,15 @@ class Plume:
 
     def ldu_handle(self):
         return lib().ffm_plume_ldu(self.h)
+
+    def raw(self, name):
+        """an array of the case in the library's own orders (ffm_plume_get_raw): cells [N], faces [F] or boundary faces [B]"""
+        cap = max(self.nCells, self.nFaces)
+        out = np.empty(cap)
+        n = lib().ffm_plume_get_raw(self.h, name.encode(), _hp(out), cap)
+        if n < 0:
+            raise FfmError("ffm_plume_get_raw(%s) failed (%d): %s" % (name, n, lib().ffm_last_error().decode()))
+        return out[:n].copy()
 
     def mesh(self):
         """the case's device mesh as an fvMesh wrapper (not owned: do not close it); tests call operators on it"""

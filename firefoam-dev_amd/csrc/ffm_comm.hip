@@ -90,6 +90,12 @@ extern "C" int ffm_comm_init(ffm_ctx *c, int rank, int nRanks, const void *uniqu
     ncclComm_t comm;
     FFM_NCCL(ncclCommInitRank(&comm, nRanks, id, rank));
     c->comm = (ncclComm *)comm;
+    // second communicator (same ranks, same order) for the overlapped ghost exchange on commStream: see ffm_ctx::haloComm
+    if (!getenv("FFM_NO_OVERLAP")) {
+        ncclComm_t halo;
+        FFM_NCCL(ncclCommSplit(comm, 0, rank, &halo, nullptr));
+        c->haloComm = (ncclComm *)halo;
+    }
     return FFM_OK;
 }
 
@@ -106,6 +112,7 @@ void ffm_comm_finalize_i(ffm_ctx *c)
     if (c->commStream) { hipStreamSynchronize(c->commStream); hipStreamDestroy(c->commStream); c->commStream = nullptr; }
     if (c->evPack) { hipEventDestroy(c->evPack); c->evPack = nullptr; }
     if (c->evRecv) { hipEventDestroy(c->evRecv); c->evRecv = nullptr; }
+    if (c->haloComm) { ncclCommDestroy((ncclComm_t)c->haloComm); c->haloComm = nullptr; }
     if (c->comm) { ncclCommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
 }
 
@@ -309,16 +316,17 @@ extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRa
 }
 
 // the send / receive group of one ghost refresh on stream s
-static int ghost_group(ffm_ldu *A, double *ghost, hipStream_t s)
+static int ghost_group(ffm_ldu *A, double *ghost, hipStream_t s, ncclComm *useComm = nullptr)
 {
     ffm_ctx *c = A->ctx;
+    ncclComm_t comm = (ncclComm_t)(useComm ? useComm : c->comm);
     const int nNbr = (int)A->ghNbrRank.size();
     const std::vector<int> order = posting_order(nNbr, A->ghTags);
     FFM_NCCL(ncclGroupStart());
     for (int q : order) {
         const int ns = A->ghSendOff[q + 1] - A->ghSendOff[q], nr = A->ghRecvOff[q + 1] - A->ghRecvOff[q];
-        if (ns) FFM_NCCL_IN_GROUP(ncclSend(A->ghSendBuf + A->ghSendOff[q], ns, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, s));
-        if (nr) FFM_NCCL_IN_GROUP(ncclRecv(ghost + A->ghRecvOff[q], nr, ncclDouble, A->ghNbrRank[q], (ncclComm_t)c->comm, s));
+        if (ns) FFM_NCCL_IN_GROUP(ncclSend(A->ghSendBuf + A->ghSendOff[q], ns, ncclDouble, A->ghNbrRank[q], comm, s));
+        if (nr) FFM_NCCL_IN_GROUP(ncclRecv(ghost + A->ghRecvOff[q], nr, ncclDouble, A->ghNbrRank[q], comm, s));
     }
     FFM_NCCL(ncclGroupEnd());
     return FFM_OK;
@@ -334,7 +342,7 @@ int ffm_ghost_exchange_begin(ffm_ldu *A, double *x)
     static const bool noOverlap = getenv("FFM_NO_OVERLAP") != nullptr;
     const int nNbr = (int)A->ghNbrRank.size();
     if (!nNbr) return FFM_OK;
-    if (!c->comm || noOverlap) return ffm_ghost_exchange(A, x);
+    if (!c->comm || !c->haloComm || noOverlap) return ffm_ghost_exchange(A, x);
     if (!c->commStream) {
         FFM_HIP(hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
         FFM_HIP(hipEventCreateWithFlags(&c->evPack, hipEventDisableTiming));
@@ -346,7 +354,7 @@ int ffm_ghost_exchange_begin(ffm_ldu *A, double *x)
     FFM_HIP(hipGetLastError());
     FFM_HIP(hipEventRecord(c->evPack, c->stream));
     FFM_HIP(hipStreamWaitEvent(c->commStream, c->evPack, 0));
-    FFM_TRY(ghost_group(A, x + A->nOwned, c->commStream));
+    FFM_TRY(ghost_group(A, x + A->nOwned, c->commStream, c->haloComm));          // its own communicator: never queued behind / ahead of the main stream's all-reduces
     FFM_HIP(hipEventRecord(c->evRecv, c->commStream));
     A->ghPending = true;
     return FFM_OK;

@@ -64,6 +64,10 @@ struct ffm_ctx {
     // communicator (RCCL); nRanks == 1 => serial
     int rank = 0, nRanks = 1;
     ncclComm *comm = nullptr;
+    // a communicator of its own for the ghost exchange that overlaps the interior rows on commStream: RCCL serialises the operations of
+    // ONE communicator, so collectives of one communicator issued from two streams (halo group on commStream, dot-product all-reduces on
+    // stream) may be launched in different orders on different ranks and deadlock; two communicators have independent queues
+    ncclComm *haloComm = nullptr;
     void *hostUser = nullptr;
     ffm_host_allreduce_fn hostAllreduce = nullptr;
     ffm_host_exchange_fn hostExchange = nullptr;

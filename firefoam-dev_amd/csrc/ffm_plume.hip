@@ -848,6 +848,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
         default: return (int)nOwn + gOff[side] + i + nx * j;
         }
     };
+    FfmStageTimer *tmS_ = new FfmStageTimer("plume_create: natural LDU");
     // ---- LDU in local natural order + cut faces owned by the owned cell (ghost index > every owned index)
     std::vector<int> l, u; std::vector<signed char> fd, fsgn;
     l.reserve(3 * nOwn + nGhost); u.reserve(3 * nOwn + nGhost); fd.reserve(3 * nOwn + nGhost); fsgn.reserve(3 * nOwn + nGhost);
@@ -862,6 +863,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
         }
     }
     const int F = (int)l.size(); P->F = F;
+    delete tmS_; tmS_ = nullptr;
     // ---- renumber once to the library's cell order (no permutation pass ever after)
     // group hint for the tiled sweeps: 2-D tiles of x-columns, FFM_TILE x FFM_TILE cells in (y,z) (ignored by the level mode)
     int tileEdge = 16;
@@ -871,10 +873,12 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     std::vector<int> c2(N), f2(F);
     { FfmStageTimer tm_("plume_create: renumber_hint"); FFM_TRY(ffm_renumber_hint((int)nOwn, (int)nGhost, F, l.data(), u.data(), hint.data(), c2.data(), f2.data())); }
     P->newToOld = c2; P->faceNewToOld = f2;
+    tmS_ = new FfmStageTimer("plume_create: renumbered addressing");
     std::vector<int> oldToNew(N);
     for (long c = 0; c < N; c++) oldToNew[c2[c]] = (int)c;
     std::vector<int> l2(F), u2(F); std::vector<signed char> fd2(F), sg2(F);
     for (int f = 0; f < F; f++) { l2[f] = oldToNew[l[f2[f]]]; u2[f] = oldToNew[u[f2[f]]]; fd2[f] = fd[f2[f]]; sg2[f] = fsgn[f2[f]]; }
+    delete tmS_; tmS_ = nullptr;
     {
         std::vector<int> hintNew(nOwn);
         for (long c = 0; c < nOwn; c++) hintNew[c] = hint[c2[c]];
@@ -885,6 +889,7 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     if (nGhost == 0) { P->hL2 = l2; P->hU2 = u2; P->hOldToNew = oldToNew; P->hFd2 = fd2; }      // for the direction-ordered ray solves
     FFM_TRY(ffm_ldu_set_global_cells(P->A, (long)gx * gy * gz));
     P->nNat = P->A->upTotal;
+    tmS_ = new FfmStageTimer("plume_create: geometry + patches");
     // ---- geometry (global coordinates)
     std::vector<double> V(N, h * h * h), C(3 * N), Sf(3 * (size_t)F, 0.0), magSf(F, h * h), wgt(F, 0.5), del(F, 1.0 / h), Cfy(F);
     for (long cn = 0; cn < N; cn++) {
@@ -939,13 +944,16 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
         pD[p].assign(sizes[p], 2.0 / h); pSf[p] = pSflat[p].data(); pDel[p] = pD[p].data();
     }
     P->B = Btot;
+    delete tmS_; tmS_ = nullptr;
     { FfmStageTimer tm_("plume_create: mesh_create"); FFM_TRY(ffm_mesh_create(P->A, V.data(), C.data(), Sf.data(), magSf.data(), wgt.data(), del.data(), 4, sizes, fcs, pSf, pDel, &P->mesh)); }
+    tmS_ = new FfmStageTimer("plume_create: face centres");
     {
         // face centres (LUST correction): owner's centre + half a cell towards the neighbour
         std::vector<double> Cf(3 * (size_t)F);
         for (int f = 0; f < F; f++) for (int d = 0; d < 3; d++) Cf[(size_t)d * F + f] = C[(size_t)d * N + l2[f]] + (fd2[f] == d ? sg2[f] * 0.5 * h : 0.0);
         FFM_TRY(ffm_mesh_set_face_centres(P->mesh, Cf.data()));
     }
+    delete tmS_; tmS_ = new FfmStageTimer("plume_create: fields + tables");
     const int ny_glob = gy;
     const int B = Btot; const long nNat = P->nNat;
     // ---- fields
@@ -1006,11 +1014,13 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     }
     for (double *p : P->pool) if (!p) { ffm_set_error("plume: out of device memory"); return FFM_ERR_HIP; }
     PL_HIP(hipDeviceSynchronize());
+    delete tmS_; tmS_ = new FfmStageTimer("plume_create: hydrostatic init");
     // ---- initial state: quiescent ambient, then hydrostatic initialisation
     standin_thermo(P);
     mul(P, P->rho, P->psi, P->p, N);
     FFM_TRY(hydrostatic_init(P));
     PL_HIP(hipStreamSynchronize(ctx->stream));
+    delete tmS_; tmS_ = nullptr;
     if (const char *e = getenv("FFM_PLUME_RADIATION")) { if (atoi(e) > 0) FFM_TRY(ffm_plume_set_radiation(P, atoi(e), 2, 4, nullptr, nullptr)); }   // solverFreq
     *out = P;
     return FFM_OK;
@@ -1171,6 +1181,46 @@ extern "C" int ffm_plume_get_field(ffm_plume *P, const char *name, double *out)
     FFM_TRY(ffm_d2h(P->ctx, v.data(), src, sizeof(double) * P->N));
     for (int c = 0; c < P->nOwn; c++) out[P->newToOld[c]] = v[c];      // owned cells, local natural (blockMesh) order
     return FFM_OK;
+}
+
+// Raw state of the case for a driver that runs the SAME case through another path (bench.py: the reference's equation files over the
+// Foam layer, libffm_refsnippets.so): cell fields [N] in the library's cell order, face fields [F] in the renumbered LDU face order
+// (what ffm_faces_to_native takes), boundary arrays [B] in (patch, face) order -- inlet, floor, top, sides.  Returns the count.
+extern "C" long ffm_plume_get_raw(ffm_plume *P, const char *name, double *out, long cap)
+{
+    if (!P || !name || !out) return FFM_ERR_ARG;
+    if (P->N != P->nOwn) { ffm_set_error("ffm_plume_get_raw: single block only"); return FFM_ERR_ARG; }
+    const std::string n(name);
+    const long N = P->N, F = P->F, B = P->B;
+    auto cellF = [&](const double *src) -> long { if (cap < N) return FFM_ERR_ARG; return ffm_d2h(P->ctx, out, src, sizeof(double) * N) == FFM_OK ? N : FFM_ERR_HIP; };
+    auto bndF = [&](const double *src) -> long { if (cap < B) return FFM_ERR_ARG; return ffm_d2h(P->ctx, out, src, sizeof(double) * B) == FFM_OK ? B : FFM_ERR_HIP; };
+    auto faceF = [&](const double *src) -> long {
+        if (cap < F) return FFM_ERR_ARG;
+        std::vector<double> v(std::max<long>(P->nNat, 1));
+        if (ffm_d2h(P->ctx, v.data(), src, sizeof(double) * P->nNat) != FFM_OK) return FFM_ERR_HIP;
+        const std::vector<int> &c2n = P->A->h_callerToNative;
+        for (long f = 0; f < F; f++) out[f] = v[c2n[f]];
+        return F;
+    };
+    if (n == "rho") return cellF(P->rho); if (n == "p") return cellF(P->p); if (n == "p_rgh") return cellF(P->p_rgh); if (n == "h") return cellF(P->hs);
+    if (n == "K") return cellF(P->K); if (n == "dpdt") return cellF(P->dpdt); if (n == "gh") return cellF(P->gh); if (n == "T") return cellF(P->T);
+    if (n == "Ux") return cellF(P->U[0]); if (n == "Uy") return cellF(P->U[1]); if (n == "Uz") return cellF(P->U[2]);
+    for (int i = 0; i < NSP; i++) if (n == SPN[i]) return cellF(P->Y[i]);
+    if (n == "phi") return faceF(P->phi); if (n == "ghf") return faceF(P->ghf);
+    if (n == "phib") return bndF(P->phib); if (n == "ph_rgh_b") return bndF(P->ph_rgh_b); if (n == "kind") return bndF(P->kind_d);
+    if (n == "fStaticS") return bndF(P->fStaticS); if (n == "fStaticH") return bndF(P->fStaticH); if (n == "refH") return bndF(P->refH);
+    for (int c = 0; c < 3; c++) { if (n == std::string("fStaticU") + char('0' + c)) return bndF(P->fStaticU[c]); if (n == std::string("refU") + char('0' + c)) return bndF(P->refU[c]); }
+    for (int i = 0; i < NSP; i++) if (n == std::string("refY") + char('0' + i)) return bndF(P->refY[i]);
+    if (n == "ghfB") {      // gh on the boundary faces: the owner cell's gh moved by half a cell along the face normal
+        if (cap < B) return FFM_ERR_ARG;
+        std::vector<double> gh(N), sy(B), mg(B); std::vector<int> bc(B);
+        if (ffm_d2h(P->ctx, gh.data(), P->gh, sizeof(double) * N) != FFM_OK || ffm_d2h(P->ctx, sy.data(), ffm_mesh_geom(P->mesh, 7), sizeof(double) * B) != FFM_OK ||
+            ffm_d2h(P->ctx, mg.data(), ffm_mesh_geom(P->mesh, 4), sizeof(double) * B) != FFM_OK || ffm_d2h(P->ctx, bc.data(), ffm_mesh_bcells(P->mesh), sizeof(int) * B) != FFM_OK) return FFM_ERR_HIP;
+        for (long k = 0; k < B; k++) out[k] = gh[bc[k]] + (-9.81) * (0.5 * P->h * (sy[k] / mg[k]));
+        return B;
+    }
+    ffm_set_error("ffm_plume_get_raw: unknown array %s", name);
+    return FFM_ERR_ARG;
 }
 
 extern "C" int ffm_plume_nsolves(const ffm_plume *P) { return P ? (int)P->log.size() : FFM_ERR_ARG; }

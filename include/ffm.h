@@ -468,6 +468,11 @@ int ffm_plume_nfaces(const ffm_plume *p);
 int ffm_plume_get_field(ffm_plume *p, const char *name, double *out);
 int ffm_plume_nsolves(const ffm_plume *p);
 int ffm_plume_get_solve(const ffm_plume *p, int i, char *name16, ffm_perf *perf);
+/* the case's raw state for a driver that runs the same case through another path (bench.py: the reference's equation files over the Foam
+ * layer): cell fields [N] in the library's cell order, face fields [F] in the renumbered LDU face order, boundary arrays [B] in (patch, face)
+ * order; returns the number of values or a negative FFM_ERR_*.  Names: rho p p_rgh h K dpdt gh Ux Uy Uz <specie> | phi ghf | phib ph_rgh_b kind
+ * fStaticU<c> refU<c> fStaticS fStaticH refH refY<i> ghfB */
+long ffm_plume_get_raw(ffm_plume *p, const char *name, double *out, long cap);
 ffm_ldu *ffm_plume_ldu(ffm_plume *p);
 ffm_mesh *ffm_plume_mesh(ffm_plume *p);          /* the case's device mesh (tests: operators on the tile-numbered mesh) */
 

@@ -471,3 +471,32 @@ def test_reference_equation_files_hold_1e8_over_six_steps_on_the_conditioned_cas
     lib.firefoam_snippets_destroy(solver)
     print("reference files, conditioned case, worst rel-L2 over six steps: %.2e" % worst)
     A.close()
+
+
+def test_the_compiled_case_advanced_by_the_reference_files(O, ffm, ctx):
+    """bench.py's class-layer measurement: the state of a compiled plume case (ffm.Plume) exported in the library's own orders
+    (ffm_plume_get_raw -> firefoam-dev_amd/snippets.py:FromPlume) and advanced by the reference's unchanged equation files on the plume's
+    own matrix and mesh, against the compiled driver advanced from the same state: identical iteration counts, fields to 1e-8 after the
+    first step (the later ones at the 1e-5 of the free-running common limiter, tests/test_plume_gpu.py)."""
+    S = ffm.snippets
+    lib = S.load()
+    if lib is None:
+        pytest.skip("libffm_refsnippets.so not built (needs /root/reference at build time)")
+    n = (24, 30, 20)
+    case = ffm.Plume(ctx, n)
+    snap = S.FromPlume(case)
+    out = snap.outputs()
+    os.environ["FFM_FOAM_QUIET"] = "1"
+    solver = lib.firefoam_snippets_create(ctx.h, case.ldu_handle(), case.mesh().h, C.byref(snap.cs))
+    other = ffm.Plume(ctx, n)                      # the compiled driver from the same start state (its own matrix)
+    for step in range(3):
+        nsol = lib.firefoam_snippets_advance(solver, C.byref(snap.cs), 1)
+        other.step()
+        its = [p["nIterations"] for _, p in other.solves()]
+        assert list(snap.nit[:nsol]) == its, (step, list(snap.nit[:nsol]), its)
+        tol = 1e-8 if step == 0 else 1e-5
+        for name, a in (("rho", out["rho"]), ("T", out["T"]), ("h", out["h"]), ("p", out["p"]), ("Uy", out["U"][1]), ("O2", out["Y"][0])):
+            b = other.raw(name)
+            assert rel_l2(a, b) < tol, (step, name, rel_l2(a, b))
+    lib.firefoam_snippets_destroy(solver)
+    case.close(); other.close()
