@@ -46,7 +46,8 @@ extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, con
     // face geometry: caller (LDU) face order -> native
     auto toNative = [&](const double *src, double fill) {
         std::vector<double> v(std::max(nNat, 1), fill);
-        for (int f = 0; f < F; f++) v[A->h_callerToNative[f]] = src[f];
+        const int *c2n = A->h_callerToNative.data(); double *vp = v.data();
+        ffm_parallel_for(F, [=](long lo, long hi) { for (long f = lo; f < hi; f++) vp[c2n[f]] = src[f]; });      // (distinct destinations)
         return v;
     };
     int rc = FFM_OK;
@@ -123,7 +124,10 @@ extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, con
             const double scale = t0[0] * t0[0] + 2 * t0[1] * t0[1] + 2 * t0[2] * t0[2] + t0[3] * t0[3] + 2 * t0[4] * t0[4] + t0[5] * t0[5];
             if (scale > 0) { rm[0] = t0[0] * t0[0] / scale < 1e-15; rm[1] = t0[3] * t0[3] / scale < 1e-15; rm[2] = t0[5] * t0[5] / scale < 1e-15; }
         }
-        for (int c = 0; c < N; c++) {
+        const double *Tp = T.data(); double *invp = inv.data();
+        const bool rm0 = rm[0], rm1 = rm[1], rm2 = rm[2];
+        ffm_parallel_for(N, [=](long c0_, long c1_) { const double *T = Tp; double *inv = invp; const bool rm[3] = {rm0, rm1, rm2};
+        for (long c = c0_; c < c1_; c++) {
             const double a = T[c] + (rm[0] ? 1.0 : 0.0), b = T[(size_t)N + c], cc = T[(size_t)2 * N + c], d = T[(size_t)3 * N + c] + (rm[1] ? 1.0 : 0.0),
                          e = T[(size_t)4 * N + c], f = T[(size_t)5 * N + c] + (rm[2] ? 1.0 : 0.0);
             const double det = a * (d * f - e * e) - b * (b * f - e * cc) + cc * (b * e - d * cc);
@@ -131,7 +135,7 @@ extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, con
             inv[c] = (d * f - e * e) / det - (rm[0] ? 1.0 : 0.0); inv[(size_t)N + c] = (cc * e - b * f) / det; inv[(size_t)2 * N + c] = (b * e - cc * d) / det;
             inv[(size_t)3 * N + c] = (a * f - cc * cc) / det - (rm[1] ? 1.0 : 0.0); inv[(size_t)4 * N + c] = (b * cc - a * e) / det;
             inv[(size_t)5 * N + c] = (a * d - b * b) / det - (rm[2] ? 1.0 : 0.0);
-        }
+        } });
         if ((rc = up(m->ctx, &m->invT, inv))) return rc;
     }
     *out = m;

@@ -11,6 +11,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <thread>
 #include <algorithm>
 #include <unordered_map>
 
@@ -114,6 +115,18 @@ template <class T> inline int ffm_upload_vec(ffm_ctx *c, T **d, const std::vecto
     return ffm_h2d(c, *d, v.data(), sizeof(T) * v.size());
 }
 #pragma GCC poison hipMemcpy hipMemset
+
+// Host set-up loops over cells / faces (renumbered addressing, geometry in the native layout, the reconstruction tensors): independent
+// iterations split over the host's cores (at most 16 threads; FFM_HOST_THREADS overrides; below 1M iterations: the caller's thread)
+template <class Fn> inline void ffm_parallel_for(long n, Fn fn)
+{
+    static const int nT = [] { const char *e = getenv("FFM_HOST_THREADS"); int t = e ? atoi(e) : (int)std::thread::hardware_concurrency(); return std::max(1, std::min(t, 16)); }();
+    if (n < (1L << 20) || nT == 1) { fn(0L, n); return; }
+    std::vector<std::thread> th;
+    const long chunk = (n + nT - 1) / nT;
+    for (int t = 0; t < nT; t++) { const long lo = t * chunk, hi = std::min(n, lo + chunk); if (lo < hi) th.emplace_back([=] { fn(lo, hi); }); }
+    for (auto &x : th) x.join();
+}
 
 // key of a cached hipGraph of level-scheduled sweeps: EVERY device pointer the captured kernels bake in
 struct SweepGraphKey {

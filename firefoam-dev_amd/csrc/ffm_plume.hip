@@ -159,6 +159,12 @@ template <class Fn> static void forN(ffm_plume *P, long n, Fn f)
 {
     if (n > 0) hipLaunchKernelGGL(k_for<Fn>, dim3(sgrid(n)), dim3(256), 0, P->ctx->stream, n, f);
 }
+static double *dfill(ffm_plume *P, size_t n, double value)          // a field with one value everywhere, filled on the device
+{
+    double *p = dalloc(P, n);
+    if (p && n) forN(P, (long)n, [=] __device__(long i) { p[i] = value; });
+    return p;
+}
 static void dcopy(ffm_plume *P, double *d, const double *s, long n)
 { hipMemcpyAsync(d, s, sizeof(double) * n, hipMemcpyDeviceToDevice, P->ctx->stream); }
 
@@ -877,7 +883,9 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     std::vector<int> oldToNew(N);
     for (long c = 0; c < N; c++) oldToNew[c2[c]] = (int)c;
     std::vector<int> l2(F), u2(F); std::vector<signed char> fd2(F), sg2(F);
-    for (int f = 0; f < F; f++) { l2[f] = oldToNew[l[f2[f]]]; u2[f] = oldToNew[u[f2[f]]]; fd2[f] = fd[f2[f]]; sg2[f] = fsgn[f2[f]]; }
+    { const int *o2n = oldToNew.data(), *lp = l.data(), *up_ = u.data(), *f2p = f2.data(); const signed char *fdp = fd.data(), *sgp = fsgn.data();
+      int *l2p = l2.data(), *u2p = u2.data(); signed char *fd2p = fd2.data(), *sg2p = sg2.data();
+      ffm_parallel_for(F, [=](long a, long b) { for (long f = a; f < b; f++) { l2p[f] = o2n[lp[f2p[f]]]; u2p[f] = o2n[up_[f2p[f]]]; fd2p[f] = fdp[f2p[f]]; sg2p[f] = sgp[f2p[f]]; } }); }
     delete tmS_; tmS_ = nullptr;
     {
         std::vector<int> hintNew(nOwn);
@@ -892,22 +900,26 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     tmS_ = new FfmStageTimer("plume_create: geometry + patches");
     // ---- geometry (global coordinates)
     std::vector<double> V(N, h * h * h), C(3 * N), Sf(3 * (size_t)F, 0.0), magSf(F, h * h), wgt(F, 0.5), del(F, 1.0 / h), Cfy(F);
-    for (long cn = 0; cn < N; cn++) {
-        const int co = c2[cn];
-        int i, j, k;
-        if (co < nOwn) { i = co % nx; j = (co / nx) % ny; k = co / (nx * ny); }
-        else {
-            int side = 0; while (co - nOwn >= gOff[side + 1]) side++;
-            const int r = co - (int)nOwn - gOff[side];
-            switch (side >> 1) {
-            case 0: j = r % ny; k = r / ny; i = (side & 1) ? nx : -1; break;
-            case 1: i = r % nx; k = r / nx; j = (side & 1) ? ny : -1; break;
-            default: i = r % nx; j = r / nx; k = (side & 1) ? nz : -1; break;
+    {
+        double *Cp = C.data(), *Sfp = Sf.data(), *Cfyp = Cfy.data(); const int *c2p = c2.data(), *l2p = l2.data(); const signed char *fd2p = fd2.data(), *sg2p = sg2.data();
+        const int lo0 = lo[0], lo1 = lo[1], lo2 = lo[2]; int gO[7]; for (int q = 0; q < 7; q++) gO[q] = gOff[q];
+        ffm_parallel_for(N, [=](long a, long b) { for (long cn = a; cn < b; cn++) {
+            const int co = c2p[cn];
+            int i, j, k;
+            if (co < nOwn) { i = co % nx; j = (co / nx) % ny; k = co / (nx * ny); }
+            else {
+                int side = 0; while (co - nOwn >= gO[side + 1]) side++;
+                const int r = co - (int)nOwn - gO[side];
+                switch (side >> 1) {
+                case 0: j = r % ny; k = r / ny; i = (side & 1) ? nx : -1; break;
+                case 1: i = r % nx; k = r / nx; j = (side & 1) ? ny : -1; break;
+                default: i = r % nx; j = r / nx; k = (side & 1) ? nz : -1; break;
+                }
             }
-        }
-        C[cn] = (lo[0] + i + 0.5) * h; C[N + cn] = (lo[1] + j + 0.5) * h; C[2 * N + cn] = (lo[2] + k + 0.5) * h;
+            Cp[cn] = (lo0 + i + 0.5) * h; Cp[N + cn] = (lo1 + j + 0.5) * h; Cp[2 * N + cn] = (lo2 + k + 0.5) * h;
+        } });
+        ffm_parallel_for(F, [=](long a, long b) { for (long f = a; f < b; f++) { Sfp[(size_t)fd2p[f] * F + f] = sg2p[f] * h * h; Cfyp[f] = Cp[N + l2p[f]] + (fd2p[f] == 1 ? sg2p[f] * 0.5 * h : 0.0); } });
     }
-    for (int f = 0; f < F; f++) { Sf[(size_t)fd2[f] * F + f] = sg2[f] * h * h; Cfy[f] = C[N + l2[f]] + (fd2[f] == 1 ? sg2[f] * 0.5 * h : 0.0); }
     // ---- ghost exchange plan: side s sends the owned layer adjacent to it, receives the ghost layer across it
     {
         std::vector<int> ranks, sc, rc, cells;
@@ -950,7 +962,8 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     {
         // face centres (LUST correction): owner's centre + half a cell towards the neighbour
         std::vector<double> Cf(3 * (size_t)F);
-        for (int f = 0; f < F; f++) for (int d = 0; d < 3; d++) Cf[(size_t)d * F + f] = C[(size_t)d * N + l2[f]] + (fd2[f] == d ? sg2[f] * 0.5 * h : 0.0);
+        { double *Cfp = Cf.data(); const double *Cp = C.data(); const int *l2p = l2.data(); const signed char *fd2p = fd2.data(), *sg2p = sg2.data();
+          ffm_parallel_for(F, [=](long a, long b) { for (long f = a; f < b; f++) for (int d = 0; d < 3; d++) Cfp[(size_t)d * F + f] = Cp[(size_t)d * N + l2p[f]] + (fd2p[f] == d ? sg2p[f] * 0.5 * h : 0.0); }); }
         FFM_TRY(ffm_mesh_set_face_centres(P->mesh, Cf.data()));
     }
     delete tmS_; tmS_ = new FfmStageTimer("plume_create: fields + tables");
@@ -958,10 +971,10 @@ extern "C" int ffm_plume_create_block(ffm_ctx *ctx, int gx, int gy, int gz, cons
     const int B = Btot; const long nNat = P->nNat;
     // ---- fields
     auto NN = [&]() { return dalloc(P, N); };
-    for (int i = 0; i < NSP; i++) { P->Y[i] = dupload(P, std::vector<double>(N, Y_AMB[i])); P->Y0[i] = NN(); }
-    P->T = dupload(P, std::vector<double>(N, TREF)); P->hs = NN(); P->hs0 = NN();
+    for (int i = 0; i < NSP; i++) { P->Y[i] = dfill(P, N, Y_AMB[i]); P->Y0[i] = NN(); }
+    P->T = dfill(P, N, TREF); P->hs = NN(); P->hs0 = NN();
     for (int c = 0; c < 3; c++) { P->U[c] = NN(); P->U0[c] = NN(); }
-    P->p = dupload(P, std::vector<double>(N, PREF)); P->p0 = NN(); P->p_rgh = NN(); P->p_rgh0 = NN(); P->psi = NN(); P->psi0 = NN();
+    P->p = dfill(P, N, PREF); P->p0 = NN(); P->p_rgh = NN(); P->p_rgh0 = NN(); P->psi = NN(); P->psi0 = NN();
     P->rho = NN(); P->rho0 = NN(); P->K = NN(); P->K0 = NN(); P->dpdt = NN(); P->ph_rgh = NN();
     P->phi = dalloc(P, nNat); P->phi0 = dalloc(P, nNat); P->phib = dalloc(P, B); P->phib0 = dalloc(P, B); P->ph_rgh_b = dalloc(P, B);
     {
