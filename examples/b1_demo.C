@@ -489,3 +489,17 @@ extern "C" int b1_fvdom(ffm_ctx* ctx, ffm_ldu* ldu, ffm_mesh* msh, int emptyDire
     FFM_FOAM_CHK(ffm_ctx_sync(ctx));
     return dom.nRay();
 }
+
+// ---- Time::setDeltaT / operator++ of include/ffmFoam.H (Time::adjustDeltaT with writeControl adjustableRunTime) stepped n times with the
+// wished deltaT of every step: the adjusted deltaT, the time and the write index after every step (tests/test_abi_cpu.py)
+extern "C" int b1_time_sequence(double deltaT0, double writeInterval, int n, const double* wish, double* dtOut, double* tOut, int* writeIndexOut)
+{
+    Time runTime(0, deltaT0);
+    runTime.setWriteInterval(writeInterval);
+    for (int i = 0; i < n; i++) {
+        runTime.setDeltaT(wish[i]);
+        runTime++;
+        dtOut[i] = runTime.deltaTValue(); tOut[i] = runTime.value(); writeIndexOut[i] = (int)runTime.writeTimeIndex();
+    }
+    return n;
+}

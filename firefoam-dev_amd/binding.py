@@ -157,6 +157,8 @@ def lib():
         "ffm_edc_correct_d": ([vp, C.c_long] + [dp] * 6 + [C.c_double] * 7 + [dp, dp], C.c_int),
         "ffm_les_keqn_nut_d": ([vp, C.c_long, C.c_double, C.c_double, dp, dp, dp, dp, dp], C.c_int),
         "ffm_gamg_face_area_pair_weights": ([C.c_int, hp, hp], C.c_int),
+        "ffm_ctx_set_gamg_forward": ([vp, C.c_int], C.c_int),
+        "ffm_ctx_gamg_forward": ([vp], C.c_int),
         "ffm_gamg_create": ([vp, vp, C.c_int, C.c_int, ip, ip, hp, C.c_int, C.c_int, C.POINTER(vp)], C.c_int),
         "ffm_gamg_set_sweeps": ([vp, C.c_int, C.c_int, C.c_int], C.c_int),
         "ffm_gamg_set_matrix_d": ([vp, dp, dp, dp], C.c_int),
@@ -737,8 +739,12 @@ class GAMG:
     """GAMGSolver for an lduMatrix (ffm_gamg_*): the agglomeration is built once from the addressing and the face weights
     (faceAreaPair: weights=None and Sf given), set_matrix() agglomerates the coefficients, solve() runs V-cycles."""
 
-    def __init__(self, ctx, A, l, u, Sf=None, weights=None, nCellsInCoarsestLevel=10, mergeLevels=1):
+    def __init__(self, ctx, A, l, u, Sf=None, weights=None, nCellsInCoarsestLevel=10, mergeLevels=1, forward=True):
+        """forward: pairGAMGAgglomeration::forward_ at the start of this agglomeration (True: the first of a run); None: continue with the
+        direction the context's previous agglomeration ended with, as a second mesh / region of one OpenFOAM run does"""
         self.ctx, self.A = ctx, A
+        if forward is not None:
+            _check(lib().ffm_ctx_set_gamg_forward(ctx.h, 1 if forward else 0), "ffm_ctx_set_gamg_forward")
         l = np.ascontiguousarray(l, np.int32); u = np.ascontiguousarray(u, np.int32)
         if weights is None:
             Sf = np.ascontiguousarray(Sf, np.float64).reshape(-1, 3)

@@ -293,7 +293,7 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
     }
     long tileMinCells = 2048;               // below this a level is a handful of tiles (measured: 2048 ... 8192 equal, 32768 slower)
     if (const char *e = getenv("FFM_GAMG_TILE_MIN_CELLS")) tileMinCells = atol(e);
-    bool forward = true;                    // pairGAMGAgglomeration::forward_ (static, true at the first agglomeration of a run)
+    bool forward = ctx->gamgForward;        // pairGAMGAgglomeration::forward_: static upstream, here kept per context (= per run)
     const int maxLevels = 50;
     while ((int)G->lev.size() - 1 < maxLevels - 1) {
         // NOTE: G->lev may reallocate below; take no references across emplace_back
@@ -356,7 +356,9 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
             (rc = dalloc(&Lc.src, nCoarse)) || (rc = dalloc(&Lc.corr, nCoarse)) || (rc = dalloc(&Lc.acf, nCoarse)) || (rc = dalloc(&Lc.pre, nCoarse)) ||
             (rc = dalloc(&Lc.tmp, nCoarse))) return fail(rc);
     }
-    if (G->lev.size() < 2) { ffm_gamg_destroy(G); ffm_set_error("GAMG: no coarse level (%d cells, nCellsInCoarsestLevel %d)", nCells, nCellsInCoarsestLevel); return FFM_ERR_ARG; }
+    ctx->gamgForward = forward;             // the next agglomeration of this run continues in the direction this one ended with
+    // no coarse level (the first agglomeration already falls below nCellsInCoarsestLevel: small meshes / regions): ffm_gamg_solve_d then
+    // runs the coarsest-level solver (PCG + DIC / PBiCGStab + DILU) on the fine matrix itself instead of failing the whole run
     int rc;
     if ((rc = dalloc(&G->lev[0].dInt, nCells)) || (rc = dalloc(&G->fRes, nCells)) || (rc = dalloc(&G->fCorr, nCells)) || (rc = dalloc(&G->fApsi, nCells)) ||
         (rc = dalloc(&G->fSumA, nCells))) return fail(rc);
@@ -364,6 +366,8 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
     return FFM_OK;
 }
 
+extern "C" int ffm_ctx_set_gamg_forward(ffm_ctx *c, int forward) { if (!c) return FFM_ERR_ARG; c->gamgForward = forward != 0; return FFM_OK; }
+extern "C" int ffm_ctx_gamg_forward(const ffm_ctx *c) { return c ? (c->gamgForward ? 1 : 0) : FFM_ERR_ARG; }
 extern "C" int ffm_gamg_nlevels(const ffm_gamg *G) { return G ? (int)G->lev.size() - 1 : FFM_ERR_ARG; }       // coarse levels
 extern "C" int ffm_gamg_level_size(const ffm_gamg *G, int level, int *nCells, int *nFaces)
 {
@@ -573,6 +577,12 @@ extern "C" int ffm_gamg_solve_d(ffm_gamg *G, int smoother, double tol, double re
     out->initialResidual = c->scal_h[S_TMP0] / normFactor;
     out->finalResidual = out->initialResidual;
     auto converged = [&]() { return out->finalResidual < tol || (relTol > 1e-20 && out->finalResidual < relTol * out->initialResidual); };
+    if (G->lev.size() < 2) {             // no coarse level: the coarsest-level solver on the fine matrix (see ffm_gamg_create)
+        ffm_perf pf;
+        FFM_TRY(ffm_solve_internal_i(A, G->symmetric ? FFM_PCG : FFM_PBICGSTAB, G->symmetric ? FFM_DIC : FFM_DILU, tol, relTol, minIter, maxIter, 1, psi, src, &pf));
+        G->coarsestLog.push_back(pf);
+        *out = pf;
+    } else
     if (minIter > 0 || !converged()) {
         do {
             FFM_TRY(vcycle(G, smoother, psi, src, tol, relTol));

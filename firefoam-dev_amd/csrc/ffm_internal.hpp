@@ -74,6 +74,9 @@ struct ffm_ctx {
     ffm_host_exchange_fn hostExchange = nullptr;
     ffm_host_exchange2_fn hostExchange2 = nullptr;
     int cuCount = 256;
+    // pairGAMGAgglomeration::forward_: a STATIC upstream -- the direction in which the next pair agglomeration visits the cells, toggled by
+    // every agglomeration of the run, so a second GAMG mesh / region starts in the direction the first one ended with (ffm_ctx_set_gamg_forward)
+    bool gamgForward = true;
     // second stream for the RCCL ghost exchange of an Amul whose interior rows do not need the ghost values (tiled Amul):
     // pack (main stream) -> evPack -> send / receive (commStream) -> evRecv -> ghost-face tail (main stream)
     hipStream_t commStream = nullptr;

@@ -578,6 +578,11 @@ int ffm_fvc_div_dev2T_gradU(ffm_mesh *m, const double *const *g, const double *g
 int ffm_les_keqn_G(ffm_mesh *m, const double *const *g, const double *nut, double *G);
 
 /* ------------------------------------------------------------------------ GAMG */
+/* pairGAMGAgglomeration::forward_ is a static upstream: the cell-visiting direction of the next pair agglomeration, toggled by every
+ * agglomeration of the run (a second GAMG mesh or region continues where the first ended).  Here it lives in the context (= the run):
+ * ffm_gamg_create reads and updates it; these two set / read it (a fresh context starts forward, as a fresh run does).               */
+int ffm_ctx_set_gamg_forward(ffm_ctx *ctx, int forward);
+int ffm_ctx_gamg_forward(const ffm_ctx *ctx);
 /* lduMatrix::solver::New(... solver GAMG ...) as the reference's dictionaries select it: agglomerator faceAreaPair,
  * mergeLevels 1, nCellsInCoarsestLevel 10, cacheAgglomeration true, smoother GaussSeidel for p_rgh / ph_rgh
  * (cases/wallFireSpread2D/system/fvSolution:36-60, cases/pyrolysis1D/system/fvSolution) and DILU for Ii

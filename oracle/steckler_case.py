@@ -264,11 +264,12 @@ class StecklerCase:
         1 + 0.1 f), 1.2)), each followed by Time::adjustDeltaT towards the next write time (cases/steckler/system/controlDict:28-56)"""
         self.CoNum, self.meanCoNum = self.courant()
 
-        def adjust(d):
-            rem = (int(self.time / writeInterval + 1e-9) + 1) * writeInterval - self.time
-            n = int(rem / d - 1e-12) + 1
+        def adjust(d):          # Time::adjustDeltaT (OpenFOAM-dev Time.C): the tracked write index, nSteps = timeToNextWrite/deltaT - SMALL
+            rem = max(0.0, (getattr(self, "writeTimeIndex", 0) + 1) * writeInterval - self.time)
+            n = int(rem / d - SMALL) + 1
             nd = rem / n
             return min(nd, 2.0 * d) if nd >= d else max(nd, 0.2 * d)
+        self._writeInterval = writeInterval
         fac = maxCo / (self.CoNum + SMALL)
         dt = adjust(min(self.dt * min(fac, 1.2), maxDeltaT))
         dt = adjust(min(min(min(fac, 1.0 + 0.1 * fac), 1.2) * dt, maxDeltaT))
@@ -283,6 +284,8 @@ class StecklerCase:
         self.time = getattr(self, "time", 0.0) or self.dt
         self.set_delta_t_next()
         self.time += self.dt
+        # Time::operator++ with writeControl adjustableRunTime: writeTimeIndex_ = label((value - startTime + 0.5 deltaT)/writeInterval) when larger
+        self.writeTimeIndex = max(getattr(self, "writeTimeIndex", 0), int((self.time + 0.5 * self.dt) / self._writeInterval))
         self.log = []
         self.psi0, self.p0, self.p_rgh0, self.phi0 = self.psi.copy(), self.p.copy(), self.p_rgh.copy(), self.phi.copy()
         self.rho0, self.U0, self.K_start, self.p_old = self.rho.copy(), self.U.copy(), self.K.copy(), self.p.copy()

@@ -181,3 +181,38 @@ def test_tile_hint_from_centres_makes_tiles_of_exactly_the_requested_width(ffm):
         pairs = np.unique(np.stack([hint, want]), axis=1)
         assert pairs.shape[1] == len(np.unique(hint)) == len(np.unique(want)) == -(-ny // T) * -(-nz // T)
         assert np.bincount(np.unique(hint, return_inverse=True)[1]).max() == nx * T * T
+
+
+def test_time_adjustDeltaT_across_several_write_times(ffm):
+    import os
+    import numpy as np
+    """Time::setDeltaT -> Time::adjustDeltaT of include/ffmFoam.H against the upstream algorithm restated here (OpenFOAM-dev Time.C:
+    timeToNextWrite = max(0, (writeTimeIndex_ + 1)*writeInterval - (value - startTime)); nSteps = timeToNextWrite/deltaT - SMALL;
+    newDeltaT = timeToNextWrite/(label(nSteps) + 1), at most doubled, at least a fifth; operator++: writeTimeIndex_ = label((value -
+    startTime + 0.5 deltaT)/writeInterval) when larger): 400 steps with a wandering wish for deltaT cross a dozen write times, the
+    time accumulating its rounding error -- deltaT, time and write index equal to the restatement at every step, and every write
+    time is hit (to rounding) by a whole number of steps."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    n, wI = 400, 0.25
+    rng = np.random.default_rng(7)
+    wish = 0.03 * (1.0 + 0.6 * np.sin(0.05 * np.arange(n))) * (1.0 + 0.05 * rng.standard_normal(n))
+    dt, t, wi = np.zeros(n), np.zeros(n), (C.c_int * n)()
+    dp = C.POINTER(C.c_double)
+    lib.b1_time_sequence.argtypes = [C.c_double, C.c_double, C.c_int, dp, dp, dp, C.POINTER(C.c_int)]
+    assert lib.b1_time_sequence(0.01, wI, n, wish.ctypes.data_as(dp), dt.ctypes.data_as(dp), t.ctypes.data_as(dp), wi) == n
+    SMALL = 1e-15
+    value, idx, hits = 0.0, 0, 0
+    for i in range(n):
+        d = wish[i]
+        rem = max(0.0, (idx + 1) * wI - value)
+        nSteps = int(rem / d - SMALL) + 1
+        nd = rem / nSteps
+        d = min(nd, 2.0 * d) if nd >= d else max(nd, 0.2 * d)
+        value += d
+        w = int((value + 0.5 * d) / wI)
+        if w > idx:
+            idx = w; hits += 1
+            assert abs(value - idx * wI) < 1e-12, (i, value)          # the write time itself was reached
+        assert dt[i] == d and t[i] == value and wi[i] == idx, (i, dt[i], d, t[i], value, wi[i], idx)
+    assert hits >= 10

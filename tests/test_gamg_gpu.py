@@ -172,3 +172,48 @@ def test_gamg_on_unstructured_addressing(O, ffm, ctx, meshName, asym, smoother):
     assert pf["nIterations"] == pr["nIterations"] and pf["converged"], (pf, pr)
     assert rel_l2(psi.cpu().numpy(), xr) < 1e-9
     G.close(); A.close()
+
+
+def test_the_agglomeration_direction_carries_over_to_the_next_mesh_of_a_run(O, ffm, ctx):
+    """pairGAMGAgglomeration::forward_ is a static upstream: it is toggled by every pair agglomeration of the run, so the hierarchy of a
+    second GAMG mesh / region depends on how many levels the first one had.  The context keeps it: a second ffm.GAMG with forward=None
+    continues in the direction the first ended with and equals the oracle's Agglomeration(forward=first.forward_after); started afresh it
+    equals the forward=True one -- and the two differ."""
+    from oracle import gamg
+    blk1, s1, Sf1 = _box(ffm, (9, 7, 6)); blk2, s2, Sf2 = _box(ffm, (14, 12, 10))
+    A1 = ffm.lduMatrix(ctx, blk1.nCells, blk1.l, blk1.u); A2 = ffm.lduMatrix(ctx, blk2.nCells, blk2.l, blk2.u)
+    G1 = ffm.GAMG(ctx, A1, blk1.l, blk1.u, Sf=Sf1)                         # the first agglomeration of the "run"
+    agg1 = gamg.Agglomeration(blk1.nCells, blk1.l, blk1.u, G1.weights)
+    G2 = ffm.GAMG(ctx, A2, blk2.l, blk2.u, Sf=Sf2, forward=None)           # continues
+    w2 = gamg.face_area_pair_weights(Sf2)
+    cont = gamg.Agglomeration(blk2.nCells, blk2.l, blk2.u, w2, forward=agg1.forward_after)
+    fresh = gamg.Agglomeration(blk2.nCells, blk2.l, blk2.u, w2)
+    want = cont if agg1.forward_after is False else fresh
+    assert G2.nLevels == want.nLevels
+    for lev in range(want.nLevels + 1):
+        l, u = G2.level_addressing(lev)
+        assert np.array_equal(l, want.l[lev]) and np.array_equal(u, want.u[lev]), lev
+    if agg1.forward_after is False:            # an odd number of levels in the first hierarchy: the second one is built the other way round
+        assert any(not np.array_equal(cont.l[lev], fresh.l[lev]) or not np.array_equal(cont.u[lev], fresh.u[lev]) for lev in range(1, min(cont.nLevels, fresh.nLevels) + 1))
+    G3 = ffm.GAMG(ctx, A2, blk2.l, blk2.u, Sf=Sf2)                         # started afresh
+    l, u = G3.level_addressing(1)
+    assert np.array_equal(l, fresh.l[1]) and np.array_equal(u, fresh.u[1])
+    G1.close(); G2.close(); G3.close(); A1.close(); A2.close()
+
+
+def test_a_mesh_below_nCellsInCoarsestLevel_is_solved_on_the_fine_matrix(O, ffm, ctx):
+    """the first agglomeration already falls below nCellsInCoarsestLevel (a small region): no coarse level; the solve then is the
+    coarsest-level solver (PCG + DIC, PBiCGStab + DILU) on the fine matrix, with its iteration count"""
+    blk, s, Sf = _box(ffm, (5, 4, 3))
+    A = ffm.lduMatrix(ctx, blk.nCells, blk.l, blk.u)
+    G = ffm.GAMG(ctx, A, blk.l, blk.u, Sf=Sf, nCellsInCoarsestLevel=50)
+    assert G.nLevels == 0
+    for lower in (None, s["upper"] * (1.0 + 0.3 * (ffm.hexmesh.hash_u(0xA1, blk.gface) - 0.5))):
+        G.set_matrix(ctx.to_device(s["diag"]), ctx.to_device(s["upper"]), None if lower is None else ctx.to_device(lower))
+        psi = ctx.zeros(blk.nCells)
+        pf = G.solve(psi, ctx.to_device(s["source"]), smoother="GaussSeidel" if lower is None else "DILU", tolerance=1e-9)
+        Ao = O.Ldu(blk.nCells, blk.l, blk.u).set_coeffs(s["diag"], s["upper"], lower)
+        ref, pr = Ao.solve(O.PCG if lower is None else O.PBICGSTAB, O.DIC if lower is None else O.DILU, np.zeros(blk.nCells), s["source"], tolerance=1e-9)
+        assert pf["nIterations"] == pr["nIterations"] and pf["converged"]
+        assert rel_l2(psi.cpu().numpy(), ref) < 1e-10
+    G.close(); A.close()
