@@ -190,15 +190,47 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
             auto idOf = [&](int lab) { return (int)(std::lower_bound(labels.begin(), labels.end(), lab) - labels.begin()); };
             std::vector<int> gid(nOwn);
             for (int c = 0; c < nOwn; c++) gid[c] = idOf(groupHint[c]);
+            int nl2 = nl;
+            // A label class that an internal wall (a sheet of baffle faces, cases/steckler/system/createBafflesDict) cuts into pieces that
+            // are not connected inside the class has dependency levels that restart behind the wall: a level then holds cells of two
+            // planes, is split over several entries, and the neighbours of a cell are no longer in the entries next to its own (the
+            // ring window of the tiled Amul; the sweeps' LDS ring).  Every connected component of a class becomes a group of its own:
+            // no new edges, so the group graph stays acyclic; classes in one piece (every tile of a box) are unchanged.
+            static const bool splitComponents = !(getenv("FFM_TILE_SPLIT_COMPONENTS") && atoi(getenv("FFM_TILE_SPLIT_COMPONENTS")) == 0);
+            if (splitComponents) {
+                std::vector<int> parent(nOwn);
+                std::iota(parent.begin(), parent.end(), 0);
+                auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+                for (int f = 0; f < F; f++) if (u[f] < nOwn && gid[l[f]] == gid[u[f]]) { const int a_ = find(l[f]), b_ = find(u[f]); if (a_ != b_) parent[std::max(a_, b_)] = std::min(a_, b_); }
+                // components of a class, numbered by their lowest cell; the first LARGE one keeps the class' id, the other large ones get
+                // new ids; fragments (a few cells cut off by scattered baffle faces: fewer than 1024 cells or a sixteenth of the class)
+                // stay with the class -- a group per fragment would only add tile hand-offs
+                std::vector<int> compSize(nOwn, 0), classSize(nl, 0);
+                for (int c = 0; c < nOwn; c++) { compSize[find(c)]++; classSize[gid[c]]++; }
+                std::vector<int> firstRoot(nl, -1), newId(nOwn, -1);
+                for (int c = 0; c < nOwn; c++) {
+                    const int r = find(c);
+                    if (newId[r] >= 0) continue;
+                    const int g = gid[r];
+                    const bool large = compSize[r] >= std::max(1024, classSize[g] / 16);
+                    if (!large) newId[r] = g;
+                    else if (firstRoot[g] < 0) { firstRoot[g] = r; newId[r] = g; }
+                    else newId[r] = nl2++;
+                }
+                if (nl2 > nl) {
+                    if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm: %d group labels in %d connected pieces (internal walls): one group per piece\n", nl, nl2);
+                    for (int c = 0; c < nOwn; c++) gid[c] = newId[find(c)];
+                }
+            }
             std::vector<std::pair<int, int>> edges;
             for (int f = 0; f < F; f++) if (u[f] < nOwn && gid[l[f]] != gid[u[f]]) edges.emplace_back(gid[l[f]], gid[u[f]]);
             std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
-            std::vector<int> indeg(nl, 0), estart(nl + 1, 0);
+            std::vector<int> indeg(nl2, 0), estart(nl2 + 1, 0);
             for (auto &e : edges) { indeg[e.second]++; estart[e.first + 1]++; }
-            for (int i = 0; i < nl; i++) estart[i + 1] += estart[i];
-            std::vector<int> rank(nl, -1), heap;
+            for (int i = 0; i < nl2; i++) estart[i + 1] += estart[i];
+            std::vector<int> rank(nl2, -1), heap;
             auto cmp = [](int x, int y) { return x > y; };
-            for (int i = 0; i < nl; i++) if (!indeg[i]) heap.push_back(i);
+            for (int i = 0; i < nl2; i++) if (!indeg[i]) heap.push_back(i);
             std::make_heap(heap.begin(), heap.end(), cmp);
             int done = 0;
             while (!heap.empty()) {
@@ -206,7 +238,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
                 rank[x] = done++;
                 for (int k = estart[x]; k < estart[x + 1]; k++) { const int y = edges[k].second; if (--indeg[y] == 0) { heap.push_back(y); std::push_heap(heap.begin(), heap.end(), cmp); } }
             }
-            if (done == nl) { hinted = true; G = nl; for (int c = 0; c < nOwn; c++) grpOfOld[c] = rank[gid[c]]; }
+            if (done == nl2) { hinted = true; G = nl2; for (int c = 0; c < nOwn; c++) grpOfOld[c] = rank[gid[c]]; }
         }
         if (!hinted && autoMode) {           // unusable hint: level-scheduled sweeps
             if (getenv("FFM_VERBOSE") && groupHint) fprintf(stderr, "ffm: the group hint gives a cyclic group graph: level-scheduled sweeps\n");
