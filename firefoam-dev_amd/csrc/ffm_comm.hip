@@ -300,6 +300,7 @@ extern "C" int ffm_ldu_set_ghost_exchange(ffm_ldu *A, int nNbr, const int *nbrRa
     for (int q = 0; q < nNbr; q++) { A->ghSendOff[q + 1] = A->ghSendOff[q] + sendCount[q]; A->ghRecvOff[q + 1] = A->ghRecvOff[q] + recvCount[q]; }
     if (A->ghRecvOff[nNbr] != A->nCells - A->nOwned) { ffm_set_error("ghost exchange: receive counts (%d) != ghost cells (%d)", A->ghRecvOff[nNbr], A->nCells - A->nOwned); A->ghNbrRank.clear(); return FFM_ERR_ARG; }
     const int nSend = A->ghSendOff[nNbr];
+    A->h_ghSendCaller.assign(sendCells, sendCells + nSend);
     for (int i = 0; i < nSend; i++) if (sendCells[i] < 0 || sendCells[i] >= A->nOwned) { ffm_set_error("ghost exchange: send cell out of range"); A->ghNbrRank.clear(); return FFM_ERR_ARG; }
     FFM_HIP(hipMalloc((void **)&A->ghSendCells, sizeof(int) * std::max(nSend, 1)));
     FFM_HIP(hipMalloc((void **)&A->ghSendBuf, sizeof(double) * std::max(nSend, 1)));

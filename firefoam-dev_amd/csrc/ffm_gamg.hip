@@ -15,12 +15,25 @@
 //   agglomerateMatrix coarse diag / upper / lower from the fine coefficients in caller (agglomeration) order, then handed to
 //                    ffm_ldu_set_coeffs_d of the coarse level
 // The V-cycle is launched level by level from the host; nothing is read back inside it (the correction scale factors stay on
-// the device) except by the coarsest-level solver, which checks its own convergence.  Serial (one rank) for now.
+// the device) except by the coarsest-level solver, which checks its own convergence.
+//
+// Decomposed meshes (OpenFOAM's default, no processorAgglomerator: cases/wallFireSpread2D/system/fvSolution:36-60 on 4 ranks): every rank
+// agglomerates ITS OWN cells over its internal faces (pairGAMGAgglomeration on the rank's lduAddressing); the processor interfaces are
+// agglomerated with them (GAMGInterface / processorGAMGInterface: a coarse interface face per pair of coarse cells either side, its
+// coefficient the sum of its fine faces').  In this library's ghost-cell form: a level has owned coarse cells + coarse GHOST cells -- one
+// per distinct coarse cell of a neighbour rank that touches this rank, numbered rank by rank in the order of first appearance along the
+// fine receive list -- the fine cut faces agglomerate into coarse cut faces, and the level's ghost exchange sends, per neighbour, the
+// coarse cells of the fine send list in the order of first appearance (the same order on both sides, because a receive list mirrors
+// the neighbour's send list).  The neighbour's restriction map reaches this rank through the fine level's ghost exchange.  Smoothers,
+// Amul and the coarsest-level Krylov solve then are the decomposed forms of ffm_ldu / ffm_solve (ghost refresh before every sweep /
+// product, block-Jacobi DIC / DILU, all-reduced dots); continueAgglomerating, normFactor, residual norms and the correction scale
+// factors are global (all-reduced).
 #include "ffm_internal.hpp"
 #include "ffm_device.hpp"
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <unordered_map>
 
 extern "C" int ffm_solve_internal_i(ffm_ldu *A, int solver, int precond, double tol, double relTol, int minIter, int maxIter, int nSweeps,
                                     double *psi, const double *source, ffm_perf *perf);
@@ -32,7 +45,8 @@ constexpr double GREAT_ = 1e15;
 struct Level {              // matrix k (0 = the caller's matrix); maps lead to matrix k + 1
     ffm_ldu *A = nullptr;
     bool owned = false;
-    int nCells = 0, nFaces = 0;
+    int nCells = 0, nFaces = 0;             // OWNED cells; faces including the cut faces towards ghost cells
+    int nGhost = 0;                         // ghost cells behind the owned ones (decomposed meshes)
     std::vector<int> l, u;                  // caller (agglomeration) order
     // ---- device, towards the coarser level
     int nCoarse = 0, nCoarseFaces = 0;
@@ -213,6 +227,16 @@ __global__ __launch_bounds__(1024) void k_sum_partials(int n, const double *__re
     if (threadIdx.x == 0) scal[slot] = r;
 }
 
+// sum of a few host values over the ranks (set-up decisions: cell counts), through the context's scalar slots
+int ffm_host_allreduce_sum(ffm_ctx *c, double *v, int n)
+{
+    if (c->nRanks <= 1 && !c->comm) return FFM_OK;
+    if (n > 4) return FFM_ERR_ARG;
+    FFM_TRY(ffm_h2d(c, c->scal_d + S_TMP0, v, sizeof(double) * n));
+    FFM_TRY(ffm_allreduce_slots(c, S_TMP0, n));
+    return ffm_d2h(c, v, c->scal_d + S_TMP0, sizeof(double) * n);
+}
+
 inline int grid_of(long n) { return (int)std::max(1L, std::min((n + 255) / 256, (long)RED_BLOCKS)); }
 
 }  // namespace
@@ -220,7 +244,7 @@ inline int grid_of(long n) { return (int)std::max(1L, std::min((n + 255) / 256, 
 struct ffm_gamg {
     ffm_ctx *ctx = nullptr;
     std::vector<Level> lev;             // lev[0]: the caller's matrix; lev[k]: coarse level k-1 of the reference's numbering
-    bool symmetric = true, haveMatrix = false;
+    bool symmetric = true, haveMatrix = false, decomposed = false;
     int nPre = 0, nPost = 2, nFinest = 2, preMul = 1, maxPre = 4, postMul = 1, maxPost = 4;
     double *fRes = nullptr, *fCorr = nullptr, *fApsi = nullptr, *fSumA = nullptr;      // finest-level work (internal order)
     int *faceToNative = nullptr;            // [nFaces] caller face -> native coefficient index (ffm_gamg_set_matrix_native_d)
@@ -266,13 +290,14 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
         ffm_set_error("ffm_gamg_create: bad argument"); return FFM_ERR_ARG;
     }
     if (mergeLevels != 1) { ffm_set_error("GAMG: mergeLevels %d not offered (the reference's dictionaries use 1)", mergeLevels); return FFM_ERR_UNSUPPORTED; }
-    if (ctx->nRanks > 1) { ffm_set_error("GAMG: one rank only (processor agglomeration is not built)"); return FFM_ERR_UNSUPPORTED; }
-    if (finest->nOwned != nCells || finest->nCells != nCells) { ffm_set_error("GAMG: the matrix has %d cells, the addressing %d", finest->nCells, nCells); return FFM_ERR_ARG; }
+    if (finest->nCells != nCells) { ffm_set_error("GAMG: the matrix has %d cells (owned + ghost), the addressing %d", finest->nCells, nCells); return FFM_ERR_ARG; }
+    const bool decomposed = finest->nCells > finest->nOwned;
+    if (decomposed && finest->ghNbrRank.empty()) { ffm_set_error("GAMG: ghost cells without a ghost exchange (ffm_ldu_set_ghost_exchange first)"); return FFM_ERR_ARG; }
     FFM_HIP(hipSetDevice(ctx->device));
     ffm_gamg *G = new ffm_gamg; G->ctx = ctx;
     auto fail = [&](int rc) { ffm_gamg_destroy(G); return rc; };
     G->lev.emplace_back();
-    { Level &L0 = G->lev[0]; L0.A = finest; L0.nCells = nCells; L0.nFaces = nFaces; L0.l.assign(lowerAddr, lowerAddr + nFaces); L0.u.assign(upperAddr, upperAddr + nFaces); }
+    { Level &L0 = G->lev[0]; L0.A = finest; L0.nCells = finest->nOwned; L0.nGhost = finest->nCells - finest->nOwned; L0.nFaces = nFaces; L0.l.assign(lowerAddr, lowerAddr + nFaces); L0.u.assign(upperAddr, upperAddr + nFaces); }
     std::vector<double> w(faceWeights, faceWeights + nFaces);
     // Tile plans for the coarse levels: when the finest matrix runs the tiled wavefront kernels, a coarse cell inherits the tile
     // (group) of its first fine cell.  On a hex box the pairs of the first few agglomerations lie inside the tiles, the coarse
@@ -282,7 +307,7 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
     std::vector<int> hint;                  // group label per cell of the current level (caller order); empty: no inheritance
     {
         const char *e = getenv("FFM_GAMG_TILES");
-        if (finest->sweepMode == 2 && finest->grpCell && finest->nGroups > 0 && !(e && atoi(e) == 0)) {
+        if (!decomposed && finest->sweepMode == 2 && finest->grpCell && finest->nGroups > 0 && !(e && atoi(e) == 0)) {
             std::vector<int> gc((size_t)finest->nGroups + 1);
             FFM_HIP(hipStreamSynchronize(ctx->stream));              // the table was uploaded on the context's (non-blocking) stream
             FFM_TRY(ffm_d2h(ctx, gc.data(), finest->grpCell, sizeof(int) * gc.size()));
@@ -298,14 +323,65 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
     while ((int)G->lev.size() - 1 < maxLevels - 1) {
         // NOTE: G->lev may reallocate below; take no references across emplace_back
         const int k = (int)G->lev.size() - 1;
-        const int nFine = G->lev[k].nCells;
+        const int nFine = G->lev[k].nCells, nFineGhost = G->lev[k].nGhost, nF = (int)G->lev[k].l.size();
         std::vector<int> cmap; int nCoarse = 0;
-        pair_agglomerate(nFine, G->lev[k].l, G->lev[k].u, w, forward, cmap, nCoarse);
+        if (!decomposed) pair_agglomerate(nFine, G->lev[k].l, G->lev[k].u, w, forward, cmap, nCoarse);
+        else {
+            // the rank's own cells over its internal faces (the cut faces belong to the processor interfaces, not to lduAddr())
+            std::vector<int> li, ui; std::vector<double> wi;
+            for (int f = 0; f < nF; f++) if (G->lev[k].u[f] < nFine) { li.push_back(G->lev[k].l[f]); ui.push_back(G->lev[k].u[f]); wi.push_back(w[f]); }
+            pair_agglomerate(nFine, li, ui, wi, forward, cmap, nCoarse);
+        }
         forward = !forward;
-        if (nCoarse < nCellsInCoarsestLevel || !(nCoarse < nFine)) break;         // continueAgglomerating
+        {   // GAMGAgglomeration::continueAgglomerating: global cell counts (nCoarse >= nProcs*nCellsInCoarsestLevel and some agglomeration happened)
+            double tot[2] = {(double)nCoarse, (double)nFine};
+            if (decomposed) { FFM_TRY(ffm_host_allreduce_sum(ctx, tot, 2)); }
+            if (tot[0] < (double)ctx->nRanks * nCellsInCoarsestLevel || !(tot[0] < tot[1])) break;
+        }
+        // ---- decomposed: the neighbours' restriction maps for the ghost cells, the coarse ghost cells and the coarse exchange lists
+        int nCoarseGhost = 0;
+        std::vector<int> cNbr, cSendCount, cSendCells, cRecvCount;
+        if (decomposed) {
+            ffm_ldu *Af = G->lev[k].A;
+            const int nNbr = (int)Af->ghNbrRank.size();
+            std::vector<double> x((size_t)nFine + nFineGhost, -1.0);
+            for (int c = 0; c < nFine; c++) x[c] = (double)cmap[c];
+            // through the level's own ghost exchange (caller order == internal order for the ghost range; owned values are gathered by the send list)
+            {
+                double *xd = nullptr;
+                FFM_TRY(ffm_malloc_uninit(ctx, sizeof(double) * x.size(), (void **)&xd));
+                std::vector<double> xi(x.size());
+                const std::vector<int> &n2o = Af->h_newToOldCell;
+                for (size_t i = 0; i < x.size(); i++) xi[i] = x[Af->identity ? i : n2o[i]];
+                FFM_TRY(ffm_h2d(ctx, xd, xi.data(), sizeof(double) * xi.size()));
+                FFM_TRY(ffm_ghost_exchange(Af, xd));
+                FFM_TRY(ffm_d2h(ctx, xi.data(), xd, sizeof(double) * xi.size()));
+                for (int g = 0; g < nFineGhost; g++) x[nFine + g] = xi[nFine + g];          // ghosts keep their place behind the owned cells in both orders
+                FFM_TRY(ffm_free(ctx, xd));
+            }
+            cmap.resize((size_t)nFine + nFineGhost);
+            cNbr = Af->ghNbrRank; cSendCount.assign(nNbr, 0); cRecvCount.assign(nNbr, 0);
+            for (int q = 0; q < nNbr; q++) {
+                // coarse ghost cells of neighbour q: its coarse cells in the order of first appearance along this rank's receive list
+                std::unordered_map<int, int> seen;
+                for (int g = Af->ghRecvOff[q]; g < Af->ghRecvOff[q + 1]; g++) {
+                    const int remote = (int)x[nFine + g];
+                    if (remote < 0) { ffm_set_error("GAMG: a ghost cell received no restriction address"); return fail(FFM_ERR_COMM); }
+                    auto it = seen.find(remote);
+                    if (it == seen.end()) { it = seen.emplace(remote, nCoarse + nCoarseGhost).first; nCoarseGhost++; cRecvCount[q]++; }
+                    cmap[nFine + g] = it->second;
+                }
+                // what this rank sends to q on the coarse level: the coarse cells of its fine send list, first appearance (the mirror image)
+                std::unordered_map<int, int> sent;
+                for (int i = Af->ghSendOff[q]; i < Af->ghSendOff[q + 1]; i++) {
+                    const int cc = cmap[Af->h_ghSendCaller[i]];
+                    if (sent.emplace(cc, 1).second) { cSendCells.push_back(cc); cSendCount[q]++; }
+                }
+            }
+        }
         std::vector<int> cl, cu, fra; std::vector<char> flip;
-        agglomerate_addressing(G->lev[k].l, G->lev[k].u, cmap, nCoarse, cl, cu, fra, flip);
-        const int nCF = (int)cl.size(), nF = (int)G->lev[k].l.size();
+        agglomerate_addressing(G->lev[k].l, G->lev[k].u, cmap, nCoarse + nCoarseGhost, cl, cu, fra, flip);
+        const int nCF = (int)cl.size();
         // restrictFaceField of the weights
         std::vector<double> cw(nCF, 0.0);
         for (int f = 0; f < nF; f++) if (fra[f] >= 0) cw[fra[f]] += w[f];
@@ -319,18 +395,25 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
             hint.swap(ch);
             if (nCoarse < tileMinCells) hint.clear();
         }
-        if (!hint.empty()) rc = ffm_ldu_create_hint(ctx, nCoarse, 0, nCF, cl.data(), cu.data(), hint.data(), &Ac);
+        if (decomposed) {
+            rc = ffm_ldu_create_ext(ctx, nCoarse, nCoarseGhost, nCF, cl.data(), cu.data(), &Ac);
+            if (!rc) rc = ffm_ldu_set_ghost_exchange(Ac, (int)cNbr.size(), cNbr.data(), cSendCount.data(), cSendCells.data(), cRecvCount.data());
+            if (!rc && !G->lev[k].A->ghTags.empty()) rc = ffm_ldu_set_exchange_tags(Ac, 1, (int)cNbr.size(), G->lev[k].A->ghTags.data());
+            if (!rc) { double gc = (double)nCoarse; rc = ffm_host_allreduce_sum(ctx, &gc, 1); if (!rc) rc = ffm_ldu_set_global_cells(Ac, (long)gc); }
+        }
+        else if (!hint.empty()) rc = ffm_ldu_create_hint(ctx, nCoarse, 0, nCF, cl.data(), cu.data(), hint.data(), &Ac);
         else rc = ffm_ldu_create(ctx, nCoarse, nCF, cl.data(), cu.data(), &Ac);
         if (rc) return fail(rc);
         if (Ac->sweepMode != 2) hint.clear();           // the planner gave up here: no tiles further down either
-        if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm gamg: coarse level %d: %d cells, %s sweeps\n", k + 1, nCoarse, Ac->sweepMode == 2 ? "tiled" : "level-scheduled");
+        if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm gamg: coarse level %d: %d cells (+ %d ghost), %s sweeps\n", k + 1, nCoarse, nCoarseGhost, Ac->sweepMode == 2 ? "tiled" : "level-scheduled");
         G->lev.emplace_back();
         Level &Lf = G->lev[k], &Lc = G->lev[k + 1];
-        Lc.A = Ac; Lc.owned = true; Lc.nCells = nCoarse; Lc.nFaces = nCF; Lc.l = cl; Lc.u = cu;
+        Lc.A = Ac; Lc.owned = true; Lc.nCells = nCoarse; Lc.nGhost = nCoarseGhost; Lc.nFaces = nCF; Lc.l = cl; Lc.u = cu;
         Lf.nCoarse = nCoarse; Lf.nCoarseFaces = nCF;
-        // ---- maps.  Caller-order CSRs for the coefficients
+        // ---- maps.  Caller-order CSRs for the coefficients (owned cells only: a ghost cell's row belongs to its own rank)
         std::vector<int> st, it;
-        group_by(nCoarse, nFine, cmap, st, it);
+        std::vector<int> cmapOwn(cmap.begin(), cmap.begin() + nFine);
+        group_by(nCoarse, nFine, cmapOwn, st, it);
         if ((rc = up(ctx, &Lf.cStart, st)) || (rc = up(ctx, &Lf.cItem, it))) return fail(rc);
         std::vector<int> key(nF);
         for (int f = 0; f < nF; f++) key[f] = fra[f] < 0 ? -1 - fra[f] : -1;
@@ -340,21 +423,23 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
         for (int f = 0; f < nF; f++) { key[f] = fra[f] >= 0 ? fra[f] : -1; val[f] = f | (flip[f] ? (int)0x80000000 : 0); }
         group_by(nCF, nF, key, st, it, &val);
         if ((rc = up(ctx, &Lf.fStart, st)) || (rc = up(ctx, &Lf.fItem, it))) return fail(rc);
-        // internal-order maps for the vectors: fine internal i = oldToNew_f[caller], coarse likewise
+        // internal-order maps for the vectors: fine internal i = oldToNew_f[caller], coarse likewise (owned cells)
         const std::vector<int> &n2oF = Lf.A->h_newToOldCell, &n2oC = Lc.A->h_newToOldCell;
         std::vector<int> o2nF(nFine), o2nC(nCoarse);
-        for (int i = 0; i < nFine; i++) o2nF[n2oF[i]] = i;
-        for (int i = 0; i < nCoarse; i++) o2nC[n2oC[i]] = i;
+        for (int i = 0; i < nFine; i++) o2nF[Lf.A->identity ? i : n2oF[i]] = i;
+        for (int i = 0; i < nCoarse; i++) o2nC[Lc.A->identity ? i : n2oC[i]] = i;
         std::vector<int> toC(nFine), keyI(nFine), valI(nFine);
-        for (int i = 0; i < nFine; i++) toC[i] = o2nC[cmap[n2oF[i]]];
+        for (int i = 0; i < nFine; i++) toC[i] = o2nC[cmap[Lf.A->identity ? i : n2oF[i]]];
         // restrict lists: per coarse internal cell its fine cells ascending in CALLER index, stored as internal indices
         for (int c = 0; c < nFine; c++) { keyI[c] = o2nC[cmap[c]]; valI[c] = o2nF[c]; }
         group_by(nCoarse, nFine, keyI, st, it, &valI);
         if ((rc = up(ctx, &Lf.rStart, st)) || (rc = up(ctx, &Lf.rItem, it)) || (rc = up(ctx, &Lf.toCoarse, toC))) return fail(rc);
         // coarse level storage
-        if ((rc = dalloc(&Lc.diag, nCoarse)) || (rc = dalloc(&Lc.upper, nCF)) || (rc = dalloc(&Lc.lower, nCF)) || (rc = dalloc(&Lc.dInt, nCoarse)) ||
-            (rc = dalloc(&Lc.src, nCoarse)) || (rc = dalloc(&Lc.corr, nCoarse)) || (rc = dalloc(&Lc.acf, nCoarse)) || (rc = dalloc(&Lc.pre, nCoarse)) ||
-            (rc = dalloc(&Lc.tmp, nCoarse))) return fail(rc);
+        const size_t nAll = (size_t)nCoarse + nCoarseGhost;           // vectors carry the ghost range behind the owned cells
+        if ((rc = dalloc(&Lc.diag, nAll)) || (rc = dalloc(&Lc.upper, nCF)) || (rc = dalloc(&Lc.lower, nCF)) || (rc = dalloc(&Lc.dInt, nAll)) ||
+            (rc = dalloc(&Lc.src, nAll)) || (rc = dalloc(&Lc.corr, nAll)) || (rc = dalloc(&Lc.acf, nAll)) || (rc = dalloc(&Lc.pre, nAll)) ||
+            (rc = dalloc(&Lc.tmp, nAll))) return fail(rc);
+        FFM_HIP(hipMemsetAsync(Lc.diag, 0, sizeof(double) * nAll, ctx->stream));     // (ghost rows: no coefficients of their own here)
     }
     ctx->gamgForward = forward;             // the next agglomeration of this run continues in the direction this one ended with
     // no coarse level (the first agglomeration already falls below nCellsInCoarsestLevel: small meshes / regions): ffm_gamg_solve_d then
@@ -362,6 +447,7 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
     int rc;
     if ((rc = dalloc(&G->lev[0].dInt, nCells)) || (rc = dalloc(&G->fRes, nCells)) || (rc = dalloc(&G->fCorr, nCells)) || (rc = dalloc(&G->fApsi, nCells)) ||
         (rc = dalloc(&G->fSumA, nCells))) return fail(rc);
+    G->decomposed = decomposed;
     *out = G;
     return FFM_OK;
 }
@@ -486,6 +572,7 @@ static int scale_level(ffm_gamg *G, int k, double *field, double *acf, const dou
     FFM_TRY(ffm_k_spmv(L.A, field, acf, false));
     FFM_TRY(ffm_k_dot(c, source, field, L.nCells, S_TMP0));
     FFM_TRY(ffm_k_dot(c, acf, field, L.nCells, S_TMP1));
+    if (G->decomposed) FFM_TRY(ffm_allreduce_slots(c, S_TMP0, 2));            // gSumProd over the ranks
     hipLaunchKernelGGL(k_scale_factor, dim3(1), dim3(64), 0, s, c->scal_d);
     hipLaunchKernelGGL(k_scale, dim3(grid_of(L.nCells)), dim3(256), 0, s, (long)L.nCells, field, (const double *)acf, source, (const double *)L.dInt, (const double *)c->scal_d);
     FFM_HIP(hipGetLastError());
@@ -568,10 +655,13 @@ extern "C" int ffm_gamg_solve_d(ffm_gamg *G, int smoother, double tol, double re
     FFM_TRY(ffm_k_spmv(A, psi, G->fApsi, false));
     FFM_TRY(ffm_k_sumA(A, G->fSumA));
     FFM_TRY(ffm_k_sum(c, psi, N, S_TMP0));
-    hipLaunchKernelGGL(k_gamg_normf, dim3(g), dim3(256), 0, s, N, (const double *)G->fApsi, src, (const double *)G->fSumA, (const double *)c->scal_d, (double)N, c->partials_d);
+    if (G->decomposed) FFM_TRY(ffm_allreduce_slots(c, S_TMP0, 1));             // xRef = gAverage(psi): global sum over the global cell count
+    hipLaunchKernelGGL(k_gamg_normf, dim3(g), dim3(256), 0, s, N, (const double *)G->fApsi, src, (const double *)G->fSumA, (const double *)c->scal_d,
+                       (double)(G->decomposed ? A->globalCells : N), c->partials_d);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(1024), 0, s, g, (const double *)c->partials_d, c->scal_d, (int)S_TMP1);
     hipLaunchKernelGGL(k_sub3, dim3(g), dim3(256), 0, s, N, G->fRes, src, (const double *)G->fApsi);
     FFM_TRY(ffm_k_summag(c, G->fRes, N, S_TMP0));
+    if (G->decomposed) FFM_TRY(ffm_allreduce_slots(c, S_TMP0, 2));             // gSumMag(residual), the normFactor sum
     FFM_TRY(ffm_read_scalars(c));
     const double normFactor = c->scal_h[S_TMP1] + 1e-20;
     out->initialResidual = c->scal_h[S_TMP0] / normFactor;
@@ -589,6 +679,7 @@ extern "C" int ffm_gamg_solve_d(ffm_gamg *G, int smoother, double tol, double re
             FFM_TRY(ffm_k_spmv(A, psi, G->fApsi, false));
             hipLaunchKernelGGL(k_sub3, dim3(g), dim3(256), 0, s, N, G->fRes, src, (const double *)G->fApsi);
             FFM_TRY(ffm_k_summag(c, G->fRes, N, S_TMP0));
+            if (G->decomposed) FFM_TRY(ffm_allreduce_slots(c, S_TMP0, 1));
             FFM_TRY(ffm_read_scalars(c));
             out->finalResidual = c->scal_h[S_TMP0] / normFactor;
         } while ((++out->nIterations < maxIter && !converged()) || out->nIterations < minIter);

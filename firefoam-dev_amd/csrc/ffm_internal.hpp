@@ -152,6 +152,7 @@ struct ffm_ldu {
     int nCells = 0, nFaces = 0;        // nCells = owned + ghost cells (array length of every cell field)
     int nOwned = 0;                    // rows of this rank; ghost cells [nOwned, nCells) are copies of neighbour-rank cells
     long globalCells = 0;
+    std::vector<int> h_ghSendCaller;        // the send cells of the ghost exchange in the caller's cell labels (GAMG: agglomerated per level)
     bool identity = true;           // caller numbering == internal numbering
     bool symmetric = true;
     bool bwdContig = true;          // backward levels are contiguous cell ranges

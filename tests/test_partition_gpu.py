@@ -84,3 +84,34 @@ def test_every_smoother_sweep_sees_the_neighbour_ranks_current_values(O, ffm, ct
     start = O.hash_u(0xF5, np.arange(N))
     assert rel_l2(a, start) > 1e-2
     assert rel_l2(b, a) < 1e-13, rel_l2(b, a)
+
+
+@pytest.mark.parametrize("meshName,world,precond,asym", [("steckler", 2, "GS", 0.0), ("steckler", 4, "GS", 0.0), ("dag_random", 2, "DILU", 0.3),
+                                                         ("steckler", 4, "SYMGS", 0.0), ("dag_random", 4, "DIC", 0.0)])
+def test_gamg_on_a_decomposed_mesh(O, ffm, ctx, meshName, world, precond, asym):
+    """GAMG over 2 and 4 ranks the way OpenFOAM runs it without a processorAgglomerator (BASELINE config 5: p_rgh by GAMG + GaussSeidel on
+    four ranks, cases/wallFireSpread2D/system/fvSolution:36-60): every rank agglomerates its own cells, the processor interfaces are
+    agglomerated with them, smoothers refresh the interfaces before every sweep, the coarsest level is solved over all ranks, the
+    stopping rule and the scale factors are global.  The device (ghost-cell form, ffm_gamg_* on ffm_ldu_create_ext matrices, ranks
+    sharing cuda:0 through the host transport) against the oracle in OpenFOAM's processor-patch form (oracle/gamg_multi.py) on the same
+    decomposition: the same hierarchy (cells per level on every rank), the same number of V-cycles, the same residuals and solution
+    (the two forms add a row's interface terms at different places of its sum: rounding level)."""
+    args = [meshName, "graph", "GAMG", precond, str(asym)]
+    port = 29400 + (os.getpid() % 150) + 11 * world + {"GS": 0, "DILU": 3, "SYMGS": 5, "DIC": 7}[precond]
+    with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
+        ref = _run_ranks("oracle", world, port, args, t1, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
+        got = _run_ranks("gpu", world, port + 1, args, t2)
+    assert len({int(p["nIter"]) for p in got}) == 1 and len({int(p["nLevels"]) for p in got}) == 1
+    for r in range(world):
+        assert int(got[r]["nLevels"]) == int(ref[r]["nLevels"]) and int(ref[r]["nLevels"]) >= 3
+        assert np.array_equal(got[r]["levelCells"], ref[r]["levelCells"]), (r, got[r]["levelCells"], ref[r]["levelCells"])
+        assert int(got[r]["nIter"]) == int(ref[r]["nIter"]) and 2 <= int(ref[r]["nIter"]) < 60, (int(got[r]["nIter"]), int(ref[r]["nIter"]))
+        assert abs(float(got[r]["initialResidual"]) - float(ref[r]["initialResidual"])) <= 1e-10
+        assert abs(float(got[r]["finalResidual"]) - float(ref[r]["finalResidual"])) <= 1e-6 * float(ref[r]["finalResidual"]) + 1e-14
+    N = sum(len(p["gcell"]) for p in ref)
+    a, b = np.empty(N), np.empty(N)
+    for p in ref:
+        a[p["gcell"]] = p["psi"]
+    for p in got:
+        b[p["gcell"]] = p["psi"]
+    assert rel_l2(b, a) < 1e-9, rel_l2(b, a)

@@ -44,6 +44,30 @@ if mode == "oracle":
             np.ctypeslib.as_array(recv[p], shape=(sizes[p],))[:] = rb[offs[p]:offs[p] + sizes[p]]
     cb = (O.ALLREDUCE_FN(_allreduce), O.EXCHANGE_FN(_exchange))
     A.comm = O.Comm(None, rank, world, cb[0], cb[1])
+    if solver == "GAMG":     # GAMG on the decomposed mesh, OpenFOAM's processor-patch form (oracle/gamg_multi.py); precond names the smoother
+        from oracle import gamg_multi
+
+        class _Comm:
+            ffo = A.comm
+
+            @staticmethod
+            def allreduce(a):
+                a = np.ascontiguousarray(a, np.float64).copy(); gloo.allreduce(a, 0); return a
+
+            @staticmethod
+            def exchange(sends):
+                recvs = [np.empty(len(s_)) for s_ in sends]
+                if ranks:
+                    gloo.exchange_var(ranks, [np.ascontiguousarray(s_, np.float64) for s_ in sends], recvs)
+                return recvs
+        w = 0.5 + O.hash_u(0xC7, sub.gface.astype(np.int64))                    # face weights of the agglomeration (any positive numbers)
+        agg = gamg_multi.AgglomerationMulti(sub.nOwned, sub.l[keep], sub.u[keep], w[keep], [p_[0] for p_ in pat], _Comm, world)
+        smoother = {"GS": "GaussSeidel", "SYMGS": "symGaussSeidel", "DIC": "DIC", "DILU": "DILU"}[precond]
+        S = gamg_multi.GAMGSolverMulti(agg, d[:sub.nOwned], upl[keep], None if lol is None else lol[keep], [p_[1] for p_ in pat], None, _Comm, N, smoother=smoother)
+        psi, perf = S.solve(np.zeros(sub.nOwned), source[sub.gcell[:sub.nOwned]], tolerance=1e-9, relTol=0.0, maxIter=60)
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), psi=psi, gcell=sub.gcell[:sub.nOwned], nIter=perf["nIterations"], initialResidual=perf["initialResidual"],
+                 finalResidual=perf["finalResidual"], nGhost=sub.nGhost, nNbr=len(sub.nbrRank), nLevels=agg.nLevels, levelCells=np.array(agg.nCells))
+        sys.exit(0)
     if solver == "GS2":      # ONE smoother call of two sweeps from a non-zero start (not a converged answer): sweep 2 needs sweep 1's neighbour values
         psi = A.gs_smooth(O.hash_u(0xF5, np.arange(N))[sub.gcell[:sub.nOwned]], source[sub.gcell[:sub.nOwned]], nSweeps=2, sym=(precond == "SYMGS"))
         perf = dict(nIterations=2, initialResidual=0.0)
@@ -56,6 +80,18 @@ else:
     A.set_ghost_exchange(sub.nbrRank, sub.sendCount, sub.sendCells, sub.recvCount, tags=sub.tags, globalCells=N)
     d, upl, lol = sub.coeffs(diag, up, lo)
     A.set_coeffs(d, upl, lol)
+    if solver == "GAMG":
+        w = 0.5 + O.hash_u(0xC7, sub.gface.astype(np.int64))
+        G = ffm.GAMG(ctx, A, sub.l, sub.u, weights=w)
+        G.set_matrix(ctx.to_device(d), ctx.to_device(upl), None if lol is None else ctx.to_device(lol))
+        psi_d = ctx.zeros(sub.nOwned + sub.nGhost)
+        smoother = {"GS": "GaussSeidel", "SYMGS": "symGaussSeidel", "DIC": "DIC", "DILU": "DILU"}[precond]
+        perf = G.solve(psi_d, ctx.to_device(sub.field(source)), smoother=smoother, tolerance=1e-9, relTol=0.0, maxIter=60)
+        levelCells = np.array([sub.nOwned] + [G.level_size(k)[0] for k in range(1, G.nLevels + 1)])
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), psi=psi_d.cpu().numpy()[:sub.nOwned], gcell=sub.gcell[:sub.nOwned], nIter=perf["nIterations"],
+                 initialResidual=perf["initialResidual"], finalResidual=perf["finalResidual"], nGhost=sub.nGhost, nNbr=len(sub.nbrRank), nLevels=G.nLevels, levelCells=levelCells)
+        G.close(); A.close(); ctx.close()
+        sys.exit(0)
     if solver == "GS2":
         out = A.smooth(ctx.to_device(sub.field(O.hash_u(0xF5, np.arange(N)))), ctx.to_device(sub.field(source)), nSweeps=2,
                        smoother="symGaussSeidel" if precond == "SYMGS" else "GaussSeidel")
