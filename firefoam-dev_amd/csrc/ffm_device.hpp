@@ -137,5 +137,6 @@ __device__ __forceinline__ void load_upper(const LduView &v, int c, RowEnt<W> &R
         if ((maxW) <= 3) { constexpr int W = 3; CALL; } \
         else if ((maxW) <= 4) { constexpr int W = 4; CALL; } \
         else if ((maxW) <= 8) { constexpr int W = 8; CALL; } \
-        else { constexpr int W = 16; CALL; }            \
+        else if ((maxW) <= 16) { constexpr int W = 16; CALL; } \
+        else { constexpr int W = 32; CALL; }            \
     } while (0)

@@ -100,7 +100,7 @@ void pair_agglomerate(int nFine, const std::vector<int> &l, const std::vector<in
 
 // GAMGAgglomeration::agglomerateLduAddressing: coarse faces in order of discovery per coarse owner
 void agglomerate_addressing(const std::vector<int> &l, const std::vector<int> &u, const std::vector<int> &rmap, int nCoarse,
-                            std::vector<int> &cl, std::vector<int> &cu, std::vector<int> &fra, std::vector<char> &flip)
+                            std::vector<int> &cl, std::vector<int> &cu, std::vector<int> &fra, std::vector<char> &flip, int nCoarseOwned = -1)
 {
     const int nF = (int)l.size();
     int maxN = 10;
@@ -129,8 +129,11 @@ void agglomerate_addressing(const std::vector<int> &l, const std::vector<int> &u
     cl.resize(nCF); cu.resize(nCF);
     std::vector<int> fmap(nCF);
     int k = 0;
-    for (int c = 0; c < nCoarse; c++) for (int i = 0; i < cCellnFaces[c]; i++) {
+    // decomposed levels (nCoarseOwned given): the faces of an owner towards OWNED cells first, then its cut faces towards ghost cells, each
+    // group in order of discovery -- the layout of every decomposed ffm_ldu (the packed lower entries need the owned faces in the first 16 slots)
+    for (int c = 0; c < nCoarse; c++) for (int pass = 0; pass < (nCoarseOwned >= 0 ? 2 : 1); pass++) for (int i = 0; i < cCellnFaces[c]; i++) {
         const int cf = cCellFaces[(size_t)maxN * c + i];
+        if (nCoarseOwned >= 0 && (initNbr[cf] >= nCoarseOwned) != (pass == 1)) continue;
         cl[k] = c; cu[k] = initNbr[cf]; fmap[cf] = k++;
     }
     flip.assign(nF, 0);
@@ -380,7 +383,7 @@ extern "C" int ffm_gamg_create(ffm_ctx *ctx, ffm_ldu *finest, int nCells, int nF
             }
         }
         std::vector<int> cl, cu, fra; std::vector<char> flip;
-        agglomerate_addressing(G->lev[k].l, G->lev[k].u, cmap, nCoarse + nCoarseGhost, cl, cu, fra, flip);
+        agglomerate_addressing(G->lev[k].l, G->lev[k].u, cmap, nCoarse + nCoarseGhost, cl, cu, fra, flip, decomposed ? nCoarse : -1);
         const int nCF = (int)cl.size();
         // restrictFaceField of the weights
         std::vector<double> cw(nCF, 0.0);

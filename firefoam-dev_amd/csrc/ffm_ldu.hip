@@ -524,13 +524,16 @@ static int ldu_create_impl(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int 
     for (int sl = 0; sl < nSl; sl++) {
         int wu = 0, wl = 0;
         for (int c = sl * 64; c < std::min(nOwn, sl * 64 + 64); c++) { wu = std::max(wu, upCnt[c]); wl = std::max(wl, loCnt[c]); }
-        if (wu > 16 || wl > 16) { ffm_set_error("a cell owns %d faces (>16): not supported by the packed layout", wu); delete A; return FFM_ERR_UNSUPPORTED; }
+        // at most 32 upper and 32 lower faces per cell (the widest instantiation of the row kernels); of the upper faces, those towards OWNED
+        // cells must sit in the first 16 slots (a lower entry packs owner << 4 | slot; checked below) -- the faces towards ghost cells, which
+        // follow them in a decomposed matrix and have no lower entry, may use the slots above (coarse GAMG levels at rank boundaries)
+        if (wu > 32 || wl > 32) { ffm_set_error("a cell has %d upper / %d lower faces (> 32): not supported by the sliced layout", wu, wl); delete A; return FFM_ERR_UNSUPPORTED; }
         upOff[sl + 1] = upOff[sl] + wu * 64; loOff[sl + 1] = loOff[sl] + wl * 64;
         uniform = (uniform == -2) ? wu : (uniform == wu ? wu : -1);
         uniformLo = (uniformLo == -2) ? wl : (uniformLo == wl ? wl : -1);
         maxW = std::max(maxW, std::max(wu, wl));
     }
-    if ((long)nSl * 16 * 64 > 0x7fffffffL || N >= (1 << 27)) { ffm_set_error("mesh too large for int32 packed entries"); delete A; return FFM_ERR_UNSUPPORTED; }
+    if ((long)nSl * 32 * 64 > 0x7fffffffL || N >= (1 << 27)) { ffm_set_error("mesh too large for int32 packed entries"); delete A; return FFM_ERR_UNSUPPORTED; }
     A->upTotal = upOff[nSl]; A->loTotal = loOff[nSl];
     A->h_upOff = upOff; A->h_loOff = loOff;
     A->upWidthUniform = (uniform >= 0) ? uniform : -1;
@@ -546,6 +549,7 @@ static int ldu_create_impl(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int 
             const int c = a.l[f];
             slot = (c == prev) ? slot + 1 : 0; prev = c;
             slotOfFace[f] = slot;
+            if (slot >= 16 && a.u[f] < nOwn) { ffm_set_error("a cell owns more than 16 faces towards owned cells (or they follow its faces towards ghost cells): not supported by the packed layout"); delete A; return FFM_ERR_UNSUPPORTED; }
             const int e = upOff[c >> 6] + slot * 64 + (c & 63);
             upNbr[e] = a.u[f]; faceSrc[e] = a.newToOldFace[f];
             A->h_callerToNative[a.newToOldFace[f]] = e;

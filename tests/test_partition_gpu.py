@@ -51,13 +51,23 @@ def test_partitioned_mesh_on_the_device(O, ffm, ctx, meshName, partitioner, worl
 def _run_ranks(mode, world, port, args, tmp, env=None):
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "part_rank.py"), mode, str(r), str(world), str(port)] + args + [tmp],
                               env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in range(world)]
+    outs = [None] * world
+    import time
+    t0 = time.time()
     try:
-        outs = [p.communicate(timeout=180) for p in procs]
+        # a rank that fails leaves the others waiting in a collective: stop all of them as soon as one has exited with an error
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs) or time.time() - t0 > 120:
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    assert [p.returncode for p in procs] == [0] * world, [o[1][-800:] for o in outs]
+        for r, p in enumerate(procs):
+            outs[r] = p.communicate()[1]
+    codes = [p.returncode for p in procs]
+    assert codes == [0] * world, (codes, [o[-700:] for o, c in zip(outs, codes) if c not in (0, -9)] or [o[-300:] for o in outs])
     return [dict(np.load(os.path.join(tmp, "rank%d.npz" % r))) for r in range(world)]
 
 
@@ -96,7 +106,7 @@ def test_gamg_on_a_decomposed_mesh(O, ffm, ctx, meshName, world, precond, asym):
     sharing cuda:0 through the host transport) against the oracle in OpenFOAM's processor-patch form (oracle/gamg_multi.py) on the same
     decomposition: the same hierarchy (cells per level on every rank), the same number of V-cycles, the same residuals and solution
     (the two forms add a row's interface terms at different places of its sum: rounding level)."""
-    args = [meshName, "graph", "GAMG", precond, str(asym)]
+    args = [meshName, "rcb", "GAMG", precond, str(asym)]          # (coordinate bisection: box-like sub-domains; a coarse cell may have at most 16 lower / upper neighbours in this library)
     port = 29400 + (os.getpid() % 150) + 11 * world + {"GS": 0, "DILU": 3, "SYMGS": 5, "DIC": 7}[precond]
     with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
         ref = _run_ranks("oracle", world, port, args, t1, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
