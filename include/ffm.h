@@ -587,7 +587,12 @@ int ffm_ctx_gamg_forward(const ffm_ctx *ctx);
  * mergeLevels 1, nCellsInCoarsestLevel 10, cacheAgglomeration true, smoother GaussSeidel for p_rgh / ph_rgh
  * (cases/wallFireSpread2D/system/fvSolution:36-60, cases/pyrolysis1D/system/fvSolution) and DILU for Ii
  * (cases/steckler/system/fvSolution:63-73).  Replaces OpenFOAM-dev's GAMGSolver::solve + pairGAMGAgglomeration (the
- * algorithm is restated with its sources in oracle/gamg.py).  One rank.
+ * algorithm is restated with its sources in oracle/gamg.py).  Decomposed meshes: `finest` is a ghost-cell matrix
+ * (ffm_ldu_create_ext + ffm_ldu_set_ghost_exchange; nCells = owned + ghost, the cut faces in lowerAddr / upperAddr); every rank
+ * agglomerates its own cells, the processor interfaces are agglomerated with them (coarse ghost cells, coarse cut faces, a ghost
+ * exchange per level), continueAgglomerating / normFactor / residuals / scale factors are global -- OpenFOAM's behaviour without a
+ * processorAgglomerator (oracle/gamg_multi.py; tests/test_partition_gpu.py::test_gamg_on_a_decomposed_mesh).  A mesh below
+ * nCellsInCoarsestLevel gets no coarse level: the solve then is the coarsest-level solver on the fine matrix.
  * ffm_gamg_create: the agglomeration of the mesh behind `finest` (created from the same lowerAddr / upperAddr), built once
  *   (cacheAgglomeration); faceWeights [nFaces] host, e.g. from ffm_gamg_face_area_pair_weights(Sf [nFaces][3]).
  * ffm_gamg_set_matrix_d: GAMGSolver::agglomerateMatrix for every level, from device coefficient arrays in the caller's
