@@ -102,3 +102,71 @@ def run_b1_demo(ffm, ctx, m, I, sub=None, part=None):
         res[k] = o[..., :nOwn]
     mesh.close(); A.close()
     return res, gcell[:nOwn].copy(), list(nit[:6])
+
+
+def run_b1_fvdom(ffm, ctx, m, T, Tb, E, emis, sub=None, part=None, nPhi=2, nTheta=2, maxIter=3, tolerance=0.0, scheme=0, a=0.3, IiTol=1e-12, nCalls=2):
+    """b1_fvdom of examples/b1_demo.C (the fvDOM handle with its iteration and grey-diffusive walls) on the whole mesh or on one rank's
+    sub-domain.  T, E: global cell fields; Tb, emis: per patch.  Returns (I [nRay][owned], G [owned], qin per owned boundary face as a
+    dict patch -> (global face positions, values)), the owned cells' global labels and the iterations of every call."""
+    N, F = m.nCells, m.nFaces
+    if sub is None:
+        gcell = np.arange(N); nOwn, nGhost = N, 0
+        l, u, gface, sign = m.l, m.u, np.arange(F), np.ones(F)
+        pmask = [np.ones(p.size, bool) for p in m.patches]
+        g2l = np.arange(N)
+    else:
+        gcell, nOwn, nGhost = sub.gcell, sub.nOwned, sub.nGhost
+        l, u, gface = sub.l, sub.u, sub.gface
+        sign = np.where(sub.flip.astype(bool), -1.0, 1.0)
+        pmask = [part[p.faceCells] == sub.rank for p in m.patches]
+        g2l = np.full(N, -1, np.int64); g2l[gcell[:nOwn]] = np.arange(nOwn)
+    nLoc = nOwn + nGhost
+    cOrd, fOrd = ffm.renumber_levels(nOwn, l, u, nGhost=nGhost)
+    l2, u2, oldToNew = ffm.hexmesh.apply_renumbering(nLoc, l, u, cOrd, fOrd)
+    A = ffm.lduMatrix(ctx, nOwn, l2, u2, nGhost=nGhost)
+    if sub is not None:
+        A.set_ghost_exchange(sub.nbrRank, sub.sendCount, oldToNew[sub.sendCells], sub.recvCount, tags=sub.tags, globalCells=N)
+    wgt = np.where(sign < 0, 1.0 - m.weights[gface], m.weights[gface])
+    patches = [(oldToNew[g2l[p.faceCells[k]]].astype(np.int32), p.Sf[k].T.copy(), p.deltaCoeffs[k]) for p, k in zip(m.patches, pmask)]
+    mesh = ffm.fvMesh(A, m.V[gcell][cOrd], m.C[gcell][cOrd].T.copy(), (m.Sf[gface] * sign[:, None])[fOrd].T.copy(), m.magSf[gface][fOrd],
+                      wgt[fOrd], m.deltaCoeffs[gface][fOrd], patches)
+    mesh.set_face_centres(m.Cf[gface][fOrd].T.copy())
+    B = sum(int(k.sum()) for k in pmask)
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    dp = C.POINTER(C.c_double)
+    h = lambda x: np.ascontiguousarray(x, np.float64)
+    cell = lambda x: h(np.asarray(x)[gcell][cOrd])
+    bnd = lambda lst: h(np.concatenate([np.asarray(x)[k] for x, k in zip(lst, pmask)])) if B else np.zeros(1)
+    solD = getattr(m, "solutionD", (1, 1, 1))
+    nRay = 4 * nPhi * nTheta if min(solD) > 0 else 4 * nPhi
+    Tc, Tbb, Ec, emb = cell(T), bnd(Tb), cell(E), bnd(emis)
+    IOut, GOut = np.empty((nRay, nLoc)), np.empty(nLoc)
+    qin, qem, qr = np.empty(max(B, 1)), np.empty(max(B, 1)), np.empty(max(B, 1))
+    iters, nSolves = (C.c_int * nCalls)(), C.c_int()
+    lib.b1_fvdom.restype = C.c_int
+    lib.b1_fvdom.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_double, C.c_int, C.c_double, C.c_double] + [dp] * 4 + [C.c_int] + [dp] * 5 + [C.POINTER(C.c_int)] * 2
+    os.environ["FFM_FOAM_QUIET"] = "1"
+    ctx._ready()
+    P = lambda x: x.ctypes.data_as(dp)
+    n = lib.b1_fvdom(ctx.h, A.h, mesh.h, sum(1 << d for d in range(3) if solD[d] < 0), nPhi, nTheta, maxIter, tolerance, scheme, a, IiTol,
+                     P(Tc), P(Tbb), P(Ec), P(emb), nCalls, P(IOut), P(GOut), P(qin), P(qem), P(qr), iters, C.byref(nSolves))
+    assert n == nRay
+    inv = np.empty(nLoc, np.int64); inv[cOrd] = np.arange(nLoc)
+    I = IOut[:, inv][:, :nOwn]; G = GOut[inv][:nOwn]
+    # qin per patch on this rank's faces: (positions inside the global patch, values)
+    qp, off = {}, 0
+    for p, k in zip(m.patches, pmask):
+        cnt = int(k.sum())
+        qp[p.name] = (np.nonzero(k)[0], qin[off:off + cnt].copy()); off += cnt
+    mesh.close(); A.close()
+    return (I, G, qp), gcell[:nOwn].copy(), list(iters)
+
+
+def fvdom_inputs(m):
+    """a flame-like temperature / emission field and wall emissivities for run_b1_fvdom"""
+    x, y = m.C[:, 0], m.C[:, 1]
+    T = 500.0 + 600.0 * np.exp(-((x - x.mean()) ** 2 + (y - 0.3 * y.max()) ** 2) / 0.05)
+    E = 2.0e5 * np.exp(-((x - x.mean()) ** 2 + (y - 0.3 * y.max()) ** 2) / 0.03)
+    Tb = [np.full(p.size, 900.0 if p.name == "inlet" else 320.0) for p in m.patches]
+    emis = [np.full(p.size, e) for p, e in zip(m.patches, (0.3, 0.85, 1.0, 0.55))]
+    return T, Tb, E, emis

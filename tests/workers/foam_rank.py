@@ -21,6 +21,14 @@ part = ffm.decompose.partition_rcb(m.C, world) if partitioner == "rcb" else ffm.
 sub = ffm.decompose.SubDomain(m.nCells, m.l, m.u, part, world, rank)
 ctx = ffm.Context(0)
 ctx.comm_init_host(rank, world, gloo.allreduce, gloo.exchange, gloo.exchange_var)
+if len(sys.argv) > 9 and sys.argv[9] == "fvdom":
+    # the fvDOM handle (iteration + grey-diffusive walls) on this rank's sub-domain: tests/test_foam_layer_decomposed_gpu.py
+    T, Tb, E, emis = foam_case.fvdom_inputs(m)
+    (I, G, qp), cells, its = foam_case.run_b1_fvdom(ffm, ctx, m, T, Tb, E, emis, sub=sub, part=part)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), cells=cells, I=I, G=G, its=np.array(its), nGhost=sub.nGhost,
+             **{"pos_" + k: v[0] for k, v in qp.items()}, **{"qin_" + k: v[1] for k, v in qp.items()})
+    ctx.close()
+    sys.exit(0)
 res, cells, nit = foam_case.run_b1_demo(ffm, ctx, m, foam_case.inputs(O, m), sub=sub, part=part)
 np.savez(os.path.join(outdir, "rank%d.npz" % rank), cells=cells, nit=np.array(nit), nGhost=sub.nGhost, **res)
 ctx.close()
