@@ -123,6 +123,10 @@ def lib():
         "ffm_debug_tile_trace": ([vp, C.c_void_p, C.c_int], C.c_int),
         "ffm_debug_set_sweep_ticket": ([vp, C.c_uint], C.c_int),
         "ffm_ldu_set_exchange_tags": ([vp, C.c_int, C.c_int, ip], C.c_int),
+        "ffm_field_binary": ([vp, C.c_int, C.c_long, dp, dp, dp], C.c_int),
+        "ffm_field_scalar": ([vp, C.c_int, C.c_long, dp, C.c_double, C.c_int, dp], C.c_int),
+        "ffm_field_unary": ([vp, C.c_int, C.c_long, dp, dp], C.c_int),
+        "ffm_field_eval": ([vp, C.c_long, C.c_int, C.POINTER(C.c_void_p), C.c_int, hp, C.c_int, C.POINTER(C.c_ushort), dp], C.c_int),
         "ffm_reduce_sum": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_min": ([vp, dp, C.c_long, hp], C.c_int),
         "ffm_reduce_max": ([vp, dp, C.c_long, hp], C.c_int),
@@ -336,6 +340,33 @@ class Context:
 
     def empty(self, n):
         return self.torch.empty(int(n), dtype=self.torch.float64, device=self.device)
+
+    # element-wise field algebra (the Foam layer's operators): op = FFM_OP_* / FFM_UN_* of include/ffm.h
+    def field_binary(self, op, a, b):
+        out = self.empty(a.numel()); self._ready()
+        _check(lib().ffm_field_binary(self.h, op, a.numel(), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr())), "ffm_field_binary")
+        return out
+
+    def field_scalar(self, op, a, s, scalarFirst=False):
+        out = self.empty(a.numel()); self._ready()
+        _check(lib().ffm_field_scalar(self.h, op, a.numel(), C.c_void_p(a.data_ptr()), float(s), int(scalarFirst), C.c_void_p(out.data_ptr())), "ffm_field_scalar")
+        return out
+
+    def field_unary(self, op, a):
+        out = self.empty(a.numel()); self._ready()
+        _check(lib().ffm_field_unary(self.h, op, a.numel(), C.c_void_p(a.data_ptr()), C.c_void_p(out.data_ptr())), "ffm_field_unary")
+        return out
+
+    def field_eval(self, arrays, imm, program):
+        """program: [("load", k) | ("imm", k) | ("binary", op) | ("unary", op)] in postfix order (ffm_field_eval)"""
+        kinds = {"load": 1, "imm": 2, "binary": 3, "unary": 4}
+        code = (C.c_ushort * len(program))(*[kinds[k] << 12 | int(a) for k, a in program])
+        ptrs = (C.c_void_p * max(len(arrays), 1))(*[t.data_ptr() for t in arrays])
+        im = np.ascontiguousarray(imm, np.float64) if len(imm) else np.zeros(1)
+        n = arrays[0].numel()
+        out = self.empty(n); self._ready()
+        _check(lib().ffm_field_eval(self.h, n, len(arrays), ptrs, len(imm), im.ctypes.data_as(C.POINTER(C.c_double)), len(program), code, C.c_void_p(out.data_ptr())), "ffm_field_eval")
+        return out
 
     def zeros(self, n):
         z = self.torch.zeros(int(n), dtype=self.torch.float64, device=self.device)

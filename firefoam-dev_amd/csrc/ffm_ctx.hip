@@ -277,5 +277,99 @@ extern "C" int ffm_field_unary(ffm_ctx *c, int op, long n, const double *a, doub
 extern "C" int ffm_field_fill(ffm_ctx *c, long n, double s, double *out)
 { return field_launch(c, n, [=] __device__(long) { return s; }, out); }
 
+// One element-wise expression in one pass: a postfix program over a four-deep operand stack.  Every operation is the one the
+// separate ffm_field_binary / _scalar / _unary call performs (same operand order, one rounding each; the library is compiled with
+// -ffp-contract=off), so the result is bit for bit that of the chain of calls -- without the intermediate arrays.  The operands of an
+// element are loaded up front (all loads in flight together), the program then runs on registers; its branches are wave-uniform.
+struct EvalProgram { int nInstr; const double *arr[FFM_EVAL_MAX_ARRAYS]; double imm[FFM_EVAL_MAX_IMM]; int code[FFM_EVAL_MAX_INSTR]; };
+__device__ __forceinline__ double eval_binary(int op, double a, double b)
+{
+    switch (op) {
+    case FFM_OP_ADD: return a + b;
+    case FFM_OP_SUB: return a - b;
+    case FFM_OP_MUL: return a * b;
+    case FFM_OP_DIV: return a / b;
+    case FFM_OP_MAX: return fmax(a, b);
+    case FFM_OP_MIN: return fmin(a, b);
+    default: return a < 0.0 ? b : a;          // FFM_OP_NEGSEL
+    }
+}
+__device__ __forceinline__ double eval_unary(int op, double a)
+{
+    switch (op) {
+    case FFM_UN_NEG: return -a;
+    case FFM_UN_SQR: return a * a;
+    case FFM_UN_MAG: return fabs(a);
+    case FFM_UN_SQRT: return sqrt(a);
+    default: return a >= 0.0 ? 1.0 : 0.0;     // FFM_UN_POS0
+    }
+}
+// NA = number of operand arrays (1..8): the loads and the operand selection are unrolled over it, nothing is indexed dynamically
+template <int NA>
+__global__ void __launch_bounds__(256) k_field_eval(long n, EvalProgram P, double *__restrict__ out)
+{
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 2 * stride) {
+        const long j = i + stride < n ? i + stride : i;          // the second element of this pass (the first again at the very end)
+#define EV_LD(k) const double x##k = k < NA ? P.arr[k < NA ? k : 0][i] : 0.0, y##k = k < NA ? P.arr[k < NA ? k : 0][j] : 0.0;
+        EV_LD(0) EV_LD(1) EV_LD(2) EV_LD(3) EV_LD(4) EV_LD(5) EV_LD(6) EV_LD(7)
+#undef EV_LD
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        for (int k = 0; k < P.nInstr; k++) {
+            const int c = P.code[k], kind = c >> 12, arg = c & 0xfff;
+            if (kind == FFM_EVAL_LOAD || kind == FFM_EVAL_IMM) {
+                s3 = s2; s2 = s1; s1 = s0; t3 = t2; t2 = t1; t1 = t0;
+                if (kind == FFM_EVAL_IMM) s0 = t0 = P.imm[arg];
+                else {
+                    s0 = x0; t0 = y0;
+#define EV_PICK(k) if (k < NA && arg == k) { s0 = x##k; t0 = y##k; }
+                    EV_PICK(1) EV_PICK(2) EV_PICK(3) EV_PICK(4) EV_PICK(5) EV_PICK(6) EV_PICK(7)
+#undef EV_PICK
+                }
+            } else if (kind == FFM_EVAL_BINARY) {
+                s0 = eval_binary(arg, s1, s0); t0 = eval_binary(arg, t1, t0);
+                s1 = s2; s2 = s3; t1 = t2; t2 = t3;
+            } else { s0 = eval_unary(arg, s0); t0 = eval_unary(arg, t0); }
+        }
+        out[i] = s0;
+        if (j != i) out[j] = t0;
+    }
+}
+extern "C" int ffm_field_eval(ffm_ctx *c, long n, int nArrays, const double *const *arrays, int nImm, const double *imm, int nInstr,
+                              const unsigned short *code, double *out)
+{
+    if (!c || n < 0 || (n && !out) || nArrays < 0 || nArrays > FFM_EVAL_MAX_ARRAYS || nImm < 0 || nImm > FFM_EVAL_MAX_IMM || nInstr < 1 ||
+        nInstr > FFM_EVAL_MAX_INSTR || !code || (nArrays && !arrays) || (nImm && !imm))
+        return FFM_ERR_ARG;
+    // the program must leave exactly one value and never hold more than four
+    int depth = 0;
+    for (int k = 0; k < nInstr; k++) {
+        const int kind = code[k] >> 12, arg = code[k] & 0xfff;
+        if (kind == FFM_EVAL_LOAD) { if (arg >= nArrays || (n && !arrays[arg])) return FFM_ERR_ARG; depth++; }
+        else if (kind == FFM_EVAL_IMM) { if (arg >= nImm) return FFM_ERR_ARG; depth++; }
+        else if (kind == FFM_EVAL_BINARY) { if (arg > FFM_OP_NEGSEL || depth < 2) return FFM_ERR_ARG; depth--; }
+        else if (kind == FFM_EVAL_UNARY) { if (arg > FFM_UN_POS0 || depth < 1) return FFM_ERR_ARG; }
+        else return FFM_ERR_ARG;
+        if (depth > 4) return FFM_ERR_ARG;
+    }
+    if (depth != 1) return FFM_ERR_ARG;
+    if (n == 0) return FFM_OK;
+    if (nArrays == 0) return FFM_ERR_ARG;          // a constant is ffm_field_fill
+    EvalProgram P{};
+    P.nInstr = nInstr;
+    for (int k = 0; k < nArrays; k++) P.arr[k] = arrays[k];
+    for (int k = 0; k < nImm; k++) P.imm[k] = imm[k];
+    for (int k = 0; k < nInstr; k++) P.code[k] = code[k];
+    FFM_HIP(hipSetDevice(c->device));
+    const int g = (int)std::max(1L, std::min((n + 511) / 512, (long)RED_BLOCKS));
+    switch (nArrays) {
+#define EV_CASE(NA) case NA: hipLaunchKernelGGL(k_field_eval<NA>, dim3(g), dim3(256), 0, c->stream, n, P, out); break;
+    EV_CASE(1) EV_CASE(2) EV_CASE(3) EV_CASE(4) EV_CASE(5) EV_CASE(6) EV_CASE(7) EV_CASE(8)
+#undef EV_CASE
+    }
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
 // debugging aid of the Foam layer (FFM_SYNC_RANGE): every queue of the device drained
 extern "C" int ffm_device_synchronize(void) { FFM_HIP(hipDeviceSynchronize()); return FFM_OK; }

@@ -481,7 +481,8 @@ __global__ void k_fvm_transport(MeshView q, double rDeltaT, const double *__rest
                 if (phi) { lo = lapSign < 0 ? lo - g : lo + g; up = lapSign < 0 ? up - g : up + g; }
                 else { lo = lapSign < 0 ? -g : g; up = lo; }
             }
-            upper[e] = up; lower[e] = lo;
+            if (upper) upper[e] = up;
+            if (lower) lower[e] = lo;
         }
         double d = rho ? rDeltaT * rho[c] * q.V[c] : 0.0;
         if (phi) d = rho ? d + dDiv : dDiv;
@@ -731,7 +732,8 @@ extern "C" int ffm_fvm_transport(ffm_mesh *m, double rDeltaT, const double *rho,
                                  const double *gamma_f, int laplacianSign, double *diag, double *upper, double *lower)
 {
     CHECK_M(m);
-    if (!diag || !upper || !lower || (phi_f && !w_f)) return FFM_ERR_ARG;
+    // upper == NULL: no face coefficients wanted (a pure ddt term has none); lower == NULL: a symmetric result (no convection), lower = upper
+    if (!diag || ((phi_f || gamma_f) && !upper) || (phi_f && (!w_f || !lower))) return FFM_ERR_ARG;
     FFM_DISPATCH_W(m->A->maxW, LAUNCH_CELLS(k_fvm_transport<W>, mview(m), rDeltaT, rho, phi_f, w_f, gamma_f, (double)laplacianSign, diag, upper, lower));
     DONE();
 }

@@ -96,6 +96,21 @@ int ffm_field_binary(ffm_ctx *ctx, int op, long n, const double *a_d, const doub
 int ffm_field_scalar(ffm_ctx *ctx, int op, long n, const double *a_d, double s, int scalarFirst, double *out_d);
 int ffm_field_unary(ffm_ctx *ctx, int op, long n, const double *a_d, double *out_d);
 int ffm_field_fill(ffm_ctx *ctx, long n, double s, double *out_d);
+/* One element-wise expression over fields in ONE pass (the Foam layer's lazily evaluated field algebra, include/ffmFoam.H: dField):
+ * a postfix program over an operand stack of depth <= 4.  code[k] = kind << 12 | arg:
+ *   FFM_EVAL_LOAD   arg = index into arrays[]          push arrays[arg][i]
+ *   FFM_EVAL_IMM    arg = index into imm[]             push imm[arg]
+ *   FFM_EVAL_BINARY arg = FFM_OP_*                     b = pop, a = pop, push (a op b)
+ *   FFM_EVAL_UNARY  arg = FFM_UN_*                     top = op(top)
+ * The value left on the stack is out[i]; at least one array (a constant is ffm_field_fill).  Every operation rounds as the separate ffm_field_binary / _scalar / _unary call does, so the
+ * result is bit for bit that of the chain of calls (OpenFOAM's tmp<Field> operator chains, e.g. solver/pEqn.H:5-12); `out` must not
+ * overlap an input.                                                                                                              */
+enum { FFM_EVAL_LOAD = 1, FFM_EVAL_IMM = 2, FFM_EVAL_BINARY = 3, FFM_EVAL_UNARY = 4 };
+#define FFM_EVAL_MAX_ARRAYS 8
+#define FFM_EVAL_MAX_IMM 8
+#define FFM_EVAL_MAX_INSTR 32
+int ffm_field_eval(ffm_ctx *ctx, long n, int nArrays, const double *const *arrays_d, int nImm, const double *imm, int nInstr,
+                   const unsigned short *code, double *out_d);
 
 /* ----------------------------------------------------------- lduAddressing */
 /* Replaces lduAddressing + lduMatrix construction
@@ -314,7 +329,8 @@ int ffm_fv_linear_upwind_correction(ffm_mesh *m, const double *phi_f, const doub
 
 /* ------------------------------------------------------- fvm:: (implicit)    */
 /* [fvm::ddt(rho,.)] + [fvm::div(phi,.)] (+/-) [fvm::laplacian(gamma,.)] in one
- * pass; absent terms: NULL.  Writes lduMatrix diag/upper/lower (native layout). */
+ * pass; absent terms: NULL.  Writes lduMatrix diag/upper/lower (native layout).
+ * upper = lower = NULL with a ddt term only (it has no face coefficients); lower = NULL without convection (symmetric: lower = upper). */
 int ffm_fvm_transport(ffm_mesh *m, double rDeltaT, const double *rho,
                       const double *phi_f, const double *w_f, const double *gamma_f,
                       int laplacianSign, double *diag, double *upper, double *lower);
