@@ -50,6 +50,7 @@ extern "C" int ffm_ctx_destroy(ffm_ctx *c)
     ffm_comm_finalize_i(c);
     ffm_ctx_trim(c);
     hipFree(c->scal_d); hipFree(c->partials_d); hipHostFree(c->scal_h);
+    if (c->multiScal_d) { hipFree(c->multiScal_d); hipHostFree(c->multiScal_h); }
     if (c->ownStream) hipStreamDestroy(c->stream);
     delete c;
     return FFM_OK;

@@ -62,6 +62,7 @@ struct ffm_ctx {
     double *scal_d = nullptr;      // [NSCAL]
     double *partials_d = nullptr;  // [4][RED_BLOCKS]
     double *scal_h = nullptr;      // pinned [NSCAL]
+    double *multiScal_d = nullptr, *multiScal_h = nullptr;      // [FFM_TILE_MAXSYS][NSCAL]: the lanes of ffm_solve_multi_d (allocated on first use)
     // communicator (RCCL); nRanks == 1 => serial
     int rank = 0, nRanks = 1;
     ncclComm *comm = nullptr;
@@ -311,6 +312,11 @@ int ffm_tile_amul_asym(ffm_ldu *A, const double *x, double *y);
 int ffm_tile_amul_pcg(ffm_ldu *A, const double *w, const double *pin, double *pout, double *psi, double *y, int dotSlot);
 int ffm_tile_pcg_bwd(ffm_ldu *A, const double *rA, double *wA, int slot);
 int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w);
+// several systems with the matrix's off-diagonal coefficients in one sweep (ffm_tile.hip: k_tile_m)
+#define FFM_TILE_MAXSYS 4
+bool ffm_tile_multi_usable(const ffm_ldu *A);
+int ffm_tile_precond_multi(ffm_ldu *A, int precond, int n, const double *const *rD, const double *const *r, double *const *w);
+int ffm_tile_calc_rD_multi(ffm_ldu *A, int n, const double *const *diag, double *const *D);
 int ffm_tile_check_abort(ffm_ldu *A);
 int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b);
 int ffm_halo_exchange(ffm_ldu *A, const double *x);

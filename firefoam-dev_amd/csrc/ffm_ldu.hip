@@ -670,7 +670,7 @@ extern "C" int ffm_ldu_set_global_cells(ffm_ldu *A, long g) { if (!A || g < A->n
 
 int ffm_ldu_work(ffm_ldu *A, int idx, double **out)
 {
-    if (idx < 0 || idx > 31) return FFM_ERR_ARG;
+    if (idx < 0 || idx > 63) return FFM_ERR_ARG;          // 32 ..: the lanes of ffm_solve_multi_d
     if ((int)A->work.size() <= idx) A->work.resize(idx + 1, nullptr);
     if (!A->work[idx]) FFM_HIP(hipMalloc((void **)&A->work[idx], sizeof(double) * (size_t)std::max(A->nCells, 1)));
     *out = A->work[idx];

@@ -1194,6 +1194,157 @@ extern "C" int ffm_solve_d(ffm_ldu *A, int solver, int precond, double tol, doub
     return FFM_OK;
 }
 
+// ------------------------------------------------------------------ several systems with common off-diagonals ---
+// fvMatrix::solveSegregated of a vector equation and the species loop under a multivariateSelection scheme solve systems that differ in
+// the diagonal and the right-hand side only.  PBiCGStab + DILU (or DIC) of nSys <= FFM_TILE_MAXSYS such systems run in lock step: every
+// system keeps its own solver state (scalars, work vectors, reciprocal diagonal) and goes through exactly the operations of pbicgstab()
+// above in the same order -- its numbers and its iteration count are those of a solve of its own -- but the preconditioner sweeps and
+// calcReciprocalD of the systems still iterating are ONE tiled sweep each (ffm_tile.hip: k_tile_m), and the host reads all residuals
+// back with one synchronisation per half iteration.
+namespace {
+struct Lane {
+    const double *diag, *source; double *psi; ffm_perf *perf;
+    double *scal_d, *scal_h;
+    double *rD, *pA, *yA, *rA, *AyA, *sA, *zA, *tA, *rA0;
+    bool active;
+};
+struct LaneGuard {          // the context's scalar block and the matrix's diagonal / reciprocal diagonal are switched per lane
+    ffm_ldu *A; double *scal_d, *scal_h, *diag, *rD; int rDKind; unsigned long rDEpoch;
+    explicit LaneGuard(ffm_ldu *a) : A(a), scal_d(a->ctx->scal_d), scal_h(a->ctx->scal_h), diag(a->diag), rD(a->rD), rDKind(a->rDKind), rDEpoch(a->rDEpoch) {}
+    void use(const Lane &l) { A->ctx->scal_d = l.scal_d; A->ctx->scal_h = l.scal_h; A->diag = const_cast<double *>(l.diag); A->rD = l.rD; }
+    ~LaneGuard() { A->ctx->scal_d = scal_d; A->ctx->scal_h = scal_h; A->diag = diag; A->rD = rD; A->rDKind = -1; A->rDEpoch = ~0ul; }
+};
+}
+static int read_lane_scalars(ffm_ctx *c, Lane *L, int n)
+{
+    for (int i = 0; i < n; i++) if (L[i].active)
+        FFM_HIP(hipMemcpyAsync(L[i].scal_h, L[i].scal_d, sizeof(double) * NSCAL, hipMemcpyDeviceToHost, c->stream));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    return FFM_OK;
+}
+static int precond_lanes(ffm_ldu *A, int precond, Lane *L, int n, double *Lane::*in, double *Lane::*out, LaneGuard &G)
+{
+    const double *rD[FFM_TILE_MAXSYS], *r[FFM_TILE_MAXSYS]; double *w[FFM_TILE_MAXSYS]; int m = 0, only = -1;
+    for (int i = 0; i < n; i++) if (L[i].active) { rD[m] = L[i].rD; r[m] = L[i].*in; w[m] = L[i].*out; m++; only = i; }
+    if (m >= 2) return ffm_tile_precond_multi(A, precond, m, rD, r, w);
+    if (m == 1) { G.use(L[only]); return ffm_precond_apply_i(A, precond, false, L[only].*in, L[only].*out); }
+    return FFM_OK;
+}
+static int pbicgstab_multi(ffm_ldu *A, int precond, const Controls &k, int n, Lane *L)
+{
+    ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned; const int g = sgrid(N);
+    LaneGuard G(A);
+    for (int i = 0; i < n; i++) {
+        Lane &l = L[i]; G.use(l);
+        FFM_TRY(scalar_op(c, OP_RESET));
+        FFM_TRY(ffm_k_spmv_sumA(A, l.psi, l.yA, l.pA));
+        hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, l.rA, l.source, l.yA);
+        FFM_TRY(norm_and_initial(A, l.psi, l.source, l.yA, l.pA, l.rA, l.perf));          // (reads this lane's scalars back)
+        l.active = k.minIter > 0 || !check_convergence(l.perf, k);
+        if (l.active) hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, s, N, l.rA0, l.rA);
+    }
+    {   // calcReciprocalD of the systems that iterate
+        const double *dg[FFM_TILE_MAXSYS]; double *D[FFM_TILE_MAXSYS]; int m = 0, only = -1;
+        for (int i = 0; i < n; i++) if (L[i].active) { dg[m] = L[i].diag; D[m] = L[i].rD; m++; only = i; }
+        if (m >= 2) {
+            FFM_TRY(ffm_tile_calc_rD_multi(A, m, dg, D));
+            for (int j = 0; j < m; j++) hipLaunchKernelGGL(k_recip, dim3(g), dim3(256), 0, s, N, D[j], (const double *)D[j]);
+        } else if (m == 1) { G.use(L[only]); A->rDKind = -1; FFM_TRY(ffm_precond_setup_i(A, precond)); }
+        A->rDKind = precond; A->rDEpoch = A->coeffEpoch;         // every lane's rD is current: the single-lane calls below must not redo it
+    }
+    for (;;) {
+        bool any = false;
+        for (int i = 0; i < n; i++) if (L[i].active) {
+            Lane &l = L[i]; G.use(l); any = true;
+            FFM_TRY(ffm_k_dot(c, l.rA0, l.rA, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_BS_RHO, 1, 0.0, l.perf->nIterations));
+            hipLaunchKernelGGL(k_bs_p, dim3(g), dim3(256), 0, s, N, l.pA, l.rA, l.AyA, c->scal_d, l.perf->nIterations == 0 ? 1 : 0);
+        }
+        if (!any) break;
+        FFM_TRY(precond_lanes(A, precond, L, n, &Lane::pA, &Lane::yA, G));
+        for (int i = 0; i < n; i++) if (L[i].active) {
+            Lane &l = L[i]; G.use(l);
+            FFM_TRY(ffm_k_spmv(A, l.yA, l.AyA, false));
+            FFM_TRY(ffm_k_dot(c, l.rA0, l.AyA, N, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_BS_ALPHA));
+            hipLaunchKernelGGL(k_bs_s, dim3(g), dim3(256), 0, s, N, l.sA, l.rA, l.AyA, c->scal_d, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_RES));
+        }
+        FFM_TRY(read_lane_scalars(c, L, n));
+        for (int i = 0; i < n; i++) if (L[i].active) {
+            Lane &l = L[i]; G.use(l);
+            if (l.scal_h[S_SING] != 0.0) { l.perf->singular = 1; l.active = false; continue; }
+            l.perf->finalResidual = l.scal_h[S_RES];
+            if (check_convergence(l.perf, k)) {
+                hipLaunchKernelGGL(k_axpy_alpha, dim3(g), dim3(256), 0, s, N, l.psi, l.yA, c->scal_d);
+                l.perf->nIterations++;
+                l.active = false;
+            }
+        }
+        FFM_TRY(precond_lanes(A, precond, L, n, &Lane::sA, &Lane::zA, G));
+        for (int i = 0; i < n; i++) if (L[i].active) {
+            Lane &l = L[i]; G.use(l);
+            FFM_TRY(ffm_k_spmv(A, l.zA, l.tA, false));
+            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, s, N, l.tA, l.sA, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0, 2));
+            FFM_TRY(finish_dot(c, OP_BS_OMEGA, 2));
+            hipLaunchKernelGGL(k_bs_xr, dim3(g), dim3(256), 0, s, N, l.psi, l.rA, l.yA, l.zA, l.sA, l.tA, c->scal_d, c->partials_d);
+            FFM_TRY(partial_sum_to(c, g, S_TMP0));
+            FFM_TRY(finish_dot(c, OP_RES));
+        }
+        FFM_TRY(read_lane_scalars(c, L, n));
+        for (int i = 0; i < n; i++) if (L[i].active) {
+            Lane &l = L[i];
+            l.perf->finalResidual = l.scal_h[S_RES];
+            l.active = (++l.perf->nIterations < k.maxIter && !check_convergence(l.perf, k)) || l.perf->nIterations < k.minIter;
+        }
+    }
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+extern "C" int ffm_solve_multi_d(ffm_ldu *A, int nSys, int solver, int precond, double tol, double relTol, int minIter, int maxIter,
+                                 const double *const *diag_d, const double *upper_d, const double *lower_d, double *const *psi_d,
+                                 const double *const *source_d, ffm_perf *out)
+{
+    if (!A || nSys < 1 || !diag_d || !psi_d || !source_d || !out) { ffm_set_error("ffm_solve_multi_d: null argument"); return FFM_ERR_ARG; }
+    for (int i = 0; i < nSys; i++) if (!diag_d[i] || !psi_d[i] || !source_d[i]) { ffm_set_error("ffm_solve_multi_d: null array"); return FFM_ERR_ARG; }
+    FFM_HIP(hipSetDevice(A->ctx->device));
+    Controls k{tol, relTol, minIter, maxIter, 1};
+    const bool batched = nSys >= 2 && nSys <= FFM_TILE_MAXSYS && solver == FFM_PBICGSTAB && (precond == FFM_DILU || precond == FFM_DIC) &&
+                         A->identity && A->sweepMode == 2 && ffm_tile_multi_usable(A) && A->ifaces.empty();
+    if (!batched) {          // one after the other (any solver, any matrix)
+        for (int i = 0; i < nSys; i++) {
+            FFM_TRY(ffm_ldu_bind_coeffs_native_d(A, diag_d[i], upper_d, lower_d, i > 0));
+            FFM_TRY(ffm_solve_d(A, solver, precond, tol, relTol, minIter, maxIter, 1, psi_d[i], source_d[i], &out[i]));
+        }
+        return FFM_OK;
+    }
+    FFM_TRY(ffm_ldu_bind_coeffs_native_d(A, diag_d[0], upper_d, lower_d, 0));
+    if (precond == FFM_DIC && !A->symmetric) { ffm_set_error("DIC needs a symmetric matrix"); return FFM_ERR_UNSUPPORTED; }
+    ffm_ctx *c = A->ctx;
+    if (!c->multiScal_d) {
+        FFM_HIP(hipMalloc((void **)&c->multiScal_d, sizeof(double) * NSCAL * FFM_TILE_MAXSYS));
+        FFM_HIP(hipHostMalloc((void **)&c->multiScal_h, sizeof(double) * NSCAL * FFM_TILE_MAXSYS, hipHostMallocDefault));
+        FFM_HIP(hipMemsetAsync(c->multiScal_d, 0, sizeof(double) * NSCAL * FFM_TILE_MAXSYS, c->stream));
+    }
+    Lane L[FFM_TILE_MAXSYS];
+    for (int i = 0; i < nSys; i++) {
+        Lane &l = L[i];
+        memset(&out[i], 0, sizeof(ffm_perf));
+        l.diag = diag_d[i]; l.source = source_d[i]; l.psi = psi_d[i]; l.perf = &out[i]; l.active = false;
+        l.scal_d = c->multiScal_d + (size_t)i * NSCAL; l.scal_h = c->multiScal_h + (size_t)i * NSCAL;
+        double **w[9] = {&l.rD, &l.pA, &l.yA, &l.rA, &l.AyA, &l.sA, &l.zA, &l.tA, &l.rA0};
+        if (i == 0) { l.rD = A->rD; for (int j = 1; j <= 8; j++) FFM_TRY(ffm_ldu_work(A, j, w[j])); }
+        else for (int j = 0; j < 9; j++) FFM_TRY(ffm_ldu_work(A, 32 + 9 * (i - 1) + j, w[j]));
+    }
+    FFM_TRY(pbicgstab_multi(A, precond, k, nSys, L));
+    FFM_HIP(hipStreamSynchronize(c->stream));
+    FFM_TRY(ffm_tile_check_abort(A));
+    return FFM_OK;
+}
+
 extern "C" int ffm_solve(ffm_ldu *A, int solver, int precond, double tol, double relTol, int minIter, int maxIter,
                          int nSweeps, double *psi, const double *source, ffm_perf *out)
 {

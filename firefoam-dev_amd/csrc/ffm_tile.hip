@@ -65,6 +65,7 @@ struct ffm_tile_plan {
     TileDir f, b;
     double *mailAll = nullptr;
     long nMail = 0;
+    double *mailMulti = nullptr;    // [FFM_TILE_MAXSYS][nMail]: the mailboxes of the multi-system sweeps (k_tile_m), allocated on first use
     unsigned long long *trace = nullptr;    // diagnostics (ffm_debug_tile_trace): per group {start, first entry done, end, re-loads} of the last launch
     // ---- general backward order: when the backward dependency order inside a group is not the mirror image of the forward
     // one (baffles, unstructured meshes), the backward sweep runs in "position space": position q holds cell cellOf[q]
@@ -121,7 +122,7 @@ void ffm_tile_free(ffm_ldu *A)
 {
     if (!A->tile) return;
     free_dir(A->tile->f); free_dir(A->tile->b);
-    hipFree(A->tile->mailAll); hipFree(A->tile->trace); hipFree(A->tile->wp); hipFree(A->tile->rDp);
+    hipFree(A->tile->mailAll); hipFree(A->tile->mailMulti); hipFree(A->tile->trace); hipFree(A->tile->wp); hipFree(A->tile->rDp);
     hipFree(A->tile->arec); hipFree(A->tile->acode); hipFree(A->tile->aext); hipFree(A->tile->aseg); hipFree(A->tile->amulPartials);
     hipFree(A->tile->fvSeg); hipFree(A->tile->upSrcCell); hipFree(A->tile->upNbrCell); hipFree(A->tile->upCoefCell); hipFree(A->tile->diagp);
     hipFree(A->tile->tailCell); hipFree(A->tile->tailStart); hipFree(A->tile->tailFace); hipFree(A->tile->tailNbr);
@@ -892,6 +893,207 @@ int ffm_tile_calc_rD(ffm_ldu *A)
     tile_fill(A, T->f.mail, (long)T->f.nPub + 1);
     hipLaunchKernelGGL((k_tile<TM_RD, false>), dim3(T->G), dim3(T_THREADS + 64), 0, A->ctx->stream, tview(A, T->f), cu, cl, (const double *)A->diag,
                        (const double *)nullptr, A->rD, (double *)nullptr);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
+// ------------------------------------------------------------------ several systems in one sweep ---
+// The segregated solves of a vector equation (fvMatrix::solveSegregated: the components of U differ in the boundary diagonal and the
+// source only) and the species equations under a multivariateSelection scheme (solver/YEEqn.H:43-60: one set of face weights, one
+// diffusivity) have the SAME off-diagonal coefficients.  k_tile_m sweeps NF such systems at once: neighbour codes and coefficients are
+// read once, every system has its own ring in LDS, its own mailboxes and its own rD / right-hand side / result; a level costs one
+// barrier for all of them and their dependency chains interleave.  Per system the arithmetic is k_tile's, operation for operation.
+constexpr int TM_PF = 4;            // read-ahead of the multi-system sweeps (NF systems' operands per slot)
+static_assert(T_PM < TM_PF, "read-ahead distances");
+template <int NF> struct TileMulti { const double *dg[NF]; const double *r[NF]; double *w[NF]; double *mail[NF]; };
+
+template <int MODE, int NF>
+__global__ __launch_bounds__(T_THREADS + 64) void k_tile_m(TileView t, const double *__restrict__ ca, const double *__restrict__ cb, TileMulti<NF> m)
+{
+    static_assert(MODE == TM_FWD || MODE == TM_BWD || MODE == TM_RD, "DILU / DIC application and calcReciprocalD");
+    constexpr bool ASC = MODE != TM_BWD;
+    constexpr bool TWO = MODE == TM_RD;
+    constexpr int W = T_W, PF = TM_PF;
+    __shared__ double ring[NF][T_LDS];
+    __shared__ int4 shRec[4];
+    __shared__ int shG;
+    __shared__ int shAbort;
+    const unsigned tid = threadIdx.x;
+    if (tid == 0) {
+        const unsigned tk = atomicAdd(&t.ticket[0], 1u);
+        const int k = (int)(tk % (unsigned)t.G);
+        shG = ASC ? k : t.G - 1 - k; shAbort = 0;
+    }
+    __syncthreads();
+    const int g = __builtin_amdgcn_readfirstlane(shG);
+    const unsigned gs = (unsigned)__builtin_amdgcn_readfirstlane(t.grpCell[g]);
+    const int e0 = __builtin_amdgcn_readfirstlane(t.grpEnt[g]), e1 = __builtin_amdgcn_readfirstlane(t.grpEnt[g + 1]);
+    if (e0 >= e1) return;
+
+    if (tid >= (unsigned)T_THREADS) {
+        // ------------------------------------------------------------------ mail wave (as in k_tile, NF values per external)
+        const unsigned lane = tid - (unsigned)T_THREADS;
+        int4 qrec[PF];
+        unsigned qne[PF], qxi[PF];
+        double qxv[PF][NF];
+#define Q_REC(k, e) { qrec[k] = t.rec[min((e), e1)]; }
+#define Q_IDX(k, e) { const int4 R_ = qrec[k]; qne[k] = ((e) < e1) ? ((unsigned)R_.y >> 16) : 0u; qxi[k] = (unsigned)t.extSrc[(unsigned)R_.w + (lane < qne[k] ? lane : 0u)]; }
+#define Q_MAIL(k) { _Pragma("unroll") for (int i_ = 0; i_ < NF; i_++) qxv[k][i_] = t_ld(&m.mail[i_][lane < qne[k] ? qxi[k] : 0u]); }
+#define Q_PUT(k, e) {                                                                                    \
+        if (lane < qne[k]) {                                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < NF; i_++) {                                           \
+                double v_ = qxv[k][i_];                                                                   \
+                if (__builtin_expect(t_pending(v_), 0)) v_ = t_wait_value<false>(&m.mail[i_][qxi[k]], t.ticket, &shAbort, nullptr); \
+                ring[i_][T_RING + (((e) & 1) * T_XMAX) + lane] = v_;                                      \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#pragma unroll
+        for (int k = 0; k < PF; k++) Q_REC(k, e0 + k);
+#pragma unroll
+        for (int k = 0; k < PF; k++) { Q_IDX(k, e0 + k); Q_REC(k, e0 + PF + k); }
+#pragma unroll
+        for (int k = 0; k < T_PM; k++) Q_MAIL(k);
+        Q_PUT(0, e0);
+        if (lane == 0) shRec[(e0 + PF) & 3] = qrec[0];
+        t_barrier();
+        for (int e = e0; e < e1; e += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int ee = e + k;
+                Q_PUT((k + 1) % PF, ee + 1);
+                if (lane == 0) shRec[(ee + 1 + PF) & 3] = qrec[(k + 1) % PF];
+                Q_IDX(k, ee + PF);
+                Q_REC(k, ee + 2 * PF);
+                Q_MAIL((k + T_PM) % PF);
+                t_barrier();
+            }
+        }
+#undef Q_REC
+#undef Q_IDX
+#undef Q_MAIL
+#undef Q_PUT
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    unsigned pc[PF], ppb[PF];
+    bool pok[PF];
+    uint2 pq[PF];
+    double pa[PF][W], pb[PF][TWO ? W : 1], pd[PF][NF], pv[PF][TWO ? 1 : NF];
+#define TM_FETCH(k, e, R_) {                                                                            \
+        const unsigned cnt_ = ((e) < e1) ? ((unsigned)R_.y & 0xFFFFu) : 0u;                              \
+        const bool ok_ = tid < cnt_;                                                                     \
+        const unsigned cc_ = ok_ ? (ASC ? (unsigned)R_.x + tid : (unsigned)R_.x + cnt_ - 1u - tid) : gs; \
+        const unsigned o8_ = cc_ * 8u, o24_ = cc_ * 24u;                                                 \
+        pq[k] = *(const uint2 *)((const char *)t.code + o8_);                                            \
+        { const T3 v_ = *(const T3 *)((const char *)ca + o24_); pa[k][0] = v_.a; pa[k][1] = v_.b; pa[k][2] = v_.c; }     \
+        if (TWO) { const T3 v_ = *(const T3 *)((const char *)cb + o24_); pb[k][0] = v_.a; pb[k][TWO ? 1 : 0] = v_.b; pb[k][TWO ? 2 : 0] = v_.c; } \
+        _Pragma("unroll") for (int i_ = 0; i_ < NF; i_++) {                                              \
+            pd[k][i_] = *(const double *)((const char *)m.dg[i_] + o8_);                                 \
+            if (!TWO) pv[k][TWO ? 0 : i_] = *(const double *)((const char *)(MODE == TM_FWD ? m.r[i_] : (const double *)m.w[i_]) + o8_); \
+        }                                                                                                \
+        pc[k] = cc_; pok[k] = ok_; ppb[k] = (unsigned)R_.z;                                              \
+    }
+#pragma unroll
+    for (int k = 0; k < PF; k++) { const int4 R0 = t.rec[min(e0 + k, e1)]; TM_FETCH(k, e0 + k, R0); }
+    t_barrier();
+    for (int e = e0; e < e1; e += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            const int ee = e + k;
+            const int4 Rn = shRec[(ee + PF) & 3];
+            {
+                const unsigned c = pc[k];
+                const unsigned cd[4] = {pq[k].x & 0xFFFFu, pq[k].x >> 16, pq[k].y & 0xFFFFu, pq[k].y >> 16};
+                unsigned sl[W];
+#pragma unroll
+                for (int s = 0; s < W; s++) sl[s] = min(cd[s], (unsigned)(T_LDS - 1));
+                double val[NF];
+#pragma unroll
+                for (int i = 0; i < NF; i++) {
+                    const double d = pd[k][i];
+                    double v;
+                    if (MODE == TM_FWD) {
+                        v = d * pv[k][TWO ? 0 : i];
+#pragma unroll
+                        for (int s = 0; s < W; s++) { const double nv = v - d * pa[k][s] * ring[i][sl[s]]; v = (cd[s] != T_NONE) ? nv : v; }
+                    } else if (MODE == TM_BWD) {
+                        v = pv[k][TWO ? 0 : i];
+#pragma unroll
+                        for (int s = W - 1; s >= 0; s--) { const double nv = v - d * pa[k][s] * ring[i][sl[s]]; v = (cd[s] != T_NONE) ? nv : v; }
+                    } else {
+                        v = d;
+#pragma unroll
+                        for (int s = 0; s < W; s++) { const double nv = v - pa[k][s] * pb[k][TWO ? s : 0] / ring[i][sl[s]]; v = (cd[s] != T_NONE) ? nv : v; }
+                    }
+                    val[i] = v;
+                }
+                if (pok[k]) {
+#pragma unroll
+                    for (int i = 0; i < NF; i++) {
+                        *(double *)((char *)m.w[i] + c * 8u) = val[i];
+                        ring[i][(c - gs) & (unsigned)(T_RING - 1)] = val[i];
+                        if (cd[3] != T_NONE) t_st(&m.mail[i][ppb[k] + cd[3]], val[i]);
+                    }
+                }
+            }
+            TM_FETCH(k, ee + PF, Rn);
+            t_barrier();
+        }
+    }
+#undef TM_FETCH
+}
+
+
+bool ffm_tile_multi_usable(const ffm_ldu *A)
+{
+    const char *e = getenv("FFM_NO_MULTI_SWEEP");
+    return !(e && atoi(e) != 0) && ffm_tile_usable(A) && A->tile->mirror && !A->tile->trace;
+}
+static int tile_multi_mail(ffm_ldu *A)
+{
+    ffm_tile_plan *T = A->tile;
+    if (!T->mailMulti) FFM_HIP(hipMalloc((void **)&T->mailMulti, sizeof(double) * (size_t)FFM_TILE_MAXSYS * (size_t)T->nMail));
+    return FFM_OK;
+}
+template <int MODE, int NF>
+static void tile_multi_launch(ffm_ldu *A, const TileDir &d, const double *ca, const double *cb, const double *const *dg, const double *const *r, double *const *w)
+{
+    ffm_tile_plan *T = A->tile;
+    TileMulti<NF> m;
+    for (int i = 0; i < NF; i++) { m.dg[i] = dg[i]; m.r[i] = r ? r[i] : nullptr; m.w[i] = w[i]; m.mail[i] = T->mailMulti + (size_t)i * T->nMail + (d.mail - T->mailAll); }
+    hipLaunchKernelGGL((k_tile_m<MODE, NF>), dim3(T->G), dim3(T_THREADS + 64), 0, A->ctx->stream, tview(A, d), ca, cb, m);
+}
+#define TILE_MULTI(MODE, n, ...) switch (n) { case 2: tile_multi_launch<MODE, 2>(__VA_ARGS__); break; case 3: tile_multi_launch<MODE, 3>(__VA_ARGS__); break; \
+                                             default: tile_multi_launch<MODE, 4>(__VA_ARGS__); break; }
+// DILU / DIC application (not transposed) of n = 2 .. FFM_TILE_MAXSYS systems with the matrix's off-diagonal coefficients and their
+// own reciprocal diagonals: w[i] = precondition(r[i]).  Mirror-ordered tile plans (ffm_tile_multi_usable).
+int ffm_tile_precond_multi(ffm_ldu *A, int precond, int n, const double *const *rD, const double *const *r, double *const *w)
+{
+    ffm_tile_plan *T = A->tile;
+    if (n < 2 || n > FFM_TILE_MAXSYS || !ffm_tile_multi_usable(A)) return FFM_ERR_ARG;
+    const double *cf, *cb;
+    FFM_TRY(tile_coef(A, T->f, precond == FFM_DIC, &cf));
+    FFM_TRY(tile_coef(A, T->b, true, &cb));
+    FFM_TRY(tile_multi_mail(A));
+    tile_fill(A, T->mailMulti, (long)n * T->nMail);
+    TILE_MULTI(TM_FWD, n, A, T->f, cf, nullptr, rD, r, w);
+    TILE_MULTI(TM_BWD, n, A, T->b, cb, nullptr, rD, nullptr, w);
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+// D[i] = diag[i] - sum upper*lower/D[i][l] in face order (un-inverted) for n systems
+int ffm_tile_calc_rD_multi(ffm_ldu *A, int n, const double *const *diag, double *const *D)
+{
+    ffm_tile_plan *T = A->tile;
+    if (n < 2 || n > FFM_TILE_MAXSYS || !ffm_tile_multi_usable(A)) return FFM_ERR_ARG;
+    const double *cu, *cl;
+    FFM_TRY(tile_coef(A, T->f, true, &cu));
+    if (A->lower == A->upper) cl = cu; else FFM_TRY(tile_coef(A, T->f, false, &cl));
+    FFM_TRY(tile_multi_mail(A));
+    tile_fill(A, T->mailMulti, (long)n * T->nMail);
+    TILE_MULTI(TM_RD, n, A, T->f, cu, cl, diag, nullptr, D);
     FFM_HIP(hipGetLastError());
     return FFM_OK;
 }
