@@ -118,6 +118,8 @@ def lib():
                          C.POINTER(Perf)], C.c_int),
         "ffm_solve": ([vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, hp, hp,
                        C.POINTER(Perf)], C.c_int),
+        "ffm_solve_multi_d": ([vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_void_p), dp, dp,
+                               C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(Perf)], C.c_int),
         "ffm_bench_spmv": ([vp, dp, dp, C.c_int, hp], C.c_int),
         "ffm_bench_precond": ([vp, C.c_int, dp, dp, C.c_int, hp], C.c_int),
         "ffm_debug_tile_trace": ([vp, C.c_void_p, C.c_int], C.c_int),
@@ -493,6 +495,17 @@ class lduMatrix:
         """0 level-scheduled, 2 tiled wavefront"""
         return lib().ffm_ldu_sweep_mode(self.h)
 
+    @property
+    def nNative(self):
+        """entries of a face array in the library's native layout (sliced owner-ELL incl. padding)"""
+        return lib().ffm_ldu_n_native_faces(self.h)
+
+    def face_map(self):
+        """callerToNative[f]: the native index of the caller's face f (ffm_ldu_get_face_map; native cell order only)"""
+        m = np.empty(self.nFaces, np.int32)
+        _check(lib().ffm_ldu_get_face_map(self.h, _ip(m)), "ffm_ldu_get_face_map")
+        return m
+
     def bind_coeffs_native(self, diag, upper, lower=None):
         """zero-copy: the matrix reads device tensors in the library's native layout (diag [nCells], upper / lower [nNative])
         until the next set / bind call; the caller keeps them alive (ffm_ldu_bind_coeffs_native_d)"""
@@ -605,6 +618,19 @@ class lduMatrix:
         _check(lib().ffm_solve_d(self.h, SOLVERS[solver], p, tolerance, relTol, minIter, maxIter, nSweeps,
                                  C.c_void_p(psi.data_ptr()), C.c_void_p(source.data_ptr()), C.byref(perf)), "ffm_solve_d")
         return perf.as_dict()
+
+    def solve_multi(self, diags, upper, lower, psis, sources, solver="PBiCGStab", preconditioner="DILU", tolerance=1e-6, relTol=0.0,
+                    minIter=0, maxIter=1000):
+        """systems with common off-diagonals (native layout, ffm_solve_multi_d): psis updated in place, a perf dict per system"""
+        self.ctx._ready()
+        n = len(diags)
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        perf = (Perf * n)()
+        self._bound = (diags, upper, lower)
+        _check(lib().ffm_solve_multi_d(self.h, n, SOLVERS[solver], PRECONDS[preconditioner], tolerance, relTol, minIter, maxIter, arr(diags),
+                                       C.c_void_p(upper.data_ptr()), None if lower is None else C.c_void_p(lower.data_ptr()), arr(psis), arr(sources), perf),
+               "ffm_solve_multi_d")
+        return [perf[i].as_dict() for i in range(n)]
 
     def solve_host(self, psi, source, solver="PCG", preconditioner="DIC", smoother=None, tolerance=1e-6,
                    relTol=0.0, minIter=0, maxIter=1000, nSweeps=1):

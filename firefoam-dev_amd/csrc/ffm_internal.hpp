@@ -317,6 +317,7 @@ int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, d
 bool ffm_tile_multi_usable(const ffm_ldu *A);
 int ffm_tile_precond_multi(ffm_ldu *A, int precond, int n, const double *const *rD, const double *const *r, double *const *w);
 int ffm_tile_calc_rD_multi(ffm_ldu *A, int n, const double *const *diag, double *const *D);
+int ffm_k_spmv_multi(ffm_ldu *A, int n, const double *const *diag, const double *const *x, double *const *y, double *const *sumA);
 int ffm_tile_check_abort(ffm_ldu *A);
 int ffm_gs_smooth_i(ffm_ldu *A, bool sym, int nSweeps, double *psi, const double *b);
 int ffm_halo_exchange(ffm_ldu *A, const double *x);

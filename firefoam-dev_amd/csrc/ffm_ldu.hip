@@ -902,6 +902,58 @@ int ffm_k_spmv(ffm_ldu *A, const double *x, double *y, bool transpose)
     return FFM_OK;
 }
 
+// y_i = A_i x_i for NF matrices with the off-diagonal coefficients upper / lower and their own diagonals (the lanes of
+// ffm_solve_multi_d): addressing and coefficients are read once per row; per system the row sum is k_rows<0> / <3>, term for term.
+template <int NF> struct RowsMulti { const double *diag[NF], *x[NF]; double *y[NF], *sum[NF]; };
+template <int MODE, int NF, int W>
+__global__ __launch_bounds__(256) void k_rows_m(LduView v, const double *__restrict__ upper, const double *__restrict__ lower, RowsMulti<NF> m)
+{
+    for (int it = blockIdx.x; it < v.nSched; it += gridDim.x) {
+        const int chunk = v.sched[it];
+        const int c = chunk * 256 + (int)threadIdx.x;
+        if (chunk < 0 || c >= v.N) continue;
+        RowEnt<W> L, U;
+        load_lower<W, true>(v, c, L);
+        load_upper<W, false, true>(v, c, U);
+        double al[W], au[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) { al[s] = lower[L.f[s]]; au[s] = upper[U.f[s]]; }
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+            const double *__restrict__ x = m.x[i];
+            double xl[W], xu[W];
+#pragma unroll
+            for (int s = 0; s < W; s++) { xl[s] = x[L.nb[s]]; xu[s] = x[U.nb[s]]; }
+            const double xc = x[c], dc = __builtin_nontemporal_load(&m.diag[i][c]);
+            double acc = dc * xc, sum = dc;
+#pragma unroll
+            for (int s = 0; s < W; s++) if (L.on[s]) { acc += al[s] * xl[s]; if (MODE == 3) sum += al[s]; }
+#pragma unroll
+            for (int s = 0; s < W; s++) if (U.on[s]) { acc += au[s] * xu[s]; if (MODE == 3) sum += au[s]; }
+            __builtin_nontemporal_store(acc, &m.y[i][c]);
+            if (MODE == 3) __builtin_nontemporal_store(sum, &m.sum[i][c]);
+        }
+    }
+}
+template <int MODE, int NF>
+static void rows_multi_launch(ffm_ldu *A, const double *const *diag, const double *const *x, double *const *y, double *const *sumA)
+{
+    RowsMulti<NF> m;
+    for (int i = 0; i < NF; i++) { m.diag[i] = diag[i]; m.x[i] = x[i]; m.y[i] = y[i]; m.sum[i] = sumA ? sumA[i] : nullptr; }
+    FFM_DISPATCH_W(A->maxW, hipLaunchKernelGGL((k_rows_m<MODE, NF, W>), dim3(rows_grid(A)), dim3(256), 0, A->ctx->stream, ffm_view(A),
+                                               (const double *)A->upper, (const double *)A->lower, m));
+}
+// n = 2 .. 4 systems; sumA != NULL: also sumA[i] = the row sums of system i (lduMatrix::sumA).  Matrices without coupled patches.
+int ffm_k_spmv_multi(ffm_ldu *A, int n, const double *const *diag, const double *const *x, double *const *y, double *const *sumA)
+{
+    if (n < 2 || n > 4 || !A->ifaces.empty()) return FFM_ERR_ARG;
+    if (!A->ghNbrRank.empty()) for (int i = 0; i < n; i++) FFM_TRY(ffm_ghost_exchange(A, const_cast<double *>(x[i])));
+    if (sumA) { if (n == 2) rows_multi_launch<3, 2>(A, diag, x, y, sumA); else if (n == 3) rows_multi_launch<3, 3>(A, diag, x, y, sumA); else rows_multi_launch<3, 4>(A, diag, x, y, sumA); }
+    else { if (n == 2) rows_multi_launch<0, 2>(A, diag, x, y, sumA); else if (n == 3) rows_multi_launch<0, 3>(A, diag, x, y, sumA); else rows_multi_launch<0, 4>(A, diag, x, y, sumA); }
+    FFM_HIP(hipGetLastError());
+    return FFM_OK;
+}
+
 int ffm_k_spmv_dot(ffm_ldu *A, const double *x, double *y, int slot)
 {
     if (!A->ifaces.empty()) {  // the halo term changes y after the row kernel: separate dot

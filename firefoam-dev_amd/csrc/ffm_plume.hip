@@ -106,6 +106,7 @@ struct ffm_plume {
     double *fStaticU[3], *fStaticS, *fStaticH, *fH, *refY[NSP], *refH;      // static templates (-1 = inletOutlet)
     // matrix + work
     double *diag, *upper, *lower, *src[3], *ic[3], *bc[3], *dWork, *sWork;
+    double *UdW[3] = {nullptr, nullptr, nullptr}, *UsW[3] = {nullptr, nullptr, nullptr};   // diagonal + source of the three components (one lock-step solve)
     double *wN[12], *wF[6], *wB[8];
     double *ddtCorrF = nullptr; bool ddtCorrValid = false;      // coeff*rDeltaT*phiCorr of fvc::ddtCorr(rho, U, phi): old-time fields only, the same in both correctors of a step
     // fused assembly (ffm_fused.hip): gradients of up to 4 fields, the matrices of the 4 transported species, their patch values
@@ -204,6 +205,22 @@ static int solve_named(ffm_plume *P, const char *name, int solver, int pre, doub
     if (P->stecklerSolvers && solver == FFM_PBICGSTAB && !keepSolver) { solver = FFM_SMOOTH; pre = FFM_SYMGS; maxIter = P->tight ? 1000 : 10; }
     FFM_TRY(ffm_solve_d(P->A, solver, pre, tol, relTol, 0, maxIter, 1, psi, src, &L.perf));
     P->log.push_back(L);
+    return FFM_OK;
+}
+
+// n systems with the off-diagonal coefficients up / lo (the components of U; the species under the common limiter): ffm_solve_multi_d
+static int solve_named_multi(ffm_plume *P, int n, const char *const *names, double tol, const double *const *d, const double *up, const double *lo,
+                             double *const *psi, const double *const *src)
+{
+    if (P->stecklerSolvers || n < 2) {
+        for (int i = 0; i < n; i++) FFM_TRY(solve_named(P, names[i], FFM_PBICGSTAB, FFM_DILU, tol, 0.0, d[i], up, lo, psi[i], src[i], i > 0));
+        return FFM_OK;
+    }
+    double relTol = 0.0;
+    if (P->tight) { tol = 1e-13; relTol = 0.0; }
+    std::vector<ffm_perf> pf(n);
+    FFM_TRY(ffm_solve_multi_d(P->A, n, FFM_PBICGSTAB, FFM_DILU, tol, relTol, 0, 1000, d, up, lo, psi, src, pf.data()));
+    for (int i = 0; i < n; i++) { SolveLog L; memset(&L, 0, sizeof(L)); strncpy(L.name, names[i], sizeof(L.name) - 1); L.perf = pf[i]; P->log.push_back(L); }
     return FFM_OK;
 }
 
@@ -625,11 +642,17 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         double *s = P->Usrc[c]; const double *rho0 = P->rho0, *u0 = P->U0[c];
         forN(P, N, [=] __device__(long i) { s[i] = rdt * rho0[i] * u0[i] * V[i] - V[i] * divc[i]; });
     }
-    for (int c = 0; c < 3; c++) {
-        FFM_TRY(ffm_fvm_add_boundary(m, P->Uic[c], P->Ubc[c], P->Udiag, P->Usrc[c], rec[c], P->dWork, P->sWork));
+    {
+        // fvMatrix::solveSegregated: the three components share the face coefficients -- one lock-step solve (ffm_solve_multi_d)
         const char *nm[3] = {"Ux", "Uy", "Uz"};
-        FFM_TRY(solve_named(P, nm[c], FFM_PBICGSTAB, FFM_DILU, 1e-6, 0.0, P->dWork, P->Uupper, P->Ulower, P->U[c], P->sWork, c > 0));
-        FFM_TRY(HX(P, P->U[c]));
+        const double *dd[3], *ss[3]; double *pp[3];
+        for (int c = 0; c < 3; c++) {
+            if (!P->UdW[c]) { P->UdW[c] = dalloc(P, N); P->UsW[c] = dalloc(P, N); if (!P->UdW[c] || !P->UsW[c]) return FFM_ERR_HIP; }
+            FFM_TRY(ffm_fvm_add_boundary(m, P->Uic[c], P->Ubc[c], P->Udiag, P->Usrc[c], rec[c], P->UdW[c], P->UsW[c]));
+            dd[c] = P->UdW[c]; ss[c] = P->UsW[c]; pp[c] = P->U[c];
+        }
+        FFM_TRY(solve_named_multi(P, 3, nm, 1e-6, dd, P->Uupper, P->Ulower, pp, ss));
+        for (int c = 0; c < 3; c++) FFM_TRY(HX(P, P->U[c]));
     }
     {
         double *K = P->K; const double *U0 = P->U[0], *U1 = P->U[1], *U2 = P->U[2];
@@ -721,10 +744,14 @@ extern "C" int ffm_plume_step(ffm_plume *P)
         FFM_TRY(ffm_fvm_scalar_transport_multi(m, ns, 3, 1.0, 0.0, 1.0, rdt, P->rho, P->rho0, P->phi, P->phib, af, afb, vf, cgx, cgy, cgz, vf0,
                                                fq, rq, gq, suq, nullptr, nullptr, nullptr, P->spD, P->spU, P->spL, P->spS));
         }
+        if (P->mvSelection) {          // common weights, one diffusivity: the species' systems differ in diagonal and source only
+            const char *nmq[4]; const double *dq[4], *sq[4]; double *pq[4];
+            for (int j = 0; j < ns; j++) { nmq[j] = SPN[sp[j]]; dq[j] = P->spD[j]; sq[j] = P->spS[j]; pq[j] = P->Y[sp[j]]; }
+            FFM_TRY(solve_named_multi(P, ns, nmq, 1e-8, dq, P->spU[0], P->spL[0], pq, sq));
+        }
         for (int j = 0; j < ns; j++) {
             const int i = sp[j];
-            if (P->mvSelection) FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[0], P->spL[0], P->Y[i], P->spS[j], j > 0));
-            else FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[j], P->spL[j], P->Y[i], P->spS[j]));
+            if (!P->mvSelection) FFM_TRY(solve_named(P, SPN[i], FFM_PBICGSTAB, FFM_DILU, 1e-8, 0.0, P->spD[j], P->spU[j], P->spL[j], P->Y[i], P->spS[j]));
             FFM_TRY(HX(P, P->Y[i]));
             double *Yi = P->Y[i];
             forN(P, N, [=] __device__(long c) { const double v = fmax(Yi[c], 0.0); Yi[c] = v; Yt[c] += v; });

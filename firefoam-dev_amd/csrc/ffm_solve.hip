@@ -1230,14 +1230,27 @@ static int precond_lanes(ffm_ldu *A, int precond, Lane *L, int n, double *Lane::
     if (m == 1) { G.use(L[only]); return ffm_precond_apply_i(A, precond, false, L[only].*in, L[only].*out); }
     return FFM_OK;
 }
+// out = A in for the lanes still iterating: one pass over the coefficients for all of them (ffm_ldu.hip: k_rows_m)
+static int amul_lanes(ffm_ldu *A, Lane *L, int n, double *Lane::*in, double *Lane::*out, LaneGuard &G)
+{
+    const double *dg[FFM_TILE_MAXSYS], *x[FFM_TILE_MAXSYS]; double *y[FFM_TILE_MAXSYS]; int m = 0, only = -1;
+    for (int i = 0; i < n; i++) if (L[i].active) { dg[m] = L[i].diag; x[m] = L[i].*in; y[m] = L[i].*out; m++; only = i; }
+    if (m >= 2) return ffm_k_spmv_multi(A, m, dg, x, y, nullptr);
+    if (m == 1) { G.use(L[only]); return ffm_k_spmv(A, L[only].*in, L[only].*out, false); }
+    return FFM_OK;
+}
 static int pbicgstab_multi(ffm_ldu *A, int precond, const Controls &k, int n, Lane *L)
 {
     ffm_ctx *c = A->ctx; hipStream_t s = c->stream; const long N = A->nOwned; const int g = sgrid(N);
     LaneGuard G(A);
+    {   // wA = A psi and sumA of every system in one pass
+        const double *dg[FFM_TILE_MAXSYS], *x[FFM_TILE_MAXSYS]; double *y[FFM_TILE_MAXSYS], *sm[FFM_TILE_MAXSYS];
+        for (int i = 0; i < n; i++) { dg[i] = L[i].diag; x[i] = L[i].psi; y[i] = L[i].yA; sm[i] = L[i].pA; }
+        FFM_TRY(ffm_k_spmv_multi(A, n, dg, x, y, sm));
+    }
     for (int i = 0; i < n; i++) {
         Lane &l = L[i]; G.use(l);
         FFM_TRY(scalar_op(c, OP_RESET));
-        FFM_TRY(ffm_k_spmv_sumA(A, l.psi, l.yA, l.pA));
         hipLaunchKernelGGL(k_sub, dim3(g), dim3(256), 0, s, N, l.rA, l.source, l.yA);
         FFM_TRY(norm_and_initial(A, l.psi, l.source, l.yA, l.pA, l.rA, l.perf));          // (reads this lane's scalars back)
         l.active = k.minIter > 0 || !check_convergence(l.perf, k);
@@ -1262,9 +1275,9 @@ static int pbicgstab_multi(ffm_ldu *A, int precond, const Controls &k, int n, La
         }
         if (!any) break;
         FFM_TRY(precond_lanes(A, precond, L, n, &Lane::pA, &Lane::yA, G));
+        FFM_TRY(amul_lanes(A, L, n, &Lane::yA, &Lane::AyA, G));
         for (int i = 0; i < n; i++) if (L[i].active) {
             Lane &l = L[i]; G.use(l);
-            FFM_TRY(ffm_k_spmv(A, l.yA, l.AyA, false));
             FFM_TRY(ffm_k_dot(c, l.rA0, l.AyA, N, S_TMP0));
             FFM_TRY(finish_dot(c, OP_BS_ALPHA));
             hipLaunchKernelGGL(k_bs_s, dim3(g), dim3(256), 0, s, N, l.sA, l.rA, l.AyA, c->scal_d, c->partials_d);
@@ -1283,9 +1296,9 @@ static int pbicgstab_multi(ffm_ldu *A, int precond, const Controls &k, int n, La
             }
         }
         FFM_TRY(precond_lanes(A, precond, L, n, &Lane::sA, &Lane::zA, G));
+        FFM_TRY(amul_lanes(A, L, n, &Lane::zA, &Lane::tA, G));
         for (int i = 0; i < n; i++) if (L[i].active) {
             Lane &l = L[i]; G.use(l);
-            FFM_TRY(ffm_k_spmv(A, l.zA, l.tA, false));
             hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, s, N, l.tA, l.sA, c->partials_d);
             FFM_TRY(partial_sum_to(c, g, S_TMP0, 2));
             FFM_TRY(finish_dot(c, OP_BS_OMEGA, 2));

@@ -230,6 +230,18 @@ int ffm_solve_d(ffm_ldu *ldu, int solver, int precond, double tolerance,
 int ffm_solve(ffm_ldu *ldu, int solver, int precond, double tolerance,
               double relTol, int minIter, int maxIter, int nSweeps,
               double *psi, const double *source, ffm_perf *out);
+/* nSys systems that share the off-diagonal coefficients and differ in the diagonal and the right-hand side: the components of a
+ * vector equation (fvMatrix<Type>::solveSegregated, OpenFOAM-dev fvMatrixSolve.C; solver/UEqn.H:19-30) and the species equations
+ * under a multivariateSelection scheme with one diffusivity (solver/YEEqn.H:43-60).  Every system gets the solve a call of
+ * ffm_ldu_bind_coeffs_native_d(diag_d[i], upper_d, lower_d) + ffm_solve_d would give it -- the same operations in the same order,
+ * its own iteration count and residuals in out[i] -- but for PBiCGStab with DILU / DIC on a tiled matrix in the library's cell order
+ * the systems (at most 4 at a time) advance in lock step and the preconditioner sweeps and calcReciprocalD of those still iterating
+ * are one sweep each (coefficients and addressing read once).  Any other selection: one solve after the other.
+ * diag_d[i] [cells], upper_d / lower_d [native faces; lower_d NULL or == upper_d: symmetric], psi_d[i] in/out, source_d[i].
+ * The matrix is left bound to the caller's arrays as by ffm_ldu_bind_coeffs_native_d.                                         */
+int ffm_solve_multi_d(ffm_ldu *ldu, int nSys, int solver, int precond, double tolerance, double relTol, int minIter, int maxIter,
+                      const double *const *diag_d, const double *upper_d, const double *lower_d, double *const *psi_d,
+                      const double *const *source_d, ffm_perf *out /* [nSys] */);
 
 /* timing helper for bench.py: runs `reps` back-to-back launches of the SpMV
  * kernel used inside the solvers on the context stream, bracketed by HIP
