@@ -11,8 +11,12 @@ semantics: oracle/steckler_case.py), reproduces the FIRST TIME STEP of the refer
   smoothSolver h              Initial 1, Final 6.5274e-13, 2 iterations; min/max(T) = 298.15, 300.49              -- every printed digit
   DICPCG p_rgh                0.99822 -> 0.0080322 in 10; 0.0052595 -> 8.7647e-07 in 28                           -- every printed digit
   time step continuity errors 0.00047825 / -0.00013113 and 8.5653e-08 / -4.6658e-09                               -- every printed digit
-  smoothSolver k              Initial 1, 3 iterations; Final 1.8232e-12: the oracle gets 1.935e-12 (6 % off: the residual sum is 9.3e-16 over
-                              9000 rows of 1.4e-05-sized terms, ~60 ulp per row -- the rounding floor of its own evaluation) (**)
+  smoothSolver k              Initial 1, 3 iterations; Final 1.8232e-12: the oracle gets 1.935e-12, 6 % off.  NOT a rounding effect (round 3:
+                              test_k_final_residual_is_not_rounding_noise -- one-ulp perturbations of the system move it in the 5th digit):
+                              three symGaussSeidel sweeps reduce the residual by 1.2e-4 each, so 6 % at the end is 2 % in the per-sweep
+                              factor, i.e. a ~1 % difference in the off-diagonal / diagonal ratio of the k matrix against upstream kEqn.C
+                              (absent from /root/reference; restated from memory of OpenFOAM-dev).  Open; the k FIELD enters the log only
+                              through nut (U, h, species lines of the later steps, all matched), so its effect is below the log's digits (**)
 
 (*) the O2 field is 0.23301 almost everywhere and its final residual is 3e-9 of the initial one: it moves by 2e-4 when one
     operand changes in the last bit (pow(V,1/3) instead of cbrt(V) for the LES delta), so it is pinned to 1e-3 only.
@@ -245,3 +249,27 @@ def test_the_multivariate_limiter_is_what_the_log_shows(O):
     d.advance()
     assert sig(d.species_stats["O2"][0], 5) == "0.21674" and sig(d.species_stats["N2"][2], 5) == "0.78326"
     assert sig(dict(d.log)["h"]["initialResidual"], 5) == "0.86583"
+
+
+def test_k_final_residual_is_not_rounding_noise():
+    """is the oracle's 6 % on the k line's final residual the rounding floor of the residual evaluation?  No: with
+    every entry of the source (or of the diagonal) moved by -1, 0 or +1 ulp the three-sweep final residual stays at 1.935e-12 to four
+    digits, while the log's 1.8232e-12 is 6 % away.  The difference is therefore in the k matrix itself (see the header); the test keeps
+    that statement honest."""
+    from oracle import steckler_case as SC, oracle as O
+    rec = {}
+    c = SC.first_step_records(hook=lambda name, q: rec.update(q) if name == "k" else None)
+    m = c.m
+
+    def final(d, s):
+        A = O.Ldu(m.nCells, m.l, m.u).set_coeffs(d, rec["upper"], rec["lower"])
+        return A.solve(O.SMOOTH, O.SYMGS, rec["psi0"], s, tolerance=rec["tol"], relTol=0.0, maxIter=10)[1]
+    base = final(rec["d"], rec["s"])
+    assert base["nIterations"] == 3 and sig(base["finalResidual"], 4) == "1.935e-12"
+    rng = np.random.default_rng(0)
+    for which in ("s", "s", "d", "d"):
+        flip = 1.0 + rng.integers(-1, 2, m.nCells) * 2.0 ** -52
+        p = final(rec["d"] * (flip if which == "d" else 1.0), rec["s"] * (flip if which == "s" else 1.0))
+        assert p["nIterations"] == 3 and abs(p["finalResidual"] - base["finalResidual"]) < 5e-4 * base["finalResidual"], (which, p)
+    gold = [g for g in GOLD["solves"] if g["name"] == "k"][0]["finalResidual"]
+    assert 0.05 < abs(base["finalResidual"] - gold) / gold < 0.08
