@@ -260,6 +260,12 @@ struct FfmStageTimer {
     explicit FfmStageTimer(const char *w) : what(w), t0(now()), on(getenv("FFM_TIMING") != nullptr) {}
     ~FfmStageTimer() { if (on) fprintf(stderr, "ffm timing: %-28s %.2f s\n", what, now() - t0); }
 };
+// the same in laps: lap("x") prints the time since the previous lap (FFM_TIMING=2)
+struct FfmLapTimer {
+    const char *what; double t0; bool on;
+    explicit FfmLapTimer(const char *w) : what(w), t0(FfmStageTimer::now()), on(getenv("FFM_TIMING") != nullptr && atoi(getenv("FFM_TIMING")) >= 2) {}
+    void lap(const char *stage) { if (!on) return; const double t = FfmStageTimer::now(); fprintf(stderr, "ffm timing:   %s: %-30s %.2f s\n", what, stage, t - t0); t0 = t; }
+};
 // label of the 2-D tile (a, b) of cell columns.  Ties between tiles that are ready at the same time are broken by label
 // (ffm_ldu.hip: topological ranking), so the label orders the tickets: anti-diagonal major = the order of the sweep's wavefront
 // (FFM_TILE_ROW_ORDER=1: row-major, the round-1 order)

@@ -33,6 +33,7 @@
 #include "ffm_internal.hpp"
 #include "ffm_device.hpp"
 #include <algorithm>
+#include <atomic>
 #include <numeric>
 
 // ---------------------------------------------------------------- analysis ---
@@ -137,6 +138,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
                    const int *groupHint = nullptr, int forceMode = -1)
 {
     a.mode = forceMode >= 0 ? forceMode : default_sweep_mode();
+    FfmLapTimer lap_("analyse");
     std::vector<int> autoHint;
     const bool autoMode = a.mode == SWEEP_AUTO;
     if (a.mode == SWEEP_AUTO) {
@@ -167,6 +169,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         }
         if (l[f] >= nOwn) { ffm_set_error("LDU addressing: face %d is owned by a ghost cell", f); return FFM_ERR_ADDR; }
     }
+    lap_.lap("hint + validation");
     // forward levels
     std::vector<int> lev(N, 0);
     for (int f = 0; f < F; f++) if (u[f] < nOwn) lev[u[f]] = std::max(lev[u[f]], lev[l[f]] + 1);
@@ -184,12 +187,23 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         int G = 0;
         bool hinted = false;
         if (groupHint && nOwn > 0) {
-            std::vector<int> labels(groupHint, groupHint + nOwn);
-            std::sort(labels.begin(), labels.end()); labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+            // the distinct labels in ascending order and every cell's index into them: a presence table where the labels span a small
+            // range (tile labels do), a sort otherwise
+            std::vector<int> labels, gid(nOwn);
+            int labMin = groupHint[0], labMax = groupHint[0];
+            for (int c = 1; c < nOwn; c++) { labMin = std::min(labMin, groupHint[c]); labMax = std::max(labMax, groupHint[c]); }
+            if ((long)labMax - labMin < (1L << 24)) {
+                std::vector<int> idx((size_t)(labMax - labMin) + 1, 0);
+                for (int c = 0; c < nOwn; c++) idx[groupHint[c] - labMin] = 1;
+                for (size_t i = 0; i < idx.size(); i++) if (idx[i]) { idx[i] = (int)labels.size(); labels.push_back(labMin + (int)i); } else idx[i] = -1;
+                ffm_parallel_for(nOwn, [&](long lo, long hi) { for (long c = lo; c < hi; c++) gid[c] = idx[groupHint[c] - labMin]; });
+            } else {
+                labels.assign(groupHint, groupHint + nOwn);
+                std::sort(labels.begin(), labels.end()); labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+                ffm_parallel_for(nOwn, [&](long lo, long hi) {
+                    for (long c = lo; c < hi; c++) gid[c] = (int)(std::lower_bound(labels.begin(), labels.end(), groupHint[c]) - labels.begin()); });
+            }
             const int nl = (int)labels.size();
-            auto idOf = [&](int lab) { return (int)(std::lower_bound(labels.begin(), labels.end(), lab) - labels.begin()); };
-            std::vector<int> gid(nOwn);
-            for (int c = 0; c < nOwn; c++) gid[c] = idOf(groupHint[c]);
             int nl2 = nl;
             // A label class that an internal wall (a sheet of baffle faces, cases/steckler/system/createBafflesDict) cuts into pieces that
             // are not connected inside the class has dependency levels that restart behind the wall: a level then holds cells of two
@@ -222,6 +236,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
                     for (int c = 0; c < nOwn; c++) gid[c] = newId[find(c)];
                 }
             }
+    lap_.lap("labels + components");
             std::vector<std::pair<int, int>> edges;
             for (int f = 0; f < F; f++) if (u[f] < nOwn && gid[l[f]] != gid[u[f]]) edges.emplace_back(gid[l[f]], gid[u[f]]);
             std::sort(edges.begin(), edges.end()); edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
@@ -254,6 +269,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
             G = nOwn ? (nOwn + B - 1) / B : 0;
             for (int c = 0; c < nOwn; c++) grpOfOld[c] = c / B;
         }
+    lap_.lap("group graph");
         a.nGroups = G;
         a.grpCell.assign(G + 1, 0);
         for (int c = 0; c < nOwn; c++) a.grpCell[grpOfOld[c] + 1]++;
@@ -287,6 +303,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
             if (!G) pos.clear();
             for (int i = 0; i < nOwn; i++) { const int c = byLevel[i]; const int p = pos[grpOfOld[c]]++; a.newToOldCell[p] = c; a.oldToNewCell[c] = p; }
         }
+    lap_.lap("cell order");
         for (int c = nOwn; c < N; c++) { a.newToOldCell[c] = c; a.oldToNewCell[c] = c; }
         a.fwdLevelStart.assign(nLev + 1, 0);
     } else if (renumber) {
@@ -325,16 +342,22 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         // The counting sort leaves the faces of one owner in the caller's face order.  The device
         // layout keeps that order so every row is accumulated exactly as in the caller's face loop;
         // the public renumbering sorts by the new neighbour (a proper upper-triangular mesh).
-        if (sortByNewNeighbour) for (int c = 0; c < N; c++) {
-            std::sort(a.newToOldFace.begin() + cnt[c], a.newToOldFace.begin() + cnt[c + 1],
-                      [&](int f1, int f2) { return a.oldToNewCell[u[f1]] < a.oldToNewCell[u[f2]]; });
-        }
-        for (int f = 0; f < F; f++) {
-            int of = a.newToOldFace[f];
-            a.l[f] = a.oldToNewCell[l[of]]; a.u[f] = a.oldToNewCell[u[of]];
-            if (a.l[f] >= a.u[f]) { ffm_set_error("internal: renumbering flipped a face"); return FFM_ERR_ADDR; }
-        }
+        if (sortByNewNeighbour) ffm_parallel_for(N, [&](long lo, long hi) {
+            for (long c = lo; c < hi; c++)
+                std::sort(a.newToOldFace.begin() + cnt[c], a.newToOldFace.begin() + cnt[c + 1],
+                          [&](int f1, int f2) { return a.oldToNewCell[u[f1]] < a.oldToNewCell[u[f2]]; });
+        });
+        std::atomic<int> flipped(0);
+        ffm_parallel_for(F, [&](long lo, long hi) {
+            for (long f = lo; f < hi; f++) {
+                const int of = a.newToOldFace[f];
+                a.l[f] = a.oldToNewCell[l[of]]; a.u[f] = a.oldToNewCell[u[of]];
+                if (a.l[f] >= a.u[f]) flipped = 1;
+            }
+        });
+        if (flipped) { ffm_set_error("internal: renumbering flipped a face"); return FFM_ERR_ADDR; }
     }
+    lap_.lap("faces");
     // backward levels (new numbering)
     std::vector<int> bl(N, 0);
     for (int f = F - 1; f >= 0; f--) if (a.u[f] < nOwn) bl[a.l[f]] = std::max(bl[a.l[f]], bl[a.u[f]] + 1);
@@ -355,25 +378,46 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         int s = a.bwdLevelStart[b], e = a.bwdLevelStart[b + 1];
         if (e > s && a.bwdOrder[e - 1] - a.bwdOrder[s] != e - s - 1) a.bwdContig = false;
     }
+    lap_.lap("backward levels");
     if (a.mode >= 1) {
         const int G = a.nGroups;
         a.levNew.resize(nOwn); a.blNew.assign(bl.begin(), bl.begin() + nOwn);
-        for (int c = 0; c < nOwn; c++) a.levNew[c] = lev[a.newToOldCell[c]];
+        ffm_parallel_for(nOwn, [&](long lo, long hi) { for (long c = lo; c < hi; c++) a.levNew[c] = lev[a.newToOldCell[c]]; });
         // the group graph must be acyclic in the new numbering: every cross-group face points from a lower to a higher group
-        auto grpOfNew = [&](int c) { return grpOfOld[a.newToOldCell[c]]; };
-        for (int f = 0; f < F; f++) {
-            if (a.u[f] >= nOwn) continue;
-            if (grpOfNew(a.l[f]) > grpOfNew(a.u[f])) { ffm_set_error("internal: group graph not acyclic"); return FFM_ERR_ADDR; }
-        }
-        // backward order inside each group: by backward level, then descending cell index
-        a.bwdCells.resize(nOwn); a.bwdIsReverse = true;
-        for (int g = 0; g < G; g++) {
-            const int c0 = a.grpCell[g], c1 = a.grpCell[g + 1];
-            for (int c = c0; c < c1; c++) a.bwdCells[c0 + (c1 - 1 - c)] = c;      // descending cell index
-            std::stable_sort(a.bwdCells.begin() + c0, a.bwdCells.begin() + c1, [&](int x, int y) { return bl[x] < bl[y]; });
-            for (int p = c0; p < c1; p++) if (a.bwdCells[p] != c1 - 1 - (p - c0)) a.bwdIsReverse = false;
-        }
+        // (new numbering: the group of cell c is the one whose range [grpCell[g], grpCell[g + 1]) holds it)
+        std::vector<int> grpOfNew(nOwn);
+        ffm_parallel_for(G, [&](long lo, long hi) { for (long g = lo; g < hi; g++) std::fill(grpOfNew.begin() + a.grpCell[g], grpOfNew.begin() + a.grpCell[g + 1], (int)g); });
+        std::atomic<int> cyclic(0);
+        ffm_parallel_for(F, [&](long lo, long hi) {
+            for (long f = lo; f < hi; f++) if (a.u[f] < nOwn && grpOfNew[a.l[f]] > grpOfNew[a.u[f]]) cyclic = 1;
+        });
+        if (cyclic) { ffm_set_error("internal: group graph not acyclic"); return FFM_ERR_ADDR; }
+        // backward order inside each group: by backward level, then descending cell index (a counting sort per group; groups in parallel)
+        a.bwdCells.resize(nOwn);
+        std::atomic<int> notReverse(0);
+        auto groups = [&](long g0, long g1) {
+            std::vector<int> cntB;
+            for (long g = g0; g < g1; g++) {
+                const int c0 = a.grpCell[g], c1 = a.grpCell[g + 1];
+                if (c1 <= c0) continue;
+                int bMin = bl[c0], bMax = bl[c0];
+                for (int c = c0 + 1; c < c1; c++) { bMin = std::min(bMin, bl[c]); bMax = std::max(bMax, bl[c]); }
+                cntB.assign((size_t)(bMax - bMin) + 2, 0);
+                for (int c = c0; c < c1; c++) cntB[bl[c] - bMin + 1]++;
+                for (size_t i = 1; i < cntB.size(); i++) cntB[i] += cntB[i - 1];
+                for (int c = c1 - 1; c >= c0; c--) a.bwdCells[c0 + cntB[bl[c] - bMin]++] = c;      // descending cell index inside a level
+                for (int p = c0; p < c1; p++) if (a.bwdCells[p] != c1 - 1 - (p - c0)) { notReverse = 1; break; }
+            }
+        };
+        if (G >= 8 && nOwn >= (1 << 20)) {
+            static const int nT = [] { const char *e = getenv("FFM_HOST_THREADS"); int t = e ? atoi(e) : (int)std::thread::hardware_concurrency(); return std::max(1, std::min(t, 16)); }();
+            std::vector<std::thread> th;
+            for (int t = 0; t < nT; t++) th.emplace_back([&, t] { groups((long)G * t / nT, (long)G * (t + 1) / nT); });
+            for (auto &x : th) x.join();
+        } else groups(0, G);
+        a.bwdIsReverse = !notReverse;
     }
+    lap_.lap("group checks + backward order");
     if (a.mode == 2 && !ffm_tile_feasible(nOwn, F, a.l.data(), a.u.data())) {
         if (getenv("FFM_VERBOSE")) fprintf(stderr, "ffm: tiled sweeps not applicable (more than 3 lower or upper neighbours): level-scheduled sweeps\n");
         // the tiled sweeps cannot take this mesh / grouping: level-scheduled sweeps instead
@@ -381,6 +425,7 @@ static int analyse(int N, int nOwn, int F, const int *l, const int *u, bool renu
         FFM_TRY(analyse(N, nOwn, F, l, u, renumber, sortByNewNeighbour, b, nullptr, 0));
         a = std::move(b);
     }
+    lap_.lap("feasibility");
     return FFM_OK;
 }
 

@@ -29,3 +29,12 @@ def random_dag_mesh(O, n, seed=5):
 def rel_l2(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def free_port():
+    """a TCP port nobody listens on right now (rendezvous of the multi-process tests on 127.0.0.1): asked from the kernel, so that two
+    test cases run one after the other never meet on a port that is still in TIME_WAIT"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]

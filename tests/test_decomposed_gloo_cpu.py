@@ -13,7 +13,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from common import rel_l2
+from common import rel_l2, free_port
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -27,7 +27,7 @@ def test_gloo_ranks_match_serial_oracle(O, ffm, grid, solver, precond):
     s = H.synth_p_rgh(whole)
     ref, perf = O.Ldu(whole.nCells, whole.l, whole.u).set_coeffs(s["diag"], s["upper"]).solve(
         getattr(O, solver), getattr(O, precond), np.zeros(whole.nCells), s["source"], tolerance=1e-12)
-    port = 29700 + (os.getpid() % 200) + 3 * world
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "oracle_rank.py"), str(r), str(world), str(port),
                                    *map(str, glob), *map(str, grid), solver, precond, tmp],

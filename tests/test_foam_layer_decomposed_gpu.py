@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import foam_case
-from common import rel_l2
+from common import rel_l2, free_port
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -30,7 +30,7 @@ def test_b1_demo_on_a_decomposed_mesh(O, ffm, ctx, world, partitioner):
     I = foam_case.inputs(O, m)
     ref, cells, nit1 = foam_case.run_b1_demo(ffm, ctx, m, I)
     assert np.array_equal(cells, np.arange(m.nCells))
-    port = 29500 + (os.getpid() % 150) + 7 * world
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "foam_rank.py"), str(r), str(world), str(port)] + [str(v) for v in n]
                                   + [partitioner, tmp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in range(world)]
@@ -72,7 +72,7 @@ def test_fvdom_with_reflecting_walls_on_a_decomposed_mesh(O, ffm, ctx, world, pa
     T, Tb, E, emis = foam_case.fvdom_inputs(m)
     (I1, G1, q1), cells, its1 = foam_case.run_b1_fvdom(ffm, ctx, m, T, Tb, E, emis)
     assert its1 == [3, 3] and np.array_equal(cells, np.arange(m.nCells))
-    port = 29650 + (os.getpid() % 150) + 7 * world
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "foam_rank.py"), str(r), str(world), str(port)] + [str(v) for v in n]
                                   + [partitioner, tmp, "fvdom"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for r in range(world)]

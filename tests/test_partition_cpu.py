@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import part_cases
-from common import rel_l2
+from common import rel_l2, free_port
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -73,7 +73,7 @@ def test_partition_and_subdomains(O, ffm, meshName, partitioner, nParts):
 def test_gloo_ranks_on_a_partitioned_mesh_match_the_serial_solve(O, ffm, meshName, partitioner, world, solver, precond, asym):
     N, l, u, centres, diag, up, lo, source = part_cases.build(O, meshName, asym)
     ref, perf = O.Ldu(N, l, u).set_coeffs(diag, up, lo).solve(getattr(O, solver), getattr(O, precond), np.zeros(N), source, tolerance=1e-12)
-    port = 29900 + (os.getpid() % 150) + 5 * world + (0 if meshName == "steckler" else 40)
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "part_rank.py"), "oracle", str(r), str(world), str(port),
                                    meshName, partitioner, solver, precond, str(asym), tmp],
@@ -103,7 +103,7 @@ def test_gloo_variable_count_exchange(ffm):
         "g.exchange_var(others, sends, recvs)\n"
         "assert all(np.array_equal(rv, 100.0 * q + np.arange(q + 1 + r)) for q, rv in zip(others, recvs))\n"
     ) % os.path.dirname(HERE)
-    port = 29800 + os.getpid() % 150
+    port = free_port()
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), "3", str(port)], env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""),
                               stderr=subprocess.PIPE) for r in range(3)]
     try:

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import part_cases
-from common import rel_l2
+from common import rel_l2, free_port
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,7 +26,7 @@ def test_partitioned_mesh_on_the_device(O, ffm, ctx, meshName, partitioner, worl
     Ao = O.Ldu(N, l, u).set_coeffs(diag, up, lo)
     ref, perf = Ao.solve(getattr(O, solver), getattr(O, precond), np.zeros(N), source, tolerance=1e-12, maxIter=1000)
     yref = Ao.amul(O.hash_u(0xF4, np.arange(N)))
-    port = 29300 + (os.getpid() % 150) + 5 * world + (0 if meshName == "steckler" else 40)
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "part_rank.py"), "gpu", str(r), str(world), str(port),
                                    meshName, partitioner, solver, precond, str(asym), tmp], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -79,7 +79,7 @@ def test_every_smoother_sweep_sees_the_neighbour_ranks_current_values(O, ffm, ct
     first would be off by the size of one sweep's update (~1e-2), not by rounding."""
     world = 2
     args = [meshName, "graph", "GS2", precond, "0.3"]
-    port = 29500 + (os.getpid() % 150) + (0 if precond == "SYMGS" else 7) + (0 if meshName == "steckler" else 20)
+    port = free_port()
     with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
         ref = _run_ranks("oracle", world, port, args, t1, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
         got = _run_ranks("gpu", world, port + 1, args, t2)
@@ -107,7 +107,7 @@ def test_gamg_on_a_decomposed_mesh(O, ffm, ctx, meshName, world, precond, asym):
     decomposition: the same hierarchy (cells per level on every rank), the same number of V-cycles, the same residuals and solution
     (the two forms add a row's interface terms at different places of its sum: rounding level)."""
     args = [meshName, "rcb", "GAMG", precond, str(asym)]          # (coordinate bisection: box-like sub-domains; a coarse cell may have at most 16 lower / upper neighbours in this library)
-    port = 29400 + (os.getpid() % 150) + 11 * world + {"GS": 0, "DILU": 3, "SYMGS": 5, "DIC": 7}[precond]
+    port = free_port()
     with tempfile.TemporaryDirectory() as t1, tempfile.TemporaryDirectory() as t2:
         ref = _run_ranks("oracle", world, port, args, t1, env=dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES=""))
         got = _run_ranks("gpu", world, port + 1, args, t2)

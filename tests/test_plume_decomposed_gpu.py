@@ -10,7 +10,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from common import rel_l2
+from common import rel_l2, free_port
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -51,7 +51,7 @@ def _run(ffm, ctx, glob, grid, extraEnv, extraFields=()):
     tol = 1e-10 if big else 1e-8
     for _ in range(nSteps):
         ref.step()
-    port = 29500 + (os.getpid() % 500) + 7 * world
+    port = free_port()
     with tempfile.TemporaryDirectory() as tmp:
         procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "workers", "plume_rank.py"), str(r), str(world), str(port),
                                    *map(str, glob), *map(str, grid), str(nSteps), tmp],
