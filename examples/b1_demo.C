@@ -503,3 +503,75 @@ extern "C" int b1_time_sequence(double deltaT0, double writeInterval, int n, con
     }
     return n;
 }
+
+// ---- the value semantics of dField (include/ffmFoam.H) under lazy evaluation and shared storage, checked on the device against host
+// arithmetic: returns 0 when every check holds, else the number of the first failing check (tests/test_foam_layer_gpu.py).
+// a, b: n values each (b without zeros).
+extern "C" int b1_dfield_semantics(ffm_ctx* ctx, int n, const double* a, const double* b, int* evaluationsOut)
+{
+    std::vector<double> h(n), g(n);
+    auto same = [&](const dField& f, const std::vector<double>& ref) {
+        f.toHost(h.data());
+        return std::memcmp(h.data(), ref.data(), sizeof(double)*n) == 0;
+    };
+    auto host = [&](std::function<double(int)> fn) { std::vector<double> r(n); for (int i = 0; i < n; i++) r[i] = fn(i); return r; };
+    dField A(ctx, n), B(ctx, n);
+    A.assignHost(a); B.assignHost(b);
+    // 1: a copy is independent of its source (written after the copy)
+    {
+        dField C(A);
+        FFM_FOAM_CHK(ffm_field_fill(ctx, n, 7.0, C.data()));                  // write access: C separates from A
+        if (!same(A, host([&](int i) { return a[i]; }))) return 1;
+        if (!same(C, host([&](int) { return 7.0; }))) return 1;
+    }
+    // 2: an unevaluated expression keeps the operand values it was built from
+    {
+        dField X(A);
+        dField E(binary(FFM_OP_ADD, binary(FFM_OP_MUL, X, B), scalarOp(FFM_OP_SUB, X, 1.5, true)));       // X*B + (1.5 - X), pending
+        if (!E.pending()) return 2;
+        FFM_FOAM_CHK(ffm_field_fill(ctx, n, -3.0, X.data()));                 // overwrite the operand before the expression is evaluated
+        if (!same(E, host([&](int i) { return a[i]*b[i] + (1.5 - a[i]); }))) return 2;
+        if (!same(X, host([&](int) { return -3.0; }))) return 2;
+    }
+    // 3: an expression used twice gives the same values in both places; a constant is folded in as an immediate
+    {
+        const dField S(binary(FFM_OP_DIV, A, B));                             // pending
+        const dField P(binary(FFM_OP_ADD, S, dField(ctx, n, 2.0)));
+        const dField Q(binary(FFM_OP_MUL, S, S));
+        if (!same(P, host([&](int i) { return a[i]/b[i] + 2.0; }))) return 3;
+        if (!same(Q, host([&](int i) { const double s = a[i]/b[i]; return s*s; }))) return 3;
+        if (!same(S, host([&](int i) { return a[i]/b[i]; }))) return 3;
+    }
+    // 4: a tree larger than one program (more than 8 operand arrays / 32 operations / depth 4) is cut and still exact
+    {
+        std::vector<dField> v;
+        for (int k = 0; k < 12; k++) v.push_back(scalarOp(FFM_OP_MUL, A, 1.0 + 0.125*k));       // 12 different pending arrays
+        for (auto& f : v) (void)f.data();                                                      // ... evaluated: 12 leaves
+        dField acc(v[0]);
+        for (int k = 1; k < 12; k++) acc = binary(k % 2 ? FFM_OP_ADD : FFM_OP_SUB, acc, binary(FFM_OP_MUL, v[k], B));
+        if (!same(acc, host([&](int i) { double r = a[i]*1.0; for (int k = 1; k < 12; k++) { const double t = (a[i]*(1.0 + 0.125*k))*b[i]; r = k % 2 ? r + t : r - t; } return r; }))) return 4;
+        // right-deep: a - (b*(a + (b/(a + b)))) needs the deepest operand first
+        const dField D(binary(FFM_OP_SUB, A, binary(FFM_OP_MUL, B, binary(FFM_OP_ADD, A, binary(FFM_OP_DIV, B, binary(FFM_OP_ADD, A, binary(FFM_OP_MAX, B, unary(FFM_UN_MAG, A))))))));
+        if (!same(D, host([&](int i) { return a[i] - b[i]*(a[i] + b[i]/(a[i] + std::fmax(b[i], std::fabs(a[i])))); }))) return 4;
+    }
+    // 5: a view of a library array is read in place and copied when written
+    {
+        dField V(dField::view(ctx, n, A.data()));
+        if (((const dField&)V).data() == nullptr || ((const dField&)V).data() != ((const dField&)A).data()) return 5;      // read access: in place
+        double* w = V.data();                                                  // write access: a private copy
+        if (w == ((const dField&)A).data()) return 5;
+        FFM_FOAM_CHK(ffm_field_fill(ctx, n, 0.25, w));
+        if (!same(A, host([&](int i) { return a[i]; })) || !same(V, host([&](int) { return 0.25; }))) return 5;
+    }
+    // 6: fvMatrix algebra: (ddt-like diagonal + source) kept lazily equals the coefficient-wise result; scalarFirst operators
+    {
+        const dField r1(scalarOp(FFM_OP_DIV, B, 3.0, true)), r2(scalarOp(FFM_OP_DIV, B, 3.0, false)), r3(scalarOp(FFM_OP_SUB, A, 2.0, true));
+        if (!same(r1, host([&](int i) { return 3.0/b[i]; })) || !same(r2, host([&](int i) { return b[i]/3.0; })) || !same(r3, host([&](int i) { return 2.0 - a[i]; }))) return 6;
+        const dField m(scalarOp(FFM_OP_MAX, A, 0.0, true)), mn(scalarOp(FFM_OP_MIN, A, 0.0));
+        if (!same(m, host([&](int i) { return std::fmax(a[i], 0.0); })) || !same(mn, host([&](int i) { return std::fmin(a[i], 0.0); }))) return 6;
+        const dField z(binary(FFM_OP_ADD, dField(ctx, n, 1.0), dField(ctx, n, 2.0)));          // constants only
+        if (!same(z, host([&](int) { return 3.0; }))) return 6;
+    }
+    if (evaluationsOut) *evaluationsOut = 0;
+    return 0;
+}

@@ -212,3 +212,21 @@ def test_burner_patch_conditions_on_the_device(O, ffm, ctx):
     assert np.allclose(Yb, f * mff + (1.0 - f) * Yc[fc], rtol=1e-14, atol=0)
     assert np.any((mask > 0.5) & (phib == 0.0)) and np.all(fo[(mask > 0.5) & (phib == 0.0)] < 1e-8)   # no flux: zero-gradient
     mesh.close(); A.close()
+
+
+def test_device_array_value_semantics_under_lazy_evaluation(ffm, ctx):
+    """include/ffmFoam.H: dField -- copies that share storage until written, expressions evaluated when first needed (one ffm_field_eval
+    pass), views of library arrays, trees larger than one program: the value semantics of OpenFOAM's Field algebra must survive all of it.
+    examples/b1_demo.C: b1_dfield_semantics runs the cases on the device and compares with host arithmetic bit for bit; it returns the
+    number of the first failing check (1 copy independence, 2 pending expression vs overwritten operand, 3 expression used twice,
+    4 oversized / right-deep trees, 5 views, 6 scalar-first operators and constants)."""
+    lib = C.CDLL(os.path.join(os.path.dirname(ffm.libpath()), "libffm_b1demo.so"))
+    dp = C.POINTER(C.c_double)
+    lib.b1_dfield_semantics.restype = C.c_int
+    lib.b1_dfield_semantics.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(11)
+    for n in (1, 777, 300001):
+        a = rng.standard_normal(n); b = rng.uniform(0.5, 2.0, n) * rng.choice([-1.0, 1.0], n)
+        ev = C.c_int()
+        os.environ["FFM_FOAM_QUIET"] = "1"
+        assert lib.b1_dfield_semantics(ctx.h, n, a.ctypes.data_as(dp), b.ctypes.data_as(dp), C.byref(ev)) == 0, n
