@@ -44,23 +44,30 @@ extern "C" int ffm_mesh_create(ffm_ldu *A, const double *V, const double *C, con
     m->B = m->patchOff[nPatches];
     const int B = m->B;
     // face geometry: caller (LDU) face order -> native
-    auto toNative = [&](const double *src, double fill) {
-        std::vector<double> v(std::max(nNat, 1), fill);
-        const int *c2n = A->h_callerToNative.data(); double *vp = v.data();
-        ffm_parallel_for(F, [=](long lo, long hi) { for (long f = lo; f < hi; f++) vp[c2n[f]] = src[f]; });      // (distinct destinations)
-        return v;
-    };
+    // (one staging array for all six face fields: filled and scattered by the host threads, then uploaded)
+    std::vector<double> stage;
+    stage.reserve(std::max(nNat, 1));
     int rc = FFM_OK;
-    std::vector<double> hV(V, V + N);
-    if ((rc = up(m->ctx, &m->V, hV))) return rc;
+    auto upNative = [&](double **dst, const double *src, double fill) -> int {
+        if (stage.empty()) stage.resize(std::max(nNat, 1));
+        const int *c2n = A->h_callerToNative.data(); double *vp = stage.data();
+        ffm_parallel_for(nNat, [=](long lo, long hi) { for (long q = lo; q < hi; q++) vp[q] = fill; });
+        ffm_parallel_for(F, [=](long lo, long hi) { for (long f = lo; f < hi; f++) vp[c2n[f]] = src[f]; });      // (distinct destinations)
+        return up(m->ctx, dst, stage);
+    };
+    auto upCells = [&](double **dst, const double *src) -> int {          // straight from the caller's array
+        FFM_HIP(hipMalloc((void **)dst, sizeof(double) * std::max<size_t>(N, 1)));
+        return ffm_h2d(m->ctx, *dst, src, sizeof(double) * (size_t)N);
+    };
+    if ((rc = upCells(&m->V, V))) return rc;
     for (int d = 0; d < 3; d++) {
-        std::vector<double> c(C + (size_t)d * N, C + (size_t)(d + 1) * N);
-        if ((rc = up(m->ctx, &m->C[d], c))) return rc;
-        if ((rc = up(m->ctx, &m->Sf[d], toNative(Sf + (size_t)d * F, 0.0)))) return rc;
+        if ((rc = upCells(&m->C[d], C + (size_t)d * N))) return rc;
+        if ((rc = upNative(&m->Sf[d], Sf + (size_t)d * F, 0.0))) return rc;
     }
-    if ((rc = up(m->ctx, &m->magSf, toNative(magSf, 0.0)))) return rc;
-    if ((rc = up(m->ctx, &m->delta, toNative(deltaCoeffs, 0.0)))) return rc;
-    if ((rc = up(m->ctx, &m->w, toNative(weights, 0.5)))) return rc;
+    if ((rc = upNative(&m->magSf, magSf, 0.0))) return rc;
+    if ((rc = upNative(&m->delta, deltaCoeffs, 0.0))) return rc;
+    if ((rc = upNative(&m->w, weights, 0.5))) return rc;
+    std::vector<double>().swap(stage);
     // boundary
     std::vector<int> bc(std::max(B, 1), 0);
     std::vector<double> bS[3], bM(std::max(B, 1), 0.0), bD(std::max(B, 1), 0.0);
@@ -668,9 +675,11 @@ extern "C" int ffm_mesh_set_face_centres(ffm_mesh *m, const double *Cf)
 {
     CHECK_M(m);
     if (!Cf) return FFM_ERR_ARG;
+    std::vector<double> v(std::max(m->nNat, 1));          // one staging array, filled and scattered by the host threads
     for (int d = 0; d < 3; d++) {
-        std::vector<double> v(std::max(m->nNat, 1), 0.0);
-        for (int f = 0; f < m->F; f++) v[m->A->h_callerToNative[f]] = Cf[(size_t)d * m->F + f];
+        const int *c2n = m->A->h_callerToNative.data(); double *vp = v.data(); const double *src = Cf + (size_t)d * m->F;
+        ffm_parallel_for(m->nNat, [=](long lo, long hi) { for (long q = lo; q < hi; q++) vp[q] = 0.0; });
+        ffm_parallel_for(m->F, [=](long lo, long hi) { for (long f = lo; f < hi; f++) vp[c2n[f]] = src[f]; });
         hipFree(m->Cf[d]); m->Cf[d] = nullptr;
         FFM_TRY(up(m->ctx, &m->Cf[d], v));
     }
@@ -682,9 +691,11 @@ extern "C" int ffm_mesh_set_nonorth_correction(ffm_mesh *m, const double *corrVe
 {
     CHECK_M(m);
     if (!corrVec) return FFM_ERR_ARG;
+    std::vector<double> v(std::max(m->nNat, 1));          // one staging array, filled and scattered by the host threads
     for (int d = 0; d < 3; d++) {
-        std::vector<double> v(std::max(m->nNat, 1), 0.0);
-        for (int f = 0; f < m->F; f++) v[m->A->h_callerToNative[f]] = corrVec[(size_t)d * m->F + f];
+        const int *c2n = m->A->h_callerToNative.data(); double *vp = v.data(); const double *src = corrVec + (size_t)d * m->F;
+        ffm_parallel_for(m->nNat, [=](long lo, long hi) { for (long q = lo; q < hi; q++) vp[q] = 0.0; });
+        ffm_parallel_for(m->F, [=](long lo, long hi) { for (long f = lo; f < hi; f++) vp[c2n[f]] = src[f]; });
         hipFree(m->corr[d]); m->corr[d] = nullptr;
         FFM_TRY(up(m->ctx, &m->corr[d], v));
     }

@@ -122,10 +122,10 @@ template <class T> inline int ffm_upload_vec(ffm_ctx *c, T **d, const std::vecto
 
 // Host set-up loops over cells / faces (renumbered addressing, geometry in the native layout, the reconstruction tensors): independent
 // iterations split over the host's cores (at most 16 threads; FFM_HOST_THREADS overrides; below 1M iterations: the caller's thread)
-template <class Fn> inline void ffm_parallel_for(long n, Fn fn)
+template <class Fn> inline void ffm_parallel_for(long n, Fn fn, long serialBelow = 1L << 20)
 {
     static const int nT = [] { const char *e = getenv("FFM_HOST_THREADS"); int t = e ? atoi(e) : (int)std::thread::hardware_concurrency(); return std::max(1, std::min(t, 16)); }();
-    if (n < (1L << 20) || nT == 1) { fn(0L, n); return; }
+    if (n < serialBelow || nT == 1) { fn(0L, n); return; }
     std::vector<std::thread> th;
     const long chunk = (n + nT - 1) / nT;
     for (int t = 0; t < nT; t++) { const long lo = t * chunk, hi = std::min(n, lo + chunk); if (lo < hi) th.emplace_back([=] { fn(lo, hi); }); }

@@ -25,6 +25,7 @@
 #include "ffm_internal.hpp"
 #include "ffm_device.hpp"
 #include <algorithm>
+#include <atomic>
 #include <climits>
 
 constexpr int T_RING = 4096;        // doubles (power of two)
@@ -157,21 +158,25 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
     std::vector<int> nbr((size_t)W * nOwn, -1), src((size_t)W * nOwn, -1);
     std::vector<unsigned char> exposed(nOwn, 0);
     auto isExt = [&](int c, int nb) { return grpOfCell[nb] != grpOfCell[c] || std::abs(c - nb) > T_RINGD; };
-    for (int c = 0; c < nOwn; c++) {
-        const int sl = c >> 6, lane = c & 63, wdt = (off[sl + 1] - off[sl]) / 64;
-        int k = 0;
-        for (int s = 0; s < wdt; s++) {
-            const int q = off[sl] + s * 64 + lane, e = ent[q];
-            if (e < 0) continue;
-            const int nb = fwd ? (e >> 4) : e;
-            if (nb >= nOwn) continue;
-            if (k >= W) { ok = false; return FFM_OK; }
-            nbr[(size_t)W * c + k] = nb;
-            src[(size_t)W * c + k] = fwd ? (A->h_upOff[(e >> 4) >> 6] + (e & 15) * 64 + ((e >> 4) & 63)) : q;
-            if (isExt(c, nb)) exposed[nb] = 1;
-            k++;
+    std::atomic<int> tooMany(0);
+    ffm_parallel_for(nOwn, [&](long c0_, long c1_) {
+        for (long c = c0_; c < c1_; c++) {
+            const int sl = (int)(c >> 6), lane = (int)(c & 63), wdt = (off[sl + 1] - off[sl]) / 64;
+            int k = 0;
+            for (int s = 0; s < wdt; s++) {
+                const int q = off[sl] + s * 64 + lane, e = ent[q];
+                if (e < 0) continue;
+                const int nb = fwd ? (e >> 4) : e;
+                if (nb >= nOwn) continue;
+                if (k >= W) { tooMany = 1; break; }
+                nbr[(size_t)W * c + k] = nb;
+                src[(size_t)W * c + k] = fwd ? (A->h_upOff[(e >> 4) >> 6] + (e & 15) * 64 + ((e >> 4) & 63)) : q;
+                if (isExt((int)c, nb)) exposed[nb] = 1;          // (several threads may store the same 1)
+                k++;
+            }
         }
-    }
+    });
+    if (tooMany) { ok = false; return FFM_OK; }
     // entries: runs of one level, at most T_ENT cells and T_XMAX external references; forward ascending, backward descending
     std::vector<unsigned short> code((size_t)4 * nOwn, (unsigned short)T_NONE);
     std::vector<int> grpEnt(G + 1, 0), mailIdx(nOwn, -1);
@@ -206,23 +211,30 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
         grpEnt[g + 1] = (int)rec.size();
     }
     // neighbour codes and the external lists (mailbox slots are known for every group now)
-    std::vector<int> extSrc;
-    for (size_t ei = 0; ei < rec.size(); ei++) {
-        int4 &R = rec[ei];
-        const int c0 = R.x, cnt = R.y & 0xFFFF;
-        const int gs = cnt ? grpCell[grpOfCell[c0]] : 0;
-        R.w = (int)extSrc.size();
-        int t = 0;
-        for (int c = c0; c < c0 + cnt; c++) for (int k = 0; k < W; k++) {
-            const int nb = nbr[(size_t)W * c + k];
-            if (nb < 0) continue;
-            if (isExt(c, nb)) {
-                if (mailIdx[nb] < 0) { ffm_set_error("internal: tile plan references an unpublished cell"); return FFM_ERR_ADDR; }
-                code[(size_t)4 * c + k] = (unsigned short)(T_RING + (int)(ei & 1) * T_XMAX + t); extSrc.push_back(mailIdx[nb]); t++;
-            } else code[(size_t)4 * c + k] = (unsigned short)((nb - gs) & (T_RING - 1));
+    // (the entries' external lists start at the running sum of their external counts: the entries are independent of each other)
+    size_t nExtAll = 0;
+    for (int4 &R : rec) { R.w = (int)nExtAll; nExtAll += (size_t)(R.y >> 16); }
+    std::vector<int> extSrc(nExtAll);
+    std::atomic<int> bad(0);
+    ffm_parallel_for((long)rec.size(), [&](long e0_, long e1_) {
+        for (long ei = e0_; ei < e1_; ei++) {
+            const int4 &R = rec[ei];
+            const int c0 = R.x, cnt = R.y & 0xFFFF;
+            const int gs = cnt ? grpCell[grpOfCell[c0]] : 0;
+            int t = 0;
+            for (int c = c0; c < c0 + cnt; c++) for (int k = 0; k < W; k++) {
+                const int nb = nbr[(size_t)W * c + k];
+                if (nb < 0) continue;
+                if (isExt(c, nb)) {
+                    if (mailIdx[nb] < 0 || t >= (R.y >> 16)) { bad = mailIdx[nb] < 0 ? 1 : 2; continue; }
+                    code[(size_t)4 * c + k] = (unsigned short)(T_RING + (int)(ei & 1) * T_XMAX + t); extSrc[(size_t)R.w + t] = mailIdx[nb]; t++;
+                } else code[(size_t)4 * c + k] = (unsigned short)((nb - gs) & (T_RING - 1));
+            }
+            if (t != (R.y >> 16)) bad = 2;
         }
-        if (t != (R.y >> 16)) { ffm_set_error("internal: tile plan external count mismatch"); return FFM_ERR_ADDR; }
-    }
+    }, nOwn >= (1 << 20) ? 1024 : (1L << 40));
+    if (bad == 1) { ffm_set_error("internal: tile plan references an unpublished cell"); return FFM_ERR_ADDR; }
+    if (bad) { ffm_set_error("internal: tile plan external count mismatch"); return FFM_ERR_ADDR; }
     D.nEnt = (int)rec.size(); D.nPub = nPub;
     if (recOut) *recOut = rec;
     if (grpEntOut) *grpEntOut = grpEnt;
