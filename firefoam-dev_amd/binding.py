@@ -120,6 +120,7 @@ def lib():
                        C.POINTER(Perf)], C.c_int),
         "ffm_solve_multi_d": ([vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_void_p), dp, dp,
                                C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(Perf)], C.c_int),
+        "ffm_ldu_unbind_coeffs": ([vp], C.c_int),
         "ffm_bench_spmv": ([vp, dp, dp, C.c_int, hp], C.c_int),
         "ffm_bench_precond": ([vp, C.c_int, dp, dp, C.c_int, hp], C.c_int),
         "ffm_debug_tile_trace": ([vp, C.c_void_p, C.c_int], C.c_int),

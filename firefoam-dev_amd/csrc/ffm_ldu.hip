@@ -633,7 +633,27 @@ static int ldu_create_impl(ffm_ctx *ctx, int nOwn, int nGhost, int F, const int 
             hipMemsetAsync(A->sweepTicket, 0, 2 * sizeof(unsigned int), ctx->stream);
         }
         if (!A->identity && (rc = upload(ctx, &A->cellPerm, a.newToOldCell))) break;
-        if (A->sweepMode == 2) { A->h_loEnt = loEnt; A->h_upNbr = upNbr; rc = ffm_tile_build(A, a.levNew, a.blNew, a.grpCell, a.bwdIsReverse ? nullptr : &a.bwdCells); A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit(); if (rc) break; }
+        if (A->sweepMode == 2) {
+            A->h_loEnt = loEnt; A->h_upNbr = upNbr;
+            // Backward order of the tiled sweeps.  Where the backward dependency levels are the mirror image of the forward ones (a box)
+            // the backward sweep walks the forward entries in reverse.  Where they are not (internal walls, unstructured graphs) it STILL
+            // can: the reverse of a topological order is a topological order of the reversed graph, and the cells of one forward level are
+            // never neighbours, so they form a valid backward entry as well -- neighbours that are then far away in the numbering go
+            // through the mailboxes like any other external.  The sweeps of such meshes therefore take the mirror kernels (fused PCG
+            // iteration, multi-system sweeps, no permutation passes); FFM_TILE_POS_BACKWARD=1 keeps the separate backward-level order in
+            // "position space" (round 2's form).
+            static const bool posBackward = getenv("FFM_TILE_POS_BACKWARD") && atoi(getenv("FFM_TILE_POS_BACKWARD")) != 0;
+            if (a.bwdIsReverse || posBackward) rc = ffm_tile_build(A, a.levNew, a.blNew, a.grpCell, a.bwdIsReverse ? nullptr : &a.bwdCells);
+            else {
+                int maxLev = 0;
+                for (int c = 0; c < nOwn; c++) maxLev = std::max(maxLev, a.levNew[c]);
+                std::vector<int> blSym(nOwn);
+                for (int c = 0; c < nOwn; c++) blSym[c] = maxLev - a.levNew[c];
+                rc = ffm_tile_build(A, a.levNew, blSym, a.grpCell, nullptr);
+            }
+            A->h_loEnt.clear(); A->h_loEnt.shrink_to_fit(); A->h_upNbr.clear(); A->h_upNbr.shrink_to_fit();
+            if (rc) break;
+        }
         {
             // XCD-aware schedule (see ffm_internal.hpp): chunks of 256 rows, binned by the eighth of their dependency level
             const int nChunks = (nOwn + 255) / 256;
@@ -837,6 +857,17 @@ extern "C" int ffm_ldu_bind_coeffs_native_d(ffm_ldu *A, const double *diag_d, co
     else { A->lower = A->upper; A->symmetric = true; }
     A->coeffEpoch++;
     if (!offDiagUnchanged) A->offDiagEpoch++;
+    return FFM_OK;
+}
+
+// after a bind: the matrix points at its own coefficient buffers again (their contents are whatever the last set call left), so that
+// nothing in the library refers to the caller's arrays once they are gone
+extern "C" int ffm_ldu_unbind_coeffs(ffm_ldu *A)
+{
+    if (!A) return FFM_ERR_ARG;
+    A->diag = A->diagBuf; A->upper = A->upperBuf;
+    if (A->symmetric || !A->lowerBuf) { A->lower = A->upper; A->symmetric = true; } else A->lower = A->lowerBuf;
+    A->coeffEpoch++; A->offDiagEpoch++;
     return FFM_OK;
 }
 

@@ -187,6 +187,8 @@ int ffm_ldu_set_coeffs_native_d(ffm_ldu *ldu, const double *diag_d,
  * (the components of a vector equation differ in the boundary diagonal only: fvMatrix::solveSegregated)               */
 int ffm_ldu_bind_coeffs_native_d(ffm_ldu *ldu, const double *diag_d, const double *upper_d,
                                  const double *lower_d, int offDiagUnchanged);
+/* ends a bind: the matrix refers to its own buffers again (contents unspecified until the next set / bind), the caller may free its arrays */
+int ffm_ldu_unbind_coeffs(ffm_ldu *ldu);
 
 /* processor patches (lduInterface / interfaceBouCoeffs / interfaceIntCoeffs):
  * face i of patch p couples cell faceCells[p][i] (caller numbering) with face i

@@ -21,10 +21,17 @@ i0 = starts[-1]
 step = rows[i0:]
 wall = step[-1][1] - step[0][0]
 busy = 0; tot = collections.Counter(); cnt = collections.Counter(); last_end = step[0][0]; gap = 0
+gapAfter = collections.Counter(); gapCnt = collections.Counter(); prev = None
 for s, e, n in step:
     tot[n] += e - s; cnt[n] += 1; busy += e - s
-    if s > last_end: gap += s - last_end
-    last_end = max(last_end, e)
+    if s > last_end:
+        gap += s - last_end
+        if prev is not None and s - last_end > 2000: gapAfter[prev] += s - last_end; gapCnt[prev] += 1      # idle time by the kernel that ran before it
+    last_end = max(last_end, e); prev = n
 print("last step: %d kernels, wall %.2f ms, kernel time %.2f ms, idle gaps %.2f ms" % (len(step), wall / 1e6, busy / 1e6, gap / 1e6))
 for n, t in tot.most_common(int(__import__('os').environ.get('TOP', '45'))):
     print("%8.2f ms %6d x %8.1f us  %s" % (t / 1e6, cnt[n], t / cnt[n] / 1e3, n[:110]))
+if __import__('os').environ.get('GAPS'):
+    print("idle time (gaps > 2 us) by the kernel that ran before the gap:")
+    for n, t in gapAfter.most_common(int(__import__('os').environ['GAPS'])):
+        print("%8.2f ms %6d x %8.1f us  after %s" % (t / 1e6, gapCnt[n], t / gapCnt[n] / 1e3, n[:100]))
