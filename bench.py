@@ -45,6 +45,12 @@ def main():
                     help="rccl: one rank per GPU over xGMI (production); host: ranks share GPUs, halo through gloo (rehearsal)")
     args = ap.parse_args()
 
+    # stdout carries the ONE JSON line and nothing else: whatever a library prints there while the run is set up (gloo's "[Gloo] Rank 0 is
+    # connected to ..." on the host transport) goes to stderr; the line itself is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -299,7 +305,8 @@ def main():
             "transport_degraded": bool(world > 1 and used_transport != requested_transport),
             "roofline": roofline, "roofline_dic_sweeps": sweeps, "class_layer": class_layer, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     case.close()
     ctx.close()
     if world > 1:
