@@ -867,7 +867,9 @@ extern "C" int ffm_ldu_unbind_coeffs(ffm_ldu *A)
     if (!A) return FFM_ERR_ARG;
     A->diag = A->diagBuf; A->upper = A->upperBuf;
     if (A->symmetric || !A->lowerBuf) { A->lower = A->upper; A->symmetric = true; } else A->lower = A->lowerBuf;
-    A->coeffEpoch++; A->offDiagEpoch++;
+    // (the layouts derived from the off-diagonal coefficients stay as they are: a following bind with offDiagUnchanged != 0 -- the same
+    // values again, e.g. the next specie sharing its coefficient arrays -- finds them current; any other set / bind renews them)
+    A->coeffEpoch++;
     return FFM_OK;
 }
 
