@@ -61,3 +61,6 @@ if os.environ.get("FFM_TRACE"):
                 print("    group %4d: start %.1f first %.1f end %.1f reloads %d" % (g, st[g], fe[g], en[g], sp[g]))
 print("box %dx%dx%d N=%d levels=%d sweep=%s tile=%d: %.4f ms per apply (2 sweeps) = %.3f us/level/sweep, %.1f GB/s of 2x60 B/cell"
       % (nx, ny, nz, N, A.nLevels, os.environ.get("FFM_SWEEP", "levels"), T, ms, ms * 1e3 / 2 / max(A.nLevels, 1), 120.0 * N / ms / 1e6))
+ctx.sync()
+wh = w.cpu().numpy()
+print("result: sum %.17g, xor of the bit patterns %016x" % (wh.sum(), int(np.bitwise_xor.reduce(wh.view(np.uint64)))))
