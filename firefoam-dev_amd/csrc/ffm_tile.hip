@@ -66,7 +66,6 @@ struct ffm_tile_plan {
     TileDir f, b;
     double *mailAll = nullptr;
     long nMail = 0;
-    int maxEntryCells = 0;           // the largest entry of either direction (k_wtile: <= 64)
     double *mailMulti = nullptr;    // [FFM_TILE_MAXSYS][nMail]: the mailboxes of the multi-system sweeps (k_tile_m), allocated on first use
     unsigned long long *trace = nullptr;    // diagnostics (ffm_debug_tile_trace): per group {start, first entry done, end, re-loads} of the last launch
     // ---- general backward order: when the backward dependency order inside a group is not the mirror image of the forward
@@ -194,7 +193,6 @@ static int build_dir(ffm_ldu *A, bool fwd, const std::vector<int> &lvl, const st
             for (int c = c0; c < c1; c++) if (exposed[c]) { code[(size_t)4 * c + 3] = (unsigned short)slot; mailIdx[c] = nPub + slot; slot++; }
             rec.push_back(make_int4(c0, (c1 - c0) | (nExt << 16), nPub, 0));
             nPub += slot;
-            A->tile->maxEntryCells = std::max(A->tile->maxEntryCells, c1 - c0);
         };
         if (fwd) {
             for (int c = gs; c < ge;) {
@@ -758,120 +756,6 @@ static int tile_up_coef_cell(ffm_ldu *A, const double **out)
     return FFM_OK;
 }
 
-// ------------------------------------------------------------------ one wave per group (prototype, FFM_WAVE_TILES=1) ---
-// The sweeps above pay one workgroup barrier and one LDS round trip per dependency level while only the four compute waves of a CU's
-// one resident workgroup work.  With groups of at most 64 cells per level (8 x 8 column tiles: FFM_TILE=8) a group is ONE WAVE's work:
-// k_wtile gives every wave a group of its own -- its own ring in LDS (W_RING entries), its own externals, no workgroup barrier at all --
-// and lets the SIMDs hide the per-level latency by running several such waves each.  Same plan, same arithmetic, same mailboxes.
-// Measured in DESIGN.md section 4; not wired into the fused PCG / multi-system / Gauss-Seidel forms.
-__global__ void k_wtile_ticket(unsigned int *ticket, unsigned int v) { ticket[0] = v; }
-constexpr int W_RING = 1024;                    // ring entries per wave (power of two; in-ring distances of 8 x 8 tiles are <= a few levels of 64)
-constexpr int W_LDS = W_RING + 2 * T_XMAX + 1;
-constexpr int W_WAVES = 4;                      // waves (groups) per workgroup
-template <int MODE>
-__global__ __launch_bounds__(64 * W_WAVES) void k_wtile(TileView t, const double *__restrict__ ca, const double *__restrict__ dg, const double *__restrict__ r, double *w,
-                                                        unsigned tkLo, unsigned tkHi)
-{
-    static_assert(MODE == TM_FWD || MODE == TM_BWD, "DIC / DILU application");
-    constexpr bool ASC = MODE != TM_BWD;
-    constexpr int W = T_W, PF = 4;             // (read-ahead of four entries: the latency is hidden by the SIMD's other waves)
-    __shared__ double ringAll[W_WAVES][W_LDS];
-    __shared__ int shAbortAll[W_WAVES];
-    const unsigned wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    double *const ring = ringAll[wv];
-    int *const shAbort = &shAbortAll[wv];
-    unsigned tk = 0;
-    if (lane == 0) { tk = atomicAdd(&t.ticket[0], 1u); *shAbort = 0; }
-    tk = __builtin_amdgcn_readfirstlane(tk);
-    if (tk < tkLo || tk >= tkHi) return;                         // (the grid is rounded up to whole workgroups: the surplus waves leave)
-    const int kq = (int)(tk % (unsigned)t.G);
-    const int g = ASC ? kq : t.G - 1 - kq;
-    const unsigned gs = (unsigned)__builtin_amdgcn_readfirstlane(t.grpCell[g]);
-    const int e0 = __builtin_amdgcn_readfirstlane(t.grpEnt[g]), e1 = __builtin_amdgcn_readfirstlane(t.grpEnt[g + 1]);
-    if (e0 >= e1) return;
-    auto slotOf = [](unsigned cd) -> unsigned { return cd == T_NONE ? (unsigned)(W_LDS - 1) : (cd < (unsigned)T_RING ? (cd & (unsigned)(W_RING - 1)) : cd - (unsigned)T_RING + (unsigned)W_RING); };
-    // read-ahead: entry records 2 PF ahead, external lists PF ahead, mailbox values T_PM ahead, cell operands PF ahead
-    int4 qrec[PF];
-    unsigned qne[PF], qxi[PF];
-    double qxv[PF];
-    unsigned pc[PF], ppb[PF];
-    bool pok[PF];
-    uint2 pq[PF];
-    double pa[PF][W], pd[PF], pv[PF];
-#define Q_REC(k, e) { qrec[k] = t.rec[min((e), e1)]; }
-#define Q_IDX(k, e) { const int4 R_ = qrec[k]; qne[k] = ((e) < e1) ? ((unsigned)R_.y >> 16) : 0u; qxi[k] = (unsigned)t.extSrc[(unsigned)R_.w + (lane < qne[k] ? lane : 0u)]; }
-#define Q_MAIL(k) { qxv[k] = t_ld(&t.mail[lane < qne[k] ? qxi[k] : 0u]); }
-#define Q_PUT(k, e) {                                                                                    \
-        if (lane < qne[k]) {                                                                              \
-            double v_ = qxv[k];                                                                           \
-            if (__builtin_expect(t_pending(v_), 0)) v_ = t_wait_value<false>(&t.mail[qxi[k]], t.ticket, shAbort, nullptr); \
-            ring[W_RING + (((e) & 1) * T_XMAX) + lane] = v_;                                              \
-        }                                                                                                 \
-    }
-#define W_FETCH(k, e, R_) {                                                                             \
-        const unsigned cnt_ = ((e) < e1) ? ((unsigned)R_.y & 0xFFFFu) : 0u;                              \
-        const bool ok_ = lane < cnt_;                                                                    \
-        const unsigned cc_ = ok_ ? (ASC ? (unsigned)R_.x + lane : (unsigned)R_.x + cnt_ - 1u - lane) : gs; \
-        const unsigned o8_ = cc_ * 8u, o24_ = cc_ * 24u;                                                 \
-        pq[k] = *(const uint2 *)((const char *)t.code + o8_);                                            \
-        { const T3 v_ = *(const T3 *)((const char *)ca + o24_); pa[k][0] = v_.a; pa[k][1] = v_.b; pa[k][2] = v_.c; }     \
-        pd[k] = *(const double *)((const char *)dg + o8_);                                               \
-        pv[k] = (MODE == TM_FWD) ? *(const double *)((const char *)r + o8_) : *(const double *)((const char *)w + o8_); \
-        pc[k] = cc_; pok[k] = ok_; ppb[k] = (unsigned)R_.z;                                              \
-    }
-#pragma unroll
-    for (int k = 0; k < PF; k++) Q_REC(k, e0 + k);
-#pragma unroll
-    for (int k = 0; k < PF; k++) { W_FETCH(k, e0 + k, qrec[k]); Q_IDX(k, e0 + k); Q_REC(k, e0 + PF + k); }
-#pragma unroll
-    for (int k = 0; k < T_PM; k++) Q_MAIL(k);
-    for (int e = e0; e < e1; e += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-            const int ee = e + k;
-            Q_PUT(k, ee);                                           // this entry's externals into the halo buffer of its parity
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            {
-                const unsigned c = pc[k];
-                const unsigned cd[4] = {pq[k].x & 0xFFFFu, pq[k].x >> 16, pq[k].y & 0xFFFFu, pq[k].y >> 16};
-                double x[W];
-#pragma unroll
-                for (int s2 = 0; s2 < W; s2++) x[s2] = ring[slotOf(cd[s2])];
-                const double d = pd[k];
-                double val;
-                if (MODE == TM_FWD) {
-                    val = d * pv[k];
-#pragma unroll
-                    for (int s2 = 0; s2 < W; s2++) { const double nv = val - d * pa[k][s2] * x[s2]; val = (cd[s2] != T_NONE) ? nv : val; }
-                } else {
-                    val = pv[k];
-#pragma unroll
-                    for (int s2 = W - 1; s2 >= 0; s2--) { const double nv = val - d * pa[k][s2] * x[s2]; val = (cd[s2] != T_NONE) ? nv : val; }
-                }
-                if (pok[k]) { *(double *)((char *)w + c * 8u) = val; ring[(c - gs) & (unsigned)(W_RING - 1)] = val; }
-                if (pok[k] && cd[3] != T_NONE) t_st(&t.mail[ppb[k] + cd[3]], val);
-            }
-            // refill slot k: the cell operands of entry ee + PF (record in qrec[k] since the pass before), then its external list and the record after
-            W_FETCH(k, ee + PF, qrec[k]);
-            Q_IDX(k, ee + PF);
-            Q_REC(k, ee + 2 * PF);
-            Q_MAIL((k + T_PM) % PF);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-    }
-#undef Q_REC
-#undef Q_IDX
-#undef Q_MAIL
-#undef Q_PUT
-#undef W_FETCH
-}
-// every entry of both directions fits one wave
-static bool wave_tiles_ok(ffm_ldu *A)
-{
-    static const bool on = getenv("FFM_WAVE_TILES") && atoi(getenv("FFM_WAVE_TILES")) != 0;
-    return on && A->tile->mirror && !A->tile->trace && A->tile->maxEntryCells <= 64;
-}
-
 int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, double *w)
 {
     ffm_tile_plan *T = A->tile;
@@ -896,15 +780,6 @@ int ffm_tile_precond(ffm_ldu *A, int precond, bool transpose, const double *r, d
         hipLaunchKernelGGL(k_tile_permute<true>, dim3(g), dim3(256), 0, s, n, T->cellOf, (const double *)w, T->wp);
         hipLaunchKernelGGL((k_tile<TM_BWD, false, true>), dim3(T->G), dim3(T_THREADS + 64), 0, s, tview(A, T->b), cb, (const double *)nullptr, (const double *)T->rDp, r, T->wp, (double *)nullptr);
         hipLaunchKernelGGL(k_tile_permute<false>, dim3(g), dim3(256), 0, s, n, T->cellOf, (const double *)T->wp, w);
-        FFM_HIP(hipGetLastError());
-        return FFM_OK;
-    }
-    if (wave_tiles_ok(A)) {
-        const int nb = (T->G + W_WAVES - 1) / W_WAVES;
-        hipLaunchKernelGGL((k_wtile<TM_FWD>), dim3(nb), dim3(64 * W_WAVES), 0, s, tview(A, T->f), cf, (const double *)A->rD, r, w, 0u, (unsigned)T->G);
-        // the forward launch took tickets 0 .. nb*W_WAVES-1 (the surplus waves of the last workgroup return at once): the backward sweep's start at G
-        hipLaunchKernelGGL(k_wtile_ticket, dim3(1), dim3(1), 0, s, A->sweepTicket, (unsigned)T->G);
-        hipLaunchKernelGGL((k_wtile<TM_BWD>), dim3(nb), dim3(64 * W_WAVES), 0, s, tview(A, T->b), cb, (const double *)A->rD, r, w, (unsigned)T->G, 2u * (unsigned)T->G);
         FFM_HIP(hipGetLastError());
         return FFM_OK;
     }
